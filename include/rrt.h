@@ -1,0 +1,285 @@
+/*
+ * rrt.h — C ABI of the MI355X-native render hot path that replaces
+ *         rs_ray_toy's  renderprocess.rs -> integrator/ -> bvh.rs + shape/ ->
+ *         reflection.rs/material/ -> film.rs   (reference @ /root/reference/src).
+ *
+ * The reference has no FFI of its own (single Rust crate, no extern "C"); the
+ * boundary a Rust maintainer would bind is therefore defined here, one entry
+ * point per reference call it replaces (file:line cited on each prototype).
+ * INTEGRATION.md shows the matching `extern "C"` block and the ctypes stub.
+ *
+ * Conventions
+ *   - plain pointers + sizes, no C++ / torch types;
+ *   - every function returns 0 on success or a negative RRT_E* code and never
+ *     throws / aborts; rrt_last_error() gives the message for this thread;
+ *   - the reference's panics (assert!/unwrap) map to RRT_EPANIC with the same
+ *     condition in the message;
+ *   - scene data is *host* memory owned by an rrt_scene; device state is owned
+ *     by an rrt_handle (one HIP stream per handle, thread-compatible);
+ *   - ray / hit / film batches may be host or device memory (`mem` field).
+ *
+ * All reference arithmetic is f64 (geometry.rs:12-20); the scene description
+ * below therefore carries f64, and the device handle picks its compute type
+ * (RRT_F32 = product path, RRT_F64 = bit-tight parity mode) at create time.
+ */
+#ifndef RRT_H
+#define RRT_H
+
+#include <stddef.h>
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define RRT_ABI_VERSION 1
+
+/* ---- error codes ------------------------------------------------------- */
+enum {
+  RRT_OK = 0,
+  RRT_EINVAL = -1,   /* bad argument                                         */
+  RRT_EIO = -2,      /* file could not be read / written                     */
+  RRT_EPARSE = -3,   /* scene.json / OBJ syntax                              */
+  RRT_EPANIC = -4,   /* the reference would panic here (message says where)  */
+  RRT_EUNSUP = -5,   /* feature outside SURVEY §8 scope (named in message)   */
+  RRT_EDEVICE = -6,  /* HIP error / no GPU / extension not usable            */
+  RRT_ENOMEM = -7
+};
+
+/* ---- compat flags (SURVEY §8.0 quirk ledger). Default = all reference. --- */
+enum {
+  RRT_FIX_BVH_LBVH_SLICE = 1u << 0, /* Q26 off: emit_lbvh second child uses slice[split..] */
+  RRT_FIX_BVH_SAH        = 1u << 1, /* Q27 off: real 12-bucket SAH in build_upper_sah      */
+  RRT_SKIP_MIS_BSDF_RAY  = 1u << 2  /* do not trace estimate_direct's BSDF-sampled ray;
+                                       result-invariant because of Q18     */
+};
+#define RRT_FIXED_BVH (RRT_FIX_BVH_LBVH_SLICE | RRT_FIX_BVH_SAH)
+
+/* ---- enums mirrored from the reference's scene.json vocabulary ---------- */
+enum { RRT_PRIM_TRIANGLE = 0, RRT_PRIM_SPHERE = 1 };
+enum { /* material_type, renderprocess.rs:664-871 */
+  RRT_MAT_MATTE = 0, RRT_MAT_PLASTIC = 1, RRT_MAT_METAL = 2, RRT_MAT_MIRROR = 3, RRT_MAT_DEBUG = 4
+};
+enum { RRT_LIGHT_POINT = 0, RRT_LIGHT_DIFFUSE = 1 };            /* renderprocess.rs:991-1017 */
+enum { RRT_SAMPLER_HALTON = 0, RRT_SAMPLER_STRATIFIED = 1 };    /* renderprocess.rs:1306-1325 */
+enum { RRT_FILTER_BOX = 0, RRT_FILTER_TRIANGLE = 1, RRT_FILTER_GAUSSIAN = 2 };
+enum { /* integrator_type, renderprocess.rs:1399-1499 */
+  RRT_INT_PATH = 0, RRT_INT_DIRECT = 1, RRT_INT_DEBUG = 2, RRT_INT_AO = 3
+};
+enum { RRT_STRATEGY_ONE = 0, RRT_STRATEGY_ALL = 1 };
+enum { RRT_F32 = 0, RRT_F64 = 1 };
+enum { RRT_MEM_HOST = 0, RRT_MEM_DEVICE = 1 };
+
+/* ---- flattened scene description (host memory, read-only to callers) ---- */
+
+/* Transform{m, m_inv}, transform.rs:181-184, row-major 4x4 */
+typedef struct rrt_xform { double m[16]; double m_inv[16]; } rrt_xform;
+
+/* Triangle{v,n,uv,mesh}, shape/triangle.rs:63-70 (indices into the pooled arrays) */
+typedef struct rrt_tri {
+  uint32_t v[3];
+  uint32_t n[3];    /* valid iff mesh_has_n  */
+  uint32_t uv[3];   /* valid iff mesh_has_uv */
+  uint8_t mesh_has_n;   /* !mesh.n.is_empty() && !mesh.normal_indices.is_empty(), triangle.rs:80 */
+  uint8_t mesh_has_uv;  /* !mesh.uv.is_empty() && !mesh.uv_indices.is_empty(),   triangle.rs:91 */
+  uint8_t pad[2];
+} rrt_tri;
+
+/* Sphere, shape/sphere.rs:17-26 */
+typedef struct rrt_sphere {
+  int32_t xform;    /* obj_to_world (index into xforms) */
+  double radius, z_min, z_max, theta_min, theta_max, phi_max;
+} rrt_sphere;
+
+/* GeometricPrimitive (+ optional TransformedPrimitive), primitives.rs:20-30 */
+typedef struct rrt_prim {
+  uint8_t type;         /* RRT_PRIM_*                                 */
+  uint8_t pad[3];
+  uint32_t shape;       /* index into tris / spheres                  */
+  int32_t instance;     /* primitive_to_world xform index, -1 = none  */
+  uint32_t material;    /* index into materials                       */
+} rrt_prim;
+
+/* constant-texture material parameters, material/{matte,plastic,metal,mirror,debug_material}.rs */
+typedef struct rrt_material {
+  int32_t type;         /* RRT_MAT_*                                  */
+  int32_t remap_roughness;
+  double kd[3], ks[3], kr[3];
+  double eta[3], k[3];
+  double sigma, roughness, u_roughness, v_roughness;
+} rrt_material;
+
+/* PointLight lights/point.rs:13-19, DiffuseAreaLight lights/diffuse.rs:13-22 */
+typedef struct rrt_light {
+  int32_t type;         /* RRT_LIGHT_*                                */
+  int32_t n_samples;
+  double spectrum[3];   /* I (point) or Lemit (diffuse)               */
+  double p_light[3];    /* always 0,0,0 in the reference (Q17)        */
+  int32_t shape_type;   /* RRT_PRIM_* of light_shape (diffuse only)   */
+  uint32_t shape;       /* index into spheres / tris                  */
+  double area;
+} rrt_light;
+
+/* LinearBVHNode, bvh.rs:103-109 (f64 bounds as built; device narrows conservatively) */
+typedef struct rrt_bvh_node {
+  double bounds[6];     /* pmin xyz, pmax xyz                         */
+  uint32_t offset;      /* leaf: first prim in prim_order; interior: second child */
+  uint32_t n_primitives;
+  uint32_t axis;
+  uint32_t pad;
+} rrt_bvh_node;
+
+/* LensElementInterface after RealisticCamera::new, camera.rs:32-38,80-99 (metres) */
+typedef struct rrt_lens_elem { double curvature_radius, thickness, eta, aperture_radius; } rrt_lens_elem;
+
+typedef struct rrt_camera {
+  rrt_xform camera_to_world;
+  double shutter_open, shutter_close;
+  int32_t simple_weighting;
+  int32_t n_elems;
+  const rrt_lens_elem* elems;
+  double exit_pupil_bounds[64][4];   /* Bounds2f pmin.x,pmin.y,pmax.x,pmax.y; camera.rs:121-133 */
+  uint8_t exit_pupil_valid[64];      /* only slabs the path can index are computed (Q6): 0 and 63 */
+} rrt_camera;
+
+typedef struct rrt_film {
+  int32_t xres, yres;
+  int32_t crop[4];                   /* cropped_pixel_bounds x0,y0,x1,y1; film.rs:151-160 */
+  int32_t sample_bounds[4];          /* get_sample_bounds, film.rs:188-199 */
+  double diagonal;                   /* metres */
+  double physical_extent[4];         /* get_physical_extent, film.rs:200-208 */
+  int32_t filter_type;
+  double filter_radius[2];
+  double filter_alpha;
+  double filter_table[256];          /* film.rs:163-173 (incl. Q4) */
+  double scale, max_sample_luminance;
+} rrt_film;
+
+typedef struct rrt_sampler {
+  int32_t type;
+  int32_t sample_at_center;
+  uint64_t samples_per_pixel;        /* nsamp; effective = nsamp-1 (Q1) */
+  /* Halton, samplers/halton.rs:23-61 */
+  int64_t base_scales[2], base_exponents[2];
+  uint64_t sample_stride, mult_inverse[2];
+  const uint16_t* perms;             /* radical_inverse_permutations, lowdiscrepancy.rs:250-270 (seeded) */
+  size_t n_perms;
+  uint64_t perm_seed;
+  /* Stratified (oracle/host only) */
+  int32_t xsamp, ysamp, dimension, jitter;
+} rrt_sampler;
+
+typedef struct rrt_integrator {
+  int32_t type;
+  int32_t max_depth;
+  double rr_threshold;
+  int32_t light_strategy;
+  int32_t cos_sample, n_samples;
+} rrt_integrator;
+
+typedef struct rrt_scene_desc {
+  uint32_t abi_version, flags;
+  /* pooled mesh data (TriangleMesh, triangle.rs:16-28) */
+  const double* positions; size_t n_positions;   /* xyz triples */
+  const double* normals;   size_t n_normals;
+  const double* uvs;       size_t n_uvs;         /* uv pairs */
+  const rrt_tri* tris;       size_t n_tris;
+  const rrt_sphere* spheres; size_t n_spheres;
+  const rrt_xform* xforms;   size_t n_xforms;
+  const rrt_prim* prims;     size_t n_prims;     /* aggregate input order, renderprocess.rs:1178-1304 */
+  const rrt_material* materials; size_t n_materials;
+  const rrt_light* lights;   size_t n_lights;    /* scene.lights; infinite_lights unsupported */
+  /* BVHAccel, bvh.rs:116-121 */
+  const rrt_bvh_node* bvh_nodes; size_t n_bvh_nodes;
+  const uint32_t* prim_order;    size_t n_prim_order;  /* ordered_prims -> index into prims */
+  uint32_t max_prims_in_node, bvh_depth;
+  double world_bound[6];
+  rrt_camera camera;
+  rrt_film film;
+  rrt_sampler sampler;
+  rrt_integrator integrator;
+} rrt_scene_desc;
+
+typedef struct rrt_scene rrt_scene;    /* owns every array above */
+typedef struct rrt_handle rrt_handle;  /* device state            */
+
+/* ---- batches ------------------------------------------------------------ */
+typedef struct rrt_rays {   /* SoA; element type follows the handle's precision */
+  int32_t mem;              /* RRT_MEM_*                                          */
+  int32_t precision;        /* RRT_F32 / RRT_F64 of the arrays below              */
+  const void *ox, *oy, *oz, *dx, *dy, *dz, *tmax;
+} rrt_rays;
+
+typedef struct rrt_hits {
+  int32_t mem, precision;
+  void* t;                  /* ray.t_max after traversal (unchanged if miss)      */
+  int32_t* prim;            /* index into prim_order (traversal order), -1 = miss */
+  void *u, *v;              /* barycentrics of the winning hit                    */
+  uint32_t* nodes_visited;  /* optional (may be NULL): per-ray counters, §8(d)    */
+  uint32_t* prims_tested;
+} rrt_hits;
+
+typedef struct rrt_render_stats {
+  uint64_t camera_samples;      /* W*H*(nsamp-1) in range                         */
+  uint64_t camera_rays;         /* samples with weight>0: integrator/mod.rs:101   */
+  uint64_t closest_queries, any_queries;
+  uint64_t nodes_visited, prims_tested;   /* when counting is enabled             */
+  double ms_total, ms_raygen, ms_closest, ms_any, ms_shade, ms_film;
+  uint64_t closest_launches, any_launches;
+} rrt_render_stats;
+
+/* ---- host side: scene build (stays on the host in the north_star) -------- */
+
+/* deploy_render's loader half: renderprocess.rs:92-105 make_scene + make_integrator
+ * (incl. objparser.rs parse_obj, BVHAccel::new bvh.rs:307, RealisticCamera::new camera.rs:66). */
+int rrt_scene_load(const char* scene_json_path, uint32_t flags, uint64_t perm_seed, rrt_scene** out);
+/* same, JSON text + root dir for relative assets (renderprocess.rs:94-99,114-120) */
+int rrt_scene_load_str(const char* json_text, const char* root_dir, uint32_t flags, uint64_t perm_seed,
+                       rrt_scene** out);
+const rrt_scene_desc* rrt_scene_desc_of(const rrt_scene*);
+void rrt_scene_free(rrt_scene*);
+/* the reference's non-fatal eprintln! diagnostics raised while loading (unsupported texture types, ...) */
+size_t rrt_scene_warning_count(const rrt_scene*);
+const char* rrt_scene_warning(const rrt_scene*, size_t i);
+
+/* Film::write_image film.rs:323-366 (Q3 already folded into w) + write_image renderprocess.rs:1501-1530.
+ * film_xyzw: W*H*4 host floats/doubles (X,Y,Z sums and filter_weight_sum per pixel). */
+int rrt_resolve_rgba8(const void* film_xyzw, int precision, int w, int h, double scale, uint8_t* rgba);
+int rrt_write_png(const char* path, const uint8_t* rgba, int w, int h);
+
+/* ---- device side --------------------------------------------------------- */
+int rrt_device_count(void);
+/* uploads scene (flattened to world space, SoA), allocates wavefront pools */
+int rrt_create(int device, const rrt_scene_desc* desc, int precision, rrt_handle** out);
+void rrt_destroy(rrt_handle*);
+/* raw hipStream_t of the handle (for event timing by the caller) */
+void* rrt_stream(rrt_handle*);
+
+/* BVHAccel::intersect bvh.rs:183-236 + Triangle/Sphere::intersect (closest = "last accepted", Q10) */
+int rrt_trace_closest(rrt_handle*, const rrt_rays* rays, size_t n, rrt_hits* out);
+/* BVHAccel::intersect_p bvh.rs:124-173 + Triangle::intersect_p (Q11) */
+int rrt_trace_any(rrt_handle*, const rrt_rays* rays, size_t n, uint8_t* occluded /* mem as rays->mem */);
+
+/* ISampler::get_camerasample samplers/mod.rs:28-34 + RealisticCamera::generate_ray_differential
+ * camera.rs:582-628 for sample_num in [s0,s1) of every pixel in [x0,x1)x[y0,y1) (unit test surface).
+ * Outputs (host, doubles): per sample 5 sampler dims, ray o(3) d(3), weight. Layout [pixel][sample]. */
+int rrt_camera_samples(rrt_handle*, const int32_t rect[4], uint64_t s0, uint64_t s1,
+                       double* dims5, double* ray_od6, double* weight);
+
+/* SamplerIntegrator::si_render integrator/mod.rs:48-139 restricted to pixel rect [x0,y0,x1,y1):
+ * all samples of those pixels, Li by the scene's integrator, FilmTile::add_sample + merge_film_tile.
+ * film_xyzw: full-frame W*H*4 buffer (handle precision, host or device per film_mem); only pixels the
+ * rect's samples touch are written (+=). */
+int rrt_render_rect(rrt_handle*, const int32_t rect[4], void* film_xyzw, int film_mem,
+                    rrt_render_stats* stats /* may be NULL */);
+
+/* wavefront pool sizing: max paths in flight per pass (0 = default) */
+int rrt_set_option(rrt_handle*, const char* key, double value);
+
+const char* rrt_last_error(void);
+const char* rrt_version(void);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* RRT_H */
