@@ -80,8 +80,10 @@ typedef struct rrt_tri {
   uint32_t v[3];
   uint32_t n[3];    /* valid iff mesh_has_n  */
   uint32_t uv[3];   /* valid iff mesh_has_uv */
-  uint8_t mesh_has_n;   /* !mesh.n.is_empty() && !mesh.normal_indices.is_empty(), triangle.rs:80 */
-  uint8_t mesh_has_uv;  /* !mesh.uv.is_empty() && !mesh.uv_indices.is_empty(),   triangle.rs:91 */
+  /* Triangle::new triangle.rs:73-111. 0 = mesh.n (mesh.uv) empty; 1 = array and its index list present;
+   * 2 = array present, index list empty (the reference then uses element 0 three times). */
+  uint8_t mesh_has_n;
+  uint8_t mesh_has_uv;
   uint8_t pad[2];
 } rrt_tri;
 
@@ -208,6 +210,10 @@ typedef struct rrt_rays {   /* SoA; element type follows the handle's precision 
   int32_t mem;              /* RRT_MEM_*                                          */
   int32_t precision;        /* RRT_F32 / RRT_F64 of the arrays below              */
   const void *ox, *oy, *oz, *dx, *dy, *dz, *tmax;
+  /* optional (may be NULL): for a ray spawned on a surface, the triangle it starts on (index as returned in
+   * rrt_hits.prim), excluded from the tests; -1 = none. The reference needs no such field because f64 places
+   * the self-hit at t ~ 1e-15 < 1e-7 (triangle.rs:200,263); fp32 callers should pass it. */
+  const int32_t* skip_prim;
 } rrt_rays;
 
 typedef struct rrt_hits {

@@ -110,7 +110,7 @@ class SceneDesc(C.Structure):
 
 class Rays(C.Structure):
     _fields_ = [("mem", C.c_int32), ("precision", C.c_int32)] + [(k, C.c_void_p) for k in
-                                                                  ("ox", "oy", "oz", "dx", "dy", "dz", "tmax")]
+                                                                  ("ox", "oy", "oz", "dx", "dy", "dz", "tmax", "skip_prim")]
 
 
 class Hits(C.Structure):

@@ -1,0 +1,732 @@
+// Wavefront kernels (gfx950, wave64): camera ray generation, BVH traversal (closest / any), shading
+// (next-event estimation + BSDF sampling + Russian roulette), film accumulation. One thread = one path
+// slot; live paths are carried between kernels as index queues compacted with wave ballots (wave_push).
+#pragma once
+#include "dmath.hpp"
+
+namespace rrtd {
+
+constexpr int kBlock = 256;
+enum { C_ACTIVE = 0, C_NEXT = 1, C_SHADOW = 2, C_CAMERA_RAYS = 3, C_ERROR = 4, C_CLOSEST_Q = 5, C_ANY_Q = 6, C_NODES = 8, C_PRIMS = 10, C_COUNT = 16 };
+enum { ERR_SHADING_NORMAL = 1, ERR_STACK = 2, ERR_BETA = 4 };
+
+// ------------------------------------------------------------------------------------------------------------
+// BVH traversal: BVHAccel::intersect / intersect_p (bvh.rs:124-236), same node order, same leaf order, every
+// accepted triangle overwrites the hit and t_max (Q10), triangle tests ignore t_max, box test uses it.
+// ------------------------------------------------------------------------------------------------------------
+template <typename R>
+struct RayCtx {
+  V3<R> o, d, inv;
+  int neg[3];
+  R tmax;
+};
+
+// Bounds3::intersect_p geometry.rs:1767-1800 with gamma(3) of the arithmetic type
+template <typename R>
+RRT_DEV bool box_hit(const Node<R>& nd, const RayCtx<R>& r) {
+  const R g = R(1) + R(2) * ((R(3) * Const<R>::machine_eps) / (R(1) - R(3) * Const<R>::machine_eps));
+  R t_min = ((r.neg[0] ? nd.bmax[0] : nd.bmin[0]) - r.o.x) * r.inv.x;
+  R t_max = ((r.neg[0] ? nd.bmin[0] : nd.bmax[0]) - r.o.x) * r.inv.x;
+  R ty_min = ((r.neg[1] ? nd.bmax[1] : nd.bmin[1]) - r.o.y) * r.inv.y;
+  R ty_max = ((r.neg[1] ? nd.bmin[1] : nd.bmax[1]) - r.o.y) * r.inv.y;
+  t_max *= g;
+  ty_max *= g;
+  if (t_min > ty_max || ty_min > t_max) return false;
+  if (ty_min > t_min) t_min = ty_min;
+  if (ty_max < t_max) t_max = ty_max;
+  R tz_min = ((r.neg[2] ? nd.bmax[2] : nd.bmin[2]) - r.o.z) * r.inv.z;
+  R tz_max = ((r.neg[2] ? nd.bmin[2] : nd.bmax[2]) - r.o.z) * r.inv.z;
+  tz_max *= g;
+  if (t_min > tz_max || tz_min > t_max) return false;
+  if (tz_min > t_min) t_min = tz_min;
+  if (tz_max < t_max) t_max = tz_max;
+  return (t_min < r.tmax) && (t_max > R(0));
+}
+
+// Triangle::intersect shape/triangle.rs:226-266 (Moller-Trumbore, E2 = p2 - p0)
+template <typename R>
+RRT_DEV bool tri_closest(const Tri<R>& t, const RayCtx<R>& r, R* th, R* uh, R* vh) {
+  V3<R> p0(t.p0), p1(t.p1), p2(t.p2);
+  V3<R> E1 = p1 - p0, E2 = p2 - p0;
+  V3<R> P = cross(r.d, E2);
+  R a = dot(E1, P);
+  if (a > R(-0.0000001) && a < R(0.0000001)) return false;
+  R f = R(1) / a;
+  V3<R> T = r.o - p0;
+  R u = f * dot(T, P);
+  if (u < R(0) || u > R(1)) return false;
+  V3<R> Q = cross(T, E1);
+  R v = f * dot(r.d, Q);
+  if (v < R(0) || (u + v) > R(1)) return false;
+  R tt = f * dot(E2, Q);
+  if (tt < R(0.0000001)) return false;
+  *th = tt; *uh = u; *vh = v;
+  return true;
+}
+// Triangle::intersect_p shape/triangle.rs:167-205 (E2 = p2 - p1: Q11)
+template <typename R>
+RRT_DEV bool tri_any(const Tri<R>& t, const RayCtx<R>& r) {
+  V3<R> p0(t.p0), p1(t.p1), p2(t.p2);
+  V3<R> E1 = p1 - p0, E2 = p2 - p1;
+  V3<R> P = cross(r.d, E2);
+  R a = dot(E1, P);
+  if (a > R(-0.0000001) && a < R(0.0000001)) return false;
+  R f = R(1) / a;
+  V3<R> T = r.o - p0;
+  R u = f * dot(T, P);
+  if (u < R(0) || u > R(1)) return false;
+  V3<R> Q = cross(T, E1);
+  R v = f * dot(r.d, Q);
+  if (v < R(0) || (u + v) > R(1)) return false;
+  R tt = f * dot(E2, Q);
+  if (tt < R(0.0000001)) return false;
+  return true;
+}
+
+template <typename R>
+RRT_DEV RayCtx<R> make_ctx(V3<R> o, V3<R> d, R tmax) {
+  RayCtx<R> c;
+  c.o = o; c.d = d; c.tmax = tmax;
+  c.inv = V3<R>(R(1) / d.x, R(1) / d.y, R(1) / d.z);
+  c.neg[0] = c.inv.x < R(0); c.neg[1] = c.inv.y < R(0); c.neg[2] = c.inv.z < R(0);
+  return c;
+}
+
+// Stack policies: a private array for trees no deeper than the reference's 64 entries, a strided global
+// array for deeper (compat-built) trees the reference itself could not traverse.
+struct PrivStack {
+  uint32_t a[64];
+  RRT_DEV void put(uint32_t i, uint32_t v) { a[i] = v; }
+  RRT_DEV uint32_t get(uint32_t i) const { return a[i]; }
+};
+struct GlobStack {
+  uint32_t* base;
+  uint32_t stride;
+  RRT_DEV void put(uint32_t i, uint32_t v) { base[(size_t)i * stride] = v; }
+  RRT_DEV uint32_t get(uint32_t i) const { return base[(size_t)i * stride]; }
+};
+
+// Spawned rays start exactly on their triangle (spawn_ray applies no offset, Q8) and the reference relies on
+// f64 to see that triangle again at t ~ 1e-15 < 1e-7. In fp32 the same test returns |t| ~ 1e-6, so the fp32
+// path excludes the originating triangle instead — equivalent in exact arithmetic, because a ray meets its own
+// triangle's plane only at t = 0. The same holds for every triangle *coplanar* with it (the other half of a
+// quad, and — for shadow rays — the sheared triangle Triangle::intersect_p really tests, Q11), so the exclusion
+// is by plane id. The f64 parity mode keeps the reference behaviour (skip = -1).
+template <typename R> RRT_DEV int self_prim(int prim) { return sizeof(R) == 4 ? prim : -1; }
+template <typename R> RRT_DEV uint32_t skip_plane_of(const SceneDev<R>& s, int skip) { return skip >= 0 ? s.tris[skip].plane : 0xffffffffu; }
+
+template <typename R, typename Stack>
+RRT_DEV int traverse_closest(const SceneDev<R>& s, RayCtx<R>& r, Stack& st, int skip, R* hu, R* hv, uint32_t* nn, uint32_t* np) {
+  int hit = -1;
+  const uint32_t skip_plane = skip_plane_of(s, skip);
+  uint32_t to_visit = 0, cur = 0, cn = 0, cp = 0;
+  if (s.n_nodes == 0) return -1;
+  while (true) {
+    const Node<R> nd = s.nodes[cur];
+    cn++;
+    if (box_hit(nd, r)) {
+      const uint32_t nprims = nd.meta >> 2;
+      if (nprims > 0) {
+        for (uint32_t i = 0; i < nprims; i++) {
+          cp++;
+          R t, u, v;
+          const Tri<R> tr = s.tris[nd.offset + i];
+          if (tr.plane == skip_plane) continue;
+          if (tri_closest(tr, r, &t, &u, &v)) { r.tmax = t; hit = (int)(nd.offset + i); *hu = u; *hv = v; }
+        }
+        if (to_visit == 0) break;
+        cur = st.get(--to_visit);
+      } else {
+        if (r.neg[nd.meta & 3]) { st.put(to_visit++, cur + 1); cur = nd.offset; }
+        else { st.put(to_visit++, nd.offset); cur = cur + 1; }
+      }
+    } else {
+      if (to_visit == 0) break;
+      cur = st.get(--to_visit);
+    }
+  }
+  *nn = cn; *np = cp;
+  return hit;
+}
+template <typename R, typename Stack>
+RRT_DEV bool traverse_any(const SceneDev<R>& s, const RayCtx<R>& r, Stack& st, int skip, uint32_t* nn, uint32_t* np) {
+  uint32_t to_visit = 0, cur = 0, cn = 0, cp = 0;
+  bool found = false;
+  const uint32_t skip_plane = skip_plane_of(s, skip);
+  if (s.n_nodes == 0) return false;
+  while (true) {
+    const Node<R> nd = s.nodes[cur];
+    cn++;
+    if (box_hit(nd, r)) {
+      const uint32_t nprims = nd.meta >> 2;
+      if (nprims > 0) {
+        for (uint32_t i = 0; i < nprims; i++) {
+          cp++;
+          const Tri<R> tr = s.tris[nd.offset + i];
+          if (tr.plane == skip_plane) continue;
+          if (tri_any(tr, r)) { found = true; break; }
+        }
+        if (found) break;
+        if (to_visit == 0) break;
+        cur = st.get(--to_visit);
+      } else {
+        if (r.neg[nd.meta & 3]) { st.put(to_visit++, cur + 1); cur = nd.offset; }
+        else { st.put(to_visit++, nd.offset); cur = cur + 1; }
+      }
+    } else {
+      if (to_visit == 0) break;
+      cur = st.get(--to_visit);
+    }
+  }
+  *nn = cn; *np = cp;
+  return found;
+}
+
+// Closest-hit kernel. `queue` maps launch index -> slot (nullptr = identity); `count` is read on device so
+// the host never synchronises between bounces. Optional per-ray counters feed the roofline's byte model.
+template <typename R, bool DEEP, bool COUNT>
+__global__ void __launch_bounds__(kBlock) k_closest(SceneDev<R> s, Pools<R> p, const uint32_t* queue, const uint32_t* count, uint32_t n_fixed,
+                                                     uint32_t* deep_stack, uint32_t deep_stride, uint32_t* nodes_out, uint32_t* prims_out,
+                                                     unsigned long long* totals) {
+  const uint32_t i = blockIdx.x * blockDim.x + threadIdx.x;
+  const uint32_t n = count ? *count : n_fixed;
+  if (i >= n) return;
+  const uint32_t slot = queue ? queue[i] : i;
+  RayCtx<R> r = make_ctx(V3<R>(p.ox[slot], p.oy[slot], p.oz[slot]), V3<R>(p.dx[slot], p.dy[slot], p.dz[slot]), p.tmax[slot]);
+  R hu = 0, hv = 0;
+  uint32_t nn = 0, np = 0;
+  int hit;
+  const int skip = p.skip[slot];
+  if (DEEP) { GlobStack st{deep_stack + i, deep_stride}; hit = traverse_closest(s, r, st, skip, &hu, &hv, &nn, &np); }
+  else { PrivStack st; hit = traverse_closest(s, r, st, skip, &hu, &hv, &nn, &np); }
+  p.ht[slot] = r.tmax; p.hprim[slot] = hit; p.hu[slot] = hu; p.hv[slot] = hv;
+  if (COUNT) {
+    if (nodes_out) { nodes_out[slot] = nn; prims_out[slot] = np; }
+    if (totals) { atomicAdd(&totals[0], (unsigned long long)nn); atomicAdd(&totals[1], (unsigned long long)np); }
+  }
+}
+
+// Any-hit kernel over the shadow queue: VisibilityTester::unoccluded (lights/mod.rs:60-66); unoccluded paths
+// add their pending contribution to L (estimate_direct integrator/mod.rs:459-481).
+template <typename R, bool DEEP, bool COUNT>
+__global__ void __launch_bounds__(kBlock) k_shadow(SceneDev<R> s, Pools<R> p, const uint32_t* queue, const uint32_t* count,
+                                                    uint32_t* deep_stack, uint32_t deep_stride, unsigned long long* totals) {
+  const uint32_t i = blockIdx.x * blockDim.x + threadIdx.x;
+  if (i >= *count) return;
+  const uint32_t slot = queue[i];
+  RayCtx<R> r = make_ctx(V3<R>(p.sox[slot], p.soy[slot], p.soz[slot]), V3<R>(p.sdx[slot], p.sdy[slot], p.sdz[slot]), p.stmax[slot]);
+  uint32_t nn = 0, np = 0;
+  bool occ;
+  const int skip = p.sskip[slot];
+  if (DEEP) { GlobStack st{deep_stack + i, deep_stride}; occ = traverse_any(s, r, st, skip, &nn, &np); }
+  else { PrivStack st; occ = traverse_any(s, r, st, skip, &nn, &np); }
+  if (!occ) { p.lr[slot] += p.ldr[slot]; p.lg[slot] += p.ldg[slot]; p.lb[slot] += p.ldb[slot]; }
+  if (COUNT && totals) { atomicAdd(&totals[0], (unsigned long long)nn); atomicAdd(&totals[1], (unsigned long long)np); }
+}
+
+// Public any-hit on caller rays (rrt_trace_any): rays live in the closest-ray arrays of the pool.
+template <typename R, bool DEEP>
+__global__ void __launch_bounds__(kBlock) k_any_public(SceneDev<R> s, Pools<R> p, uint32_t n, uint8_t* occluded, uint32_t* deep_stack, uint32_t deep_stride) {
+  const uint32_t i = blockIdx.x * blockDim.x + threadIdx.x;
+  if (i >= n) return;
+  RayCtx<R> r = make_ctx(V3<R>(p.ox[i], p.oy[i], p.oz[i]), V3<R>(p.dx[i], p.dy[i], p.dz[i]), p.tmax[i]);
+  uint32_t nn, np;
+  bool occ;
+  const int skip = p.skip[i];
+  if (DEEP) { GlobStack st{deep_stack + i, deep_stride}; occ = traverse_any(s, r, st, skip, &nn, &np); }
+  else { PrivStack st; occ = traverse_any(s, r, st, skip, &nn, &np); }
+  occluded[i] = occ ? 1 : 0;
+}
+
+// ------------------------------------------------------------------------------------------------------------
+// Camera ray generation: ISampler::get_camerasample (samplers/mod.rs:28-34) + generate_ray_differential.
+// Slot layout of a pass: slot = sample_local * npix + pixel_local, so the film kernel can sum a pixel's samples
+// in sample order without atomics.
+// ------------------------------------------------------------------------------------------------------------
+struct PassDesc {
+  int32_t rx0, ry0, rw;        // rect origin / width the pixel group is enumerated in
+  uint32_t pix_begin, npix;    // pixel group [pix_begin, pix_begin + npix) in rect-linear order
+  uint32_t s_begin, ns;        // sample_num range [s_begin, s_begin + ns)
+};
+
+template <typename R>
+__global__ void __launch_bounds__(kBlock) k_raygen(SceneDev<R> s, Pools<R> p, PassDesc pd, double* dbg_dims, double* dbg_ray, double* dbg_w) {
+  const uint32_t slot = blockIdx.x * blockDim.x + threadIdx.x;
+  const uint32_t total = pd.npix * pd.ns;
+  bool alive = false;
+  if (slot < total) {
+    const uint32_t pl = slot % pd.npix, sl = slot / pd.npix;
+    const uint32_t lin = pd.pix_begin + pl;
+    const uint32_t px = (uint32_t)pd.rx0 + lin % (uint32_t)pd.rw, py = (uint32_t)pd.ry0 + lin / (uint32_t)pd.rw;
+    const uint32_t sample_num = pd.s_begin + sl;
+    const uint32_t index = halton_pixel_offset(s, px, py) + sample_num * s.stride;
+    const double d0 = halton_dim(s, index, 0), d1 = halton_dim(s, index, 1), d2 = halton_dim(s, index, 2), d3 = halton_dim(s, index, 3);
+    // dimension 4 (time) is drawn and unused by a static scene
+    const R pfx = (R)px + to_real<R>(d0), pfy = (R)py + to_real<R>(d1);
+    const R lx = to_real<R>(d2) + R(0.5), ly = to_real<R>(d3) + R(0.5);  // Q5
+    RayT<R> ray;
+    const R w = generate_ray_differential(s, pfx, pfy, lx, ly, &ray);
+    alive = w > R(0);
+    p.pixel[slot] = py * (uint32_t)s.xres + px;
+    p.hindex[slot] = index;
+    p.dim_bounce[slot] = 5u;
+    p.weight[slot] = w;
+    p.pfx[slot] = pfx; p.pfy[slot] = pfy;
+    p.lr[slot] = R(0); p.lg[slot] = R(0); p.lb[slot] = R(0);
+    p.br[slot] = R(1); p.bg[slot] = R(1); p.bb[slot] = R(1);
+    if (alive) {
+      p.ox[slot] = ray.o.x; p.oy[slot] = ray.o.y; p.oz[slot] = ray.o.z;
+      p.dx[slot] = ray.d.x; p.dy[slot] = ray.d.y; p.dz[slot] = ray.d.z;
+      p.tmax[slot] = Const<R>::inf;
+      p.skip[slot] = -1;
+    }
+    if (dbg_dims) {
+      double* dd = dbg_dims + 5 * (size_t)(pl * pd.ns + sl);   // [pixel][sample]
+      dd[0] = d0; dd[1] = d1; dd[2] = d2; dd[3] = d3; dd[4] = halton_dim(s, index, 4);
+      double* rr = dbg_ray + 6 * (size_t)(pl * pd.ns + sl);
+      rr[0] = alive ? (double)ray.o.x : 0.0; rr[1] = alive ? (double)ray.o.y : 0.0; rr[2] = alive ? (double)ray.o.z : 0.0;
+      rr[3] = alive ? (double)ray.d.x : 0.0; rr[4] = alive ? (double)ray.d.y : 0.0; rr[5] = alive ? (double)ray.d.z : 0.0;
+      dbg_w[pl * pd.ns + sl] = (double)w;
+    }
+  }
+  const bool enqueue = alive && s.integrator != 3;  // AOIntegrator::li returns 0 before drawing (ao.rs:62-64)
+  const uint32_t q = wave_push(&p.counters[C_ACTIVE], enqueue);
+  if (enqueue) p.q_active[q] = slot;
+  const uint32_t cr = wave_push(&p.counters[C_CAMERA_RAYS], alive);
+  (void)cr;
+}
+
+// ------------------------------------------------------------------------------------------------------------
+// Shading
+// ------------------------------------------------------------------------------------------------------------
+template <typename R>
+struct Surf {   // the parts of SurfaceInteraction (interaction.rs:95-181) the in-scope materials read
+  V3<R> p, n, wo, sn, sdpdu;
+  uint32_t material;
+  bool ok;
+};
+
+// Triangle::intersect's SurfaceInteraction (shape/triangle.rs:267-390) rebuilt from (triangle, t, u, v)
+template <typename R>
+RRT_DEV Surf<R> build_surface(const SceneDev<R>& s, int prim, V3<R> o, V3<R> d, R t, R u, R v) {
+  Surf<R> si;
+  const Tri<R> tr = s.tris[prim];
+  V3<R> p0(tr.p0), p1(tr.p1), p2(tr.p2);
+  R uv[3][2] = {{R(0), R(0)}, {R(1), R(0)}, {R(1), R(1)}};  // get_uvs :113-128
+  uint32_t has_n = 0;
+  V3<R> vn0, vn1, vn2;
+  if (tr.shade != 0xffffffffu) {
+    const TriShade<R>& sh = s.shades[tr.shade];
+    if (sh.has_uv) for (int k = 0; k < 3; k++) { uv[k][0] = sh.uv[k][0]; uv[k][1] = sh.uv[k][1]; }
+    has_n = sh.has_n;
+    if (has_n == 1) { vn0 = V3<R>(sh.n[0]); vn1 = V3<R>(sh.n[1]); vn2 = V3<R>(sh.n[2]); }
+  }
+  R duv02[2] = {uv[0][0] - uv[2][0], uv[0][1] - uv[2][1]}, duv12[2] = {uv[1][0] - uv[2][0], uv[1][1] - uv[2][1]};
+  V3<R> dp02 = p0 - p2, dp12 = p1 - p2;
+  R determinant = duv02[0] * duv12[1] - duv02[1] * duv12[0];
+  bool degenerate_uv = rabs(determinant) < R(1e-8);
+  V3<R> dpdu, dpdv;
+  if (!degenerate_uv) {
+    R i_det = R(1) / determinant;
+    dpdu = (dp02 * duv12[1] - dp12 * duv02[1]) * i_det;
+    dpdv = (dp02 * -duv12[0] + dp12 * duv02[0]) * i_det;
+  }
+  if (degenerate_uv || len2(cross(dpdu, dpdv)) == R(0)) {
+    V3<R> ng = cross(p2 - p0, p1 - p0);
+    coordinate_system(vnormalize(ng), &dpdu, &dpdv);
+  }
+  si.p = o + d * t;
+  si.wo = -d;
+  si.n = vnormalize(cross(dp02, dp12));
+  si.sn = si.n;
+  si.sdpdu = dpdu;
+  si.material = tr.material;
+  si.ok = true;
+  if (has_n == 1) {
+    V3<R> ns = vn0 * (R(1) - u - v) + vn1 * u + vn2 * v;
+    if (len2(ns) > R(0)) ns = nnormalize(ns); else ns = si.n;
+    V3<R> ss = vnormalize(dpdu);
+    V3<R> ts = cross(ss, ns);
+    if (len2(ts) > R(0)) { ts = vnormalize(ts); ss = cross(ts, ns); }
+    else coordinate_system(ns, &ss, &ts);
+    // set_shading_geometry(.., orientation_is_authoritative = true) interaction.rs:183-202: the *geometric*
+    // normal is flipped towards the interpolated frame and stored as the shading normal (Q14) ...
+    V3<R> nn = nnormalize(cross(ss, ts));
+    si.sn = faceforward(si.n, nn);
+    si.sdpdu = ss;
+    // ... and primitives.rs:66 asserts dot(ist.n, shading.n) >= 0, i.e. panics when vn opposes the winding.
+    if (!(dot(si.n, si.sn) >= R(0))) si.ok = false;
+  }
+  return si;
+}
+
+template <typename R>
+RRT_DEV void build_bsdf(const SceneDev<R>& s, const Surf<R>& si, Bsdf<R>* b) {  // Bsdf::new reflection.rs:215-226
+  b->ns = si.sn;
+  b->ss = vnormalize(si.sdpdu);
+  b->ng = si.n;
+  b->ts = cross(b->ns, b->ss);
+  build_lobes(s.materials[si.material], b);
+}
+
+// Light::sample_li for PointLight (point.rs:55-77) and DiffuseAreaLight (diffuse.rs:63-79) over
+// Shape::sample_ref (shape/mod.rs:33-48), Sphere::sample (sphere.rs:265-285), Triangle::sample (triangle.rs:393-418)
+template <typename R>
+RRT_DEV Rgb<R> light_sample_li(const Light<R>& L, V3<R> ref_p, R u0, R u1, V3<R>* wi, R* pdf, V3<R>* p1, V3<R>* n1) {
+  if (L.type == 0) {
+    V3<R> pl(L.p_light);
+    *wi = vnormalize(pl - ref_p);
+    *pdf = R(1);
+    *p1 = pl; *n1 = V3<R>();
+    return Rgb<R>(L.spectrum) / len2(pl - ref_p);
+  }
+  V3<R> p, n;
+  if (L.shape_type == 1) {
+    V3<R> p_obj = uniform_sample_sphere(u0, u1) * L.radius;
+    n = nnormalize(aff_nrm(L.mi, p_obj));
+    p_obj = p_obj * (L.radius / len(p_obj));
+    p = aff_pt(L.m, p_obj);
+  } else {
+    V3<R> b = uniform_sample_sphere(u0, u1);  // used as barycentrics (Q19)
+    V3<R> q0(L.tp[0]), q1(L.tp[1]), q2(L.tp[2]);
+    p = q0 * b.x + q1 * b.y + q2 * b.z;
+    n = vnormalize(cross(q1 - q0, q2 - q0));
+    if (L.tri_has_n) {
+      V3<R> ns = V3<R>(L.tn[0]) * b.x + V3<R>(L.tn[1]) * b.y + V3<R>(L.tn[2]) * b.z;
+      n = faceforward(n, ns);
+    }
+  }
+  V3<R> w = p - ref_p;
+  R wl2 = len2(w), pd;
+  if (wl2 == R(0)) pd = R(0);
+  else {
+    w = vnormalize(w);
+    pd = wl2 / absdot(-w, n);
+    if (isinf(pd)) pd = R(0);
+  }
+  *pdf = pd;
+  if (pd == R(0) || len2(p - ref_p) == R(0)) { *pdf = R(0); return Rgb<R>(); }
+  *wi = vnormalize(p - ref_p);
+  *p1 = p; *n1 = n;
+  return (dot(n, -*wi) > R(0)) ? Rgb<R>(L.spectrum) : Rgb<R>();  // DiffuseAreaLight::l diffuse.rs:133-141
+}
+
+// Sphere::intersect (sphere.rs:124-259) reduced to what Shape::pdf_ref (shape/mod.rs:49-66) reads: hit point
+// and ist.n. Only needed for the MIS weight of area lights.
+template <typename R>
+RRT_DEV bool sphere_hit_for_pdf(const Light<R>& L, V3<R> ro, V3<R> rd, V3<R>* p_world, V3<R>* n_world) {
+  V3<R> oo = aff_pt(L.mi, ro), od = vnormalize(vnormalize(aff_vec(L.mi, rd)));
+  R a = od.x * od.x + od.y * od.y + od.z * od.z;
+  R b = R(2) * (od.x * oo.x + od.y * oo.y + od.z * oo.z);
+  R c = oo.x * oo.x + oo.y * oo.y + oo.z * oo.z - L.radius * L.radius;
+  R t0, t1;
+  if (!quadratic(a, b, c, &t0, &t1)) return false;
+  if (t0 > R(1999999999.0) || t1 <= R(0)) return false;
+  R th = t0;
+  if (t0 <= R(0)) { th = t1; if (th > R(1999999999.0)) return false; }
+  V3<R> ph = ro + rd * th;  // world ray (Q16)
+  if (ph.x == R(0) && ph.y == R(0)) ph.x = R(1e-5) * L.radius;
+  R phi = atan2(ph.y, ph.x);
+  if (phi < R(0)) phi += R(2) * R(RRT_PI);
+  if ((L.z_min > -L.radius && ph.z < L.z_min) || (L.z_max < L.radius && ph.z > L.z_max) || (phi > L.phi_max)) {
+    if (th == t1) return false;
+    if (t1 > R(1999999999.0)) return false;
+    th = t1;
+    ph = oo + od * th;
+    ph = ph * (L.radius / len(ph));
+    if (ph.x == R(0) && ph.y == R(0)) ph.x = R(1e-5) * L.radius;
+    phi = atan2(ph.y, ph.x);
+    if (phi < R(0)) phi += R(2) * R(RRT_PI);
+    if ((L.z_min > -L.radius && ph.z < L.z_min) || (L.z_max < L.radius && ph.z > L.z_max) || (phi > L.phi_max)) return false;
+  }
+  R theta = acos(clampr(ph.z / L.radius, R(-1), R(1)));
+  R z_radius = sqrt(ph.x * ph.x + ph.y * ph.y);
+  R inv_zr = R(1) / z_radius;
+  R cphi = ph.x * inv_zr, sphi = ph.y * inv_zr;
+  V3<R> dpdu(-L.phi_max * ph.y, L.phi_max * ph.x, R(0));
+  V3<R> dpdv = V3<R>(ph.z * cphi, ph.z * sphi, -L.radius * R(sin(theta))) * (L.theta_max - L.theta_min);
+  V3<R> n = vnormalize(cross(dpdu, dpdv));
+  *p_world = aff_pt(L.m, ph);
+  *n_world = aff_nrm(L.mi, n);
+  return true;
+}
+
+// estimate_direct's light-sampling half (integrator/mod.rs:403-481), handle_media = false, specular = false.
+// Returns true and fills the shadow ray + contribution when a visibility test is needed.
+// The BSDF-sampling half (:483-556) can only add `li * f * weight / pdf` with li = 0 (no primitive carries an
+// area light, Q18; DiffuseAreaLight::le is the trait default 0), so it is not executed: see DESIGN.md.
+template <typename R>
+RRT_DEV bool estimate_direct_light(const Surf<R>& si, const Bsdf<R>& bsdf, const Light<R>& L, R ul0, R ul1, V3<R>* so, V3<R>* sd, Rgb<R>* ld) {
+  const uint32_t flags = BXDF_ALL & ~BXDF_SPECULAR;
+  V3<R> wi, p1, n1;
+  R light_pdf = R(0);
+  Rgb<R> li = light_sample_li(L, si.p, ul0, ul1, &wi, &light_pdf, &p1, &n1);
+  if (!(light_pdf > R(0)) || li.is_black()) return false;
+  Rgb<R> f = bsdf.f(si.wo, wi, flags) * absdot(wi, si.sn);
+  R scattering_pdf = bsdf.pdf(si.wo, wi, flags);
+  if (f.is_black()) return false;
+  // spawn_ray_to_si interaction.rs:66-77 with p_error = 0 (Q8): origin = p, target = p1, Ray::new normalises d
+  // and keeps t_max = 1 - SHADOW_EPSILON (Q9)
+  *so = si.p;
+  *sd = vnormalize(p1 - si.p);
+  if (L.type == 0) *ld = f * li / light_pdf;
+  else { R w = power_heuristic1(light_pdf, scattering_pdf); *ld = li * f * w / light_pdf; }
+  return true;
+}
+
+// Distribution1D::sample_discrete sampling.rs:93-123 on the uniform light distribution
+template <typename R>
+RRT_DEV uint32_t sample_light_discrete(const SceneDev<R>& s, R u) {
+  uint32_t first = 0, len = s.n_lights + 1;
+  while (len > 0) {
+    uint32_t half = len >> 1, middle = first + half;
+    if (s.light_cdf[middle] <= u) { first = middle + 1; len -= half + 1; } else len = half;
+  }
+  uint32_t off = first - 1;
+  if (off > s.n_lights - 1) off = s.n_lights - 1;
+  return off;
+}
+
+template <typename R>
+RRT_DEV void store_shadow(Pools<R>& p, uint32_t slot, V3<R> so, V3<R> sd, Rgb<R> ld, int prim) {
+  p.sskip[slot] = self_prim<R>(prim);
+  p.sox[slot] = so.x; p.soy[slot] = so.y; p.soz[slot] = so.z;
+  p.sdx[slot] = sd.x; p.sdy[slot] = sd.y; p.sdz[slot] = sd.z;
+  p.stmax[slot] = R(1) - R(0.0001);
+  p.ldr[slot] = ld.r; p.ldg[slot] = ld.g; p.ldb[slot] = ld.b;
+}
+
+// PathIntegrator::li loop body (path.rs:74-223) for one bounce of every active path.
+template <typename R>
+__global__ void __launch_bounds__(kBlock) k_shade_path(SceneDev<R> s, Pools<R> p) {
+  const uint32_t i = blockIdx.x * blockDim.x + threadIdx.x;
+  const uint32_t n = p.counters[C_ACTIVE];
+  bool want_shadow = false, want_next = false;
+  uint32_t slot = 0;
+  if (i < n) {
+    slot = p.q_active[i];
+    const int prim = p.hprim[slot];
+    uint32_t db = p.dim_bounce[slot];
+    uint32_t dim = db & 0xffffu, bounces = db >> 16;
+    // `if !found_intersection || bounces >= max_depth { break }` (:91); emitted light is 0 (Q18)
+    if (prim >= 0 && (int)bounces < s.max_depth) {
+      V3<R> o(p.ox[slot], p.oy[slot], p.oz[slot]), d(p.dx[slot], p.dy[slot], p.dz[slot]);
+      Surf<R> si = build_surface(s, prim, o, d, p.ht[slot], p.hu[slot], p.hv[slot]);
+      if (!si.ok) { atomicOr(&p.counters[C_ERROR], (uint32_t)ERR_SHADING_NORMAL); }
+      else {
+        Bsdf<R> bsdf;
+        build_bsdf(s, si, &bsdf);
+        const uint32_t index = p.hindex[slot];
+        Rgb<R> beta(p.br[slot], p.bg[slot], p.bb[slot]);
+        // uniform_sample_one_light integrator/mod.rs:359-401 with the uniform Distribution1D (path.rs:47-49)
+        if (bsdf.num_components(BXDF_ALL & ~BXDF_SPECULAR) > 0 && s.n_lights > 0) {
+          R u_pick = to_real<R>(halton_dim(s, index, dim));
+          R ul0 = to_real<R>(halton_dim(s, index, dim + 1)), ul1 = to_real<R>(halton_dim(s, index, dim + 2));
+          dim += 5;  // 1D pick, 2D u_light, 2D u_scattering (drawn, only used by the BSDF-sampling half)
+          uint32_t ln = sample_light_discrete(s, u_pick);
+          V3<R> so, sd;
+          Rgb<R> ld;
+          if (s.light_pick_pdf != R(0) && estimate_direct_light(si, bsdf, s.lights[ln], ul0, ul1, &so, &sd, &ld)) {
+            ld = beta * (ld / s.light_pick_pdf);
+            store_shadow(p, slot, so, sd, ld, prim);
+            want_shadow = true;
+          }
+        }
+        // Sample BSDF to get new path direction (:125-148)
+        R u0 = to_real<R>(halton_dim(s, index, dim)), u1 = to_real<R>(halton_dim(s, index, dim + 1));
+        dim += 2;
+        V3<R> wi;
+        R pdf = R(0);
+        uint32_t flags = 0;
+        Rgb<R> f = bsdf.sample_f(si.wo, &wi, u0, u1, &pdf, BXDF_ALL, &flags);
+        if (!(f.is_black() || pdf == R(0))) {
+          beta = beta * (f * absdot(wi, si.sn) / pdf);
+          if (!(beta.y() > R(0)) || isinf(beta.y()) || beta.y() != beta.y()) atomicOr(&p.counters[C_ERROR], (uint32_t)ERR_BETA);  // path.rs:146-147 asserts
+          V3<R> nd = vnormalize(wi);  // spawn_ray -> Ray::new_od (Q8: no origin offset)
+          bool cont = true;
+          // Russian roulette (:214-222); eta_scale stays 1 without transmission
+          if (beta.max_component() < s.rr_threshold && bounces > 3) {
+            R q = rmax(R(1) - beta.max_component(), R(0.05));
+            R ur = to_real<R>(halton_dim(s, index, dim));
+            dim += 1;
+            if (ur < q) cont = false;
+            else beta = beta / (R(1) - q);
+          }
+          bounces += 1;
+          // the next loop iteration would trace and then break on `bounces >= max_depth` without using the
+          // hit (emission is 0): that dead closest-hit query is not issued.
+          if (cont && (int)bounces < s.max_depth) {
+            p.ox[slot] = si.p.x; p.oy[slot] = si.p.y; p.oz[slot] = si.p.z;
+            p.dx[slot] = nd.x; p.dy[slot] = nd.y; p.dz[slot] = nd.z;
+            p.tmax[slot] = Const<R>::inf;
+            p.skip[slot] = self_prim<R>(prim);
+            p.br[slot] = beta.r; p.bg[slot] = beta.g; p.bb[slot] = beta.b;
+            p.dim_bounce[slot] = (dim & 0xffffu) | (bounces << 16);
+            want_next = true;
+          }
+        }
+      }
+    }
+  }
+  const uint32_t qs = wave_push(&p.counters[C_SHADOW], want_shadow);
+  if (want_shadow) p.q_shadow[qs] = slot;
+  const uint32_t qn = wave_push(&p.counters[C_NEXT], want_next);
+  if (want_next) p.q_next[qn] = slot;
+}
+
+// DirectLighting / Debug integrators (directlighting.rs:72-132, intersect_debug.rs:56-89) as a wavefront chain:
+// one NEE launch per light (strategy all) or one (strategy one), then the specular continuation.
+// mode: light_j >= 0 -> uniform_sample_all_lights' j-th term; light_j == -1 -> uniform_sample_one_light(None).
+template <typename R>
+__global__ void __launch_bounds__(kBlock) k_shade_nee(SceneDev<R> s, Pools<R> p, int light_j, int first) {
+  const uint32_t i = blockIdx.x * blockDim.x + threadIdx.x;
+  const uint32_t n = p.counters[C_ACTIVE];
+  bool want_shadow = false;
+  uint32_t slot = 0;
+  if (i < n) {
+    slot = p.q_active[i];
+    const int prim = p.hprim[slot];
+    if (prim >= 0) {
+      V3<R> o(p.ox[slot], p.oy[slot], p.oz[slot]), d(p.dx[slot], p.dy[slot], p.dz[slot]);
+      Surf<R> si = build_surface(s, prim, o, d, p.ht[slot], p.hu[slot], p.hv[slot]);
+      if (!si.ok) atomicOr(&p.counters[C_ERROR], (uint32_t)ERR_SHADING_NORMAL);
+      else {
+        Bsdf<R> bsdf;
+        build_bsdf(s, si, &bsdf);
+        uint32_t db = p.dim_bounce[slot], dim = db & 0xffffu;
+        const uint32_t index = p.hindex[slot];
+        Rgb<R> beta(p.br[slot], p.bg[slot], p.bb[slot]);
+        if (first && s.integrator == 2) {  // Debug: l = Spectrum(0.1) on a hit (intersect_debug.rs:66-70)
+          p.lr[slot] += beta.r * R(0.1); p.lg[slot] += beta.g * R(0.1); p.lb[slot] += beta.b * R(0.1);
+        }
+        uint32_t ln;
+        R pick_pdf = R(1);
+        if (light_j >= 0) ln = (uint32_t)light_j;
+        else {
+          R u_pick = to_real<R>(halton_dim(s, index, dim));
+          dim += 1;
+          R v = u_pick * (R)s.n_lights;
+          uint32_t vi = (v != v || v <= R(0)) ? 0u : (uint32_t)v;
+          ln = vi < s.n_lights - 1 ? vi : s.n_lights - 1;
+          pick_pdf = R(1) / (R)s.n_lights;
+        }
+        R ul0 = to_real<R>(halton_dim(s, index, dim)), ul1 = to_real<R>(halton_dim(s, index, dim + 1));
+        dim += 4;  // u_light + u_scattering
+        V3<R> so, sd;
+        Rgb<R> ld;
+        if (estimate_direct_light(si, bsdf, s.lights[ln], ul0, ul1, &so, &sd, &ld)) {
+          ld = beta * (ld / pick_pdf);
+          store_shadow(p, slot, so, sd, ld, prim);
+          want_shadow = true;
+        }
+        p.dim_bounce[slot] = (dim & 0xffffu) | (db & 0xffff0000u);
+      }
+    }
+  }
+  const uint32_t qs = wave_push(&p.counters[C_SHADOW], want_shadow);
+  if (want_shadow) p.q_shadow[qs] = slot;
+}
+
+// specular_reflect (integrator/mod.rs:150-198) as the chain's continuation; specular_transmit (:199-301) finds
+// no transmissive lobe among the in-scope materials and its 2D draw lands after the recursion returns.
+// `depth` of the reference starts at 1; the high half of dim_bounce stores depth - 1.
+template <typename R>
+__global__ void __launch_bounds__(kBlock) k_shade_specular(SceneDev<R> s, Pools<R> p, int grey_only) {
+  const uint32_t i = blockIdx.x * blockDim.x + threadIdx.x;
+  const uint32_t n = p.counters[C_ACTIVE];
+  bool want_next = false;
+  uint32_t slot = 0;
+  if (i < n) {
+    slot = p.q_active[i];
+    const int prim = p.hprim[slot];
+    if (prim >= 0) {
+      uint32_t db = p.dim_bounce[slot], dim = db & 0xffffu, depth = (db >> 16) + 1;
+      if (grey_only) {  // Debug with no lights still adds the 0.1 grey
+        Rgb<R> beta(p.br[slot], p.bg[slot], p.bb[slot]);
+        p.lr[slot] += beta.r * R(0.1); p.lg[slot] += beta.g * R(0.1); p.lb[slot] += beta.b * R(0.1);
+      }
+      if ((int)(depth + 1) < s.max_depth) {
+        V3<R> o(p.ox[slot], p.oy[slot], p.oz[slot]), d(p.dx[slot], p.dy[slot], p.dz[slot]);
+        Surf<R> si = build_surface(s, prim, o, d, p.ht[slot], p.hu[slot], p.hv[slot]);
+        if (si.ok) {
+          Bsdf<R> bsdf;
+          build_bsdf(s, si, &bsdf);
+          const uint32_t index = p.hindex[slot];
+          R u0 = to_real<R>(halton_dim(s, index, dim)), u1 = to_real<R>(halton_dim(s, index, dim + 1));
+          dim += 2;
+          V3<R> wi;
+          R pdf = R(0);
+          uint32_t st = 0;
+          Rgb<R> f = bsdf.sample_f(si.wo, &wi, u0, u1, &pdf, BXDF_SPECULAR | BXDF_REFLECTION, &st);
+          if (pdf > R(0) && !f.is_black() && absdot(wi, si.sn) != R(0)) {
+            Rgb<R> beta(p.br[slot], p.bg[slot], p.bb[slot]);
+            beta = beta * (f * absdot(wi, si.sn) / pdf);
+            V3<R> nd = vnormalize(wi);
+            p.ox[slot] = si.p.x; p.oy[slot] = si.p.y; p.oz[slot] = si.p.z;
+            p.dx[slot] = nd.x; p.dy[slot] = nd.y; p.dz[slot] = nd.z;
+            p.tmax[slot] = Const<R>::inf;
+            p.skip[slot] = self_prim<R>(prim);
+            p.br[slot] = beta.r; p.bg[slot] = beta.g; p.bb[slot] = beta.b;
+            p.dim_bounce[slot] = (dim & 0xffffu) | (depth << 16);
+            want_next = true;
+          }
+        }
+      }
+    }
+  }
+  const uint32_t qn = wave_push(&p.counters[C_NEXT], want_next);
+  if (want_next) p.q_next[qn] = slot;
+}
+
+// queue rotation between bounces: active <- next, next <- 0, shadow <- 0 (single thread)
+static __global__ void k_rotate(uint32_t* c, int what) {
+  if (what == 0) { c[C_ACTIVE] = c[C_NEXT]; c[C_NEXT] = 0; c[C_SHADOW] = 0; }
+  else if (what == 1) { c[C_SHADOW] = 0; }
+  else { c[C_ACTIVE] = 0; c[C_NEXT] = 0; c[C_SHADOW] = 0; }
+}
+static __global__ void k_accumulate_counts(uint32_t* c, unsigned long long* totals) {
+  // totals[2] closest queries, totals[3] shadow queries, totals[4] camera rays
+  totals[2] += c[C_ACTIVE];
+}
+static __global__ void k_accumulate_shadow(uint32_t* c, unsigned long long* totals) { totals[3] += c[C_SHADOW]; }
+static __global__ void k_accumulate_camera(uint32_t* c, unsigned long long* totals) { totals[4] += c[C_CAMERA_RAYS]; c[C_CAMERA_RAYS] = 0; }
+
+// ------------------------------------------------------------------------------------------------------------
+// Film: FilmTile::add_sample (film.rs:77-130) + merge_film_tile (:248-263, Q3) for the box filter of radius
+// <= 0.5: every sample lands in its own pixel, so one thread owns a pixel and sums the pass's samples in sample
+// order (deterministic, no atomics). film = per pixel {X, Y, Z sums, filter_weight_sum}.
+// ------------------------------------------------------------------------------------------------------------
+template <typename R>
+__global__ void __launch_bounds__(kBlock) k_film_box(SceneDev<R> s, Pools<R> p, PassDesc pd, R* film) {
+  const uint32_t pl = blockIdx.x * blockDim.x + threadIdx.x;
+  if (pl >= pd.npix) return;
+  R cr = R(0), cg = R(0), cb = R(0), wsum = R(0);
+  uint32_t pix = 0;
+  for (uint32_t sl = 0; sl < pd.ns; sl++) {
+    const uint32_t slot = sl * pd.npix + pl;
+    pix = p.pixel[slot];
+    Rgb<R> L(p.lr[slot], p.lg[slot], p.lb[slot]);
+    // integrator/mod.rs:105-122
+    if (L.has_nan()) L = Rgb<R>();
+    else if (L.y() < R(-1e-5)) L = Rgb<R>();
+    else if (isinf(L.y())) L = Rgb<R>();
+    if (L.y() > s.max_sample_luminance) L = L * (s.max_sample_luminance / L.y());
+    const R w = p.weight[slot];
+    cr += (L.r * w) * R(1); cg += (L.g * w) * R(1); cb += (L.b * w) * R(1);  // box filter table weight 1
+    wsum += R(1);
+  }
+  // rgb_to_xyz spectrum.rs:2084-2090; filter_weight_sum is added three times per merged tile pixel (Q3)
+  R* px = film + 4 * (size_t)pix;
+  px[0] += R(0.412453) * cr + R(0.357580) * cg + R(0.180423) * cb;
+  px[1] += R(0.212671) * cr + R(0.715160) * cg + R(0.072169) * cb;
+  px[2] += R(0.019334) * cr + R(0.119193) * cg + R(0.950227) * cb;
+  px[3] += wsum; px[3] += wsum; px[3] += wsum;
+}
+
+template <typename R>
+__global__ void k_film_add(const R* src, R* dst, size_t n) {
+  size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+  if (i < n) dst[i] += src[i];
+}
+
+}  // namespace rrtd

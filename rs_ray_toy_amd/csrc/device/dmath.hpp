@@ -1,0 +1,624 @@
+// Device functions of the wavefront path tracer (gfx950): vector math, samplers, RealisticCamera ray
+// generation, BxDFs, lights. Templated on the arithmetic type R (float = product path, double = parity
+// mode whose results track the f64 oracle to rounding). Each function cites the reference lines whose
+// semantics it implements (/root/reference/src/...); formulas keep the reference's operation order.
+#pragma once
+#include "dtypes.hpp"
+
+namespace rrtd {
+
+#define RRT_DEV __device__ __forceinline__
+
+template <typename R> struct Const;
+template <> struct Const<float> {
+  static constexpr float one_minus_eps = 0.99999994f;            // 1 - 2^-24
+  static constexpr float machine_eps = 5.9604645e-8f;            // 2^-24
+  static constexpr float inf = __builtin_huge_valf();
+};
+template <> struct Const<double> {
+  static constexpr double one_minus_eps = 0.99999999999999989;   // misc.rs:19
+  static constexpr double machine_eps = 1.1102230246251565e-16;  // main.rs:53 (f64::EPSILON * 0.5)
+  static constexpr double inf = __builtin_huge_val();
+};
+#define RRT_PI 3.14159265358979323846
+#define RRT_PI_OVER_2 1.57079632679489661923
+#define RRT_PI_OVER_4 0.78539816339744830961
+
+template <typename R> RRT_DEV R rsqrt_(R x) { return sqrt(x); }
+template <typename R> RRT_DEV R rabs(R x) { return fabs(x); }
+template <typename R> RRT_DEV R rmax(R a, R b) { return fmax(a, b); }   // Rust f64::max
+template <typename R> RRT_DEV R rmin(R a, R b) { return fmin(a, b); }
+template <typename R> RRT_DEV R clampr(R v, R lo, R hi) { return v < lo ? lo : (v > hi ? hi : v); }  // misc.rs:98
+
+template <typename R>
+struct V3 {
+  R x, y, z;
+  RRT_DEV V3() : x(0), y(0), z(0) {}
+  RRT_DEV V3(R a, R b, R c) : x(a), y(b), z(c) {}
+  RRT_DEV explicit V3(const R* p) : x(p[0]), y(p[1]), z(p[2]) {}
+};
+template <typename R> RRT_DEV V3<R> operator+(V3<R> a, V3<R> b) { return {a.x + b.x, a.y + b.y, a.z + b.z}; }
+template <typename R> RRT_DEV V3<R> operator-(V3<R> a, V3<R> b) { return {a.x - b.x, a.y - b.y, a.z - b.z}; }
+template <typename R> RRT_DEV V3<R> operator-(V3<R> a) { return {-a.x, -a.y, -a.z}; }
+template <typename R> RRT_DEV V3<R> operator*(V3<R> a, R s) { return {a.x * s, a.y * s, a.z * s}; }
+template <typename R> RRT_DEV V3<R> operator/(V3<R> a, R s) { return {a.x / s, a.y / s, a.z / s}; }
+template <typename R> RRT_DEV R dot(V3<R> a, V3<R> b) { return (a.x * b.x) + (a.y * b.y) + (a.z * b.z); }
+template <typename R> RRT_DEV R absdot(V3<R> a, V3<R> b) { return rabs(dot(a, b)); }
+template <typename R> RRT_DEV V3<R> cross(V3<R> a, V3<R> b) {  // geometry.rs:1099-1107
+  return {(a.y * b.z) - (a.z * b.y), (a.z * b.x) - (a.x * b.z), (a.x * b.y) - (a.y * b.x)};
+}
+template <typename R> RRT_DEV R len2(V3<R> a) { return a.x * a.x + a.y * a.y + a.z * a.z; }
+template <typename R> RRT_DEV R len(V3<R> a) { return sqrt(len2(a)); }
+template <typename R> RRT_DEV V3<R> vnormalize(V3<R> a) { R l = len(a); return l == R(0) ? a : a / l; }  // geometry.rs:925
+template <typename R> RRT_DEV V3<R> nnormalize(V3<R> a) { return a / len(a); }                            // geometry.rs:1209
+template <typename R> RRT_DEV V3<R> faceforward(V3<R> n, V3<R> v) { return dot(n, v) < R(0) ? -n : n; }  // geometry.rs:1381
+template <typename R> RRT_DEV void coordinate_system(V3<R> v1, V3<R>* v2, V3<R>* v3) {  // geometry.rs:1146-1161
+  if (rabs(v1.x) > rabs(v1.y)) *v2 = V3<R>(-v1.z, R(0), v1.x) / R(sqrt(v1.x * v1.x + v1.z * v1.z));
+  else *v2 = V3<R>(R(0), v1.z, -v1.y) / R(sqrt(v1.y * v1.y + v1.z * v1.z));
+  *v3 = cross(v1, *v2);
+}
+
+template <typename R>
+struct Rgb {
+  R r, g, b;
+  RRT_DEV Rgb() : r(0), g(0), b(0) {}
+  RRT_DEV Rgb(R a, R c, R d) : r(a), g(c), b(d) {}
+  RRT_DEV explicit Rgb(R v) : r(v), g(v), b(v) {}
+  RRT_DEV explicit Rgb(const R* p) : r(p[0]), g(p[1]), b(p[2]) {}
+  RRT_DEV bool is_black() const { return r == R(0) && g == R(0) && b == R(0); }   // spectrum.rs:2162
+  RRT_DEV R y() const { return R(0.212671) * r + R(0.715160) * g + R(0.072169) * b; }  // spectrum.rs:2733
+  RRT_DEV R max_component() const { return rmax(rmax(r, g), b); }
+  RRT_DEV bool has_nan() const { return r != r || g != g || b != b; }
+};
+template <typename R> RRT_DEV Rgb<R> operator+(Rgb<R> a, Rgb<R> b) { return {a.r + b.r, a.g + b.g, a.b + b.b}; }
+template <typename R> RRT_DEV Rgb<R> operator-(Rgb<R> a, Rgb<R> b) { return {a.r - b.r, a.g - b.g, a.b - b.b}; }
+template <typename R> RRT_DEV Rgb<R> operator*(Rgb<R> a, Rgb<R> b) { return {a.r * b.r, a.g * b.g, a.b * b.b}; }
+template <typename R> RRT_DEV Rgb<R> operator/(Rgb<R> a, Rgb<R> b) { return {a.r / b.r, a.g / b.g, a.b / b.b}; }
+template <typename R> RRT_DEV Rgb<R> operator*(Rgb<R> a, R s) { return {a.r * s, a.g * s, a.b * s}; }
+template <typename R> RRT_DEV Rgb<R> operator/(Rgb<R> a, R s) { return {a.r / s, a.g / s, a.b / s}; }
+template <typename R> RRT_DEV Rgb<R> rgb_sqrt(Rgb<R> a) { return {R(sqrt(a.r)), R(sqrt(a.g)), R(sqrt(a.b))}; }
+template <typename R> RRT_DEV Rgb<R> rgb_clamp0(Rgb<R> a) {
+  return {clampr(a.r, R(0), Const<R>::inf), clampr(a.g, R(0), Const<R>::inf), clampr(a.b, R(0), Const<R>::inf)};
+}
+
+template <typename R> RRT_DEV bool quadratic(R a, R b, R c, R* t0, R* t1) {  // misc.rs:231-251
+  R discrim = b * b - R(4) * a * c;
+  if (discrim < R(0)) return false;
+  R root = sqrt(discrim);
+  R q = (b < R(0)) ? R(-0.5) * (b - root) : R(-0.5) * (b + root);
+  *t0 = q / a;
+  *t1 = c / q;
+  if (*t0 > *t1) { R t = *t0; *t0 = *t1; *t1 = t; }
+  return true;
+}
+
+// affine 3x4 helpers (rows of a 4x4 with last row 0 0 0 1)
+template <typename R> RRT_DEV V3<R> aff_pt(const R* m, V3<R> p) {
+  return {m[0] * p.x + m[1] * p.y + m[2] * p.z + m[3], m[4] * p.x + m[5] * p.y + m[6] * p.z + m[7],
+          m[8] * p.x + m[9] * p.y + m[10] * p.z + m[11]};
+}
+template <typename R> RRT_DEV V3<R> aff_vec(const R* m, V3<R> v) {
+  return {m[0] * v.x + m[1] * v.y + m[2] * v.z, m[4] * v.x + m[5] * v.y + m[6] * v.z, m[8] * v.x + m[9] * v.y + m[10] * v.z};
+}
+template <typename R> RRT_DEV V3<R> aff_nrm(const R* minv, V3<R> n) {  // transform.rs:506-523
+  return {minv[0] * n.x + minv[4] * n.y + minv[8] * n.z, minv[1] * n.x + minv[5] * n.y + minv[9] * n.z,
+          minv[2] * n.x + minv[6] * n.y + minv[10] * n.z};
+}
+
+// ---- wave64 queue push: one atomic per wave (ballot + popcount prefix) --------------------------------
+// Must be reached by every lane of the wave (callers keep control flow convergent up to here).
+RRT_DEV uint32_t wave_push(uint32_t* counter, bool pred) {
+  const uint64_t mask = __ballot(pred);
+  const uint32_t lane = __lane_id();
+  const uint32_t prefix = __popcll(mask & ((1ull << lane) - 1ull));
+  uint32_t base = 0;
+  if (mask != 0ull) {
+    const uint32_t leader = __ffsll((long long)mask) - 1;
+    if (lane == leader) base = atomicAdd(counter, (uint32_t)__popcll(mask));
+    base = __shfl(base, leader);
+  }
+  return base + prefix;
+}
+
+// ---- Halton (samplers/halton.rs, lowdiscrepancy.rs); values are produced in f64 in both modes ---------
+RRT_DEV uint32_t div_base(uint32_t a, const HaltonDim& hd, uint32_t fast) {
+  if (fast) return (uint32_t)(((uint64_t)a * hd.magic) >> 40);
+  return a / hd.base;
+}
+// radical_inverse_specialized lowdiscrepancy.rs:188-202
+RRT_DEV double radical_inverse_dev(uint32_t a, const HaltonDim& hd, uint32_t fast) {
+  const double inv_base = 1.0 / (double)hd.base;
+  uint64_t reversed = 0;
+  double inv_base_n = 1.0;
+  while (a != 0) {
+    uint32_t next = div_base(a, hd, fast);
+    uint32_t digit = a - next * hd.base;
+    reversed = reversed * hd.base + digit;
+    inv_base_n *= inv_base;
+    a = next;
+  }
+  return fmin((double)reversed * inv_base_n, 0.99999999999999989);
+}
+// scrambled_radical_inverse_specialized lowdiscrepancy.rs:204-227
+RRT_DEV double scrambled_radical_inverse_dev(uint32_t a, const HaltonDim& hd, const uint16_t* perm, uint32_t fast) {
+  const double inv_base = 1.0 / (double)hd.base;
+  uint64_t reversed = 0;
+  double inv_base_n = 1.0;
+  while (a > 0) {
+    uint32_t next = div_base(a, hd, fast);
+    uint32_t digit = a - next * hd.base;
+    reversed = reversed * hd.base + perm[digit];
+    inv_base_n *= inv_base;
+    a = next;
+  }
+  return fmin(inv_base_n * ((double)reversed + inv_base * (double)perm[0] / (1.0 - inv_base)), 0.99999999999999989);
+}
+// Halton::sample_dimension halton.rs:107-128 (index < 2^32 checked on the host)
+template <typename R>
+RRT_DEV double halton_dim(const SceneDev<R>& s, uint32_t index, uint32_t dim) {
+  if (s.sample_at_center && dim < 2) return 0.5;
+  if (dim == 0) {
+    uint32_t a = index >> s.base_exp0;                     // radical_inverse(0, a) = reverse_bits_64(a) * 2^-64
+    return (double)__brev(a) * 2.3283064365386963e-10;     // = rev32(a) * 2^-32 exactly, a < 2^32
+  }
+  if (dim == 1) return radical_inverse_dev(index / s.base_scale1, s.hdims[1], s.fast_div);
+  const HaltonDim hd = s.hdims[dim];
+  return scrambled_radical_inverse_dev(index, hd, s.perms + hd.perm_offset, s.fast_div);
+}
+template <typename R> RRT_DEV R to_real(double u) { return (R)u; }
+template <> RRT_DEV float to_real<float>(double u) { return fminf((float)u, Const<float>::one_minus_eps); }  // keep u < 1 after narrowing
+
+// inverse_radical_inverse lowdiscrepancy.rs:239-248
+RRT_DEV uint32_t inverse_radical_inverse_dev(uint32_t base, uint32_t inverse, uint32_t n_digits) {
+  uint32_t index = 0;
+  for (uint32_t i = 0; i < n_digits; i++) {
+    uint32_t digit = inverse % base;
+    inverse /= base;
+    index = index * base + digit;
+  }
+  return index;
+}
+// Halton::get_index_for_sample halton.rs:75-105 (dim 0 uses base_exponents[1] digits: Q24), pixel >= 0
+template <typename R>
+RRT_DEV uint32_t halton_pixel_offset(const SceneDev<R>& s, uint32_t px, uint32_t py) {
+  if (s.stride <= 1) return 0;
+  uint32_t pmx = px % 128u, pmy = py % 128u;  // K_MAX_RESOLUTION
+  uint64_t off = 0;
+  off += (uint64_t)inverse_radical_inverse_dev(2, pmx, s.base_exp1) * (uint64_t)(s.stride / s.base_scale0) * (uint64_t)s.mult_inv0;
+  off += (uint64_t)inverse_radical_inverse_dev(3, pmy, s.base_exp1) * (uint64_t)(s.stride / s.base_scale1) * (uint64_t)s.mult_inv1;
+  return (uint32_t)(off % (uint64_t)s.stride);
+}
+
+// ---- sampling.rs ------------------------------------------------------------------------------------------
+template <typename R> RRT_DEV V3<R> uniform_sample_sphere(R u0, R u1) {  // :233-243
+  R z = R(1) - R(2) * u0;
+  R r = sqrt(rmax(R(0), R(1) - z * z));
+  R phi = R(2) * R(RRT_PI) * u1;
+  return {r * R(cos(phi)), r * R(sin(phi)), z};
+}
+template <typename R> RRT_DEV V3<R> cosine_sample_hemisphere(R u0, R u1) {  // :270-304
+  R ox = u0 * R(2) - R(1), oy = u1 * R(2) - R(1);
+  R dx, dy;
+  if (ox == R(0) && oy == R(0)) { dx = R(0); dy = R(0); }
+  else {
+    R theta, r;
+    if (rabs(ox) > rabs(oy)) { r = ox; theta = R(RRT_PI_OVER_4) * (oy / ox); }
+    else { r = oy; theta = R(RRT_PI_OVER_2) - R(RRT_PI_OVER_4) * (ox / oy); }
+    dx = R(cos(theta)) * r; dy = R(sin(theta)) * r;
+  }
+  R z = sqrt(rmax(R(0), R(1) - dx * dx - dy * dy));
+  return {dx, dy, z};
+}
+template <typename R> RRT_DEV R power_heuristic1(R fp, R gp) { return (fp * fp) / (fp * fp + gp * gp); }  // :324-328, nf = ng = 1
+
+// ---- RealisticCamera (camera.rs) -----------------------------------------------------------------------------
+template <typename R> struct RayT { V3<R> o, d; };
+
+template <typename R> RRT_DEV bool refract(V3<R> wi, V3<R> n, R eta, V3<R>* wt) {  // reflection.rs:122-134
+  R cos_i = dot(n, wi);
+  R sin2_i = rmax(R(0), R(1) - cos_i * cos_i);
+  R sin2_t = eta * eta * sin2_i;
+  if (sin2_t >= R(1)) return false;
+  R cos_t = sqrt(R(1) - sin2_t);
+  *wt = (-wi) * eta + n * (eta * cos_i - cos_t);
+  return true;
+}
+// Transform::scale(1,1,-1).t(ray) then Ray::new: (x, y, -z), direction normalised twice (transform.rs:525-537)
+template <typename R> RRT_DEV RayT<R> flip_z(const RayT<R>& r) {
+  RayT<R> o;
+  o.o = V3<R>(r.o.x, r.o.y, -r.o.z);
+  o.d = vnormalize(vnormalize(V3<R>(r.d.x, r.d.y, -r.d.z)));
+  return o;
+}
+// intersect_spherical_element camera.rs:220-253
+template <typename R> RRT_DEV bool intersect_spherical(R radius, R z_center, const RayT<R>& ray, R* t, V3<R>* n) {
+  V3<R> o = ray.o - V3<R>(R(0), R(0), z_center);
+  R a = ray.d.x * ray.d.x + ray.d.y * ray.d.y + ray.d.z * ray.d.z;
+  R b = R(2) * (ray.d.x * o.x + ray.d.y * o.y + ray.d.z * o.z);
+  R c = o.x * o.x + o.y * o.y + o.z * o.z - radius * radius;
+  R t0 = 0, t1 = 0;
+  if (!quadratic(a, b, c, &t0, &t1)) return false;
+  bool use_closer = (ray.d.z > R(0)) ^ (radius < R(0));
+  *t = use_closer ? rmin(t0, t1) : rmax(t0, t1);
+  if (*t < R(0)) return false;
+  V3<R> nn = o + ray.d * *t;
+  *n = faceforward(nnormalize(nn), -ray.d);
+  return true;
+}
+// trace_lenses_from_film camera.rs:156-219. `t >= 0` is an assert in the reference (never observed to fail
+// for rays that pass the aperture tests); a failing lane is treated as a lens miss.
+template <typename R> RRT_DEV bool trace_from_film(const SceneDev<R>& s, const RayT<R>& r_camera, RayT<R>* out) {
+  R element_z = R(0);
+  RayT<R> r = flip_z(r_camera);
+  for (int i = s.n_lens - 1; i >= 0; i--) {
+    const LensElem<R> el = s.lens[i];
+    element_z -= el.thickness;
+    R t = R(0);
+    V3<R> n;
+    const bool is_stop = el.curvature_radius == R(0);
+    if (is_stop) {
+      if (r.d.z >= R(0)) return false;
+      t = (element_z - r.o.z) / r.d.z;
+    } else {
+      if (!intersect_spherical(el.curvature_radius, element_z + el.curvature_radius, r, &t, &n)) return false;
+    }
+    if (!(t >= R(0))) return false;
+    V3<R> p_hit = r.o + r.d * t;
+    R r2 = p_hit.x * p_hit.x + p_hit.y * p_hit.y;
+    if (r2 >= el.aperture_radius * el.aperture_radius) return false;
+    r.o = p_hit;
+    if (!is_stop) {
+      V3<R> w;
+      R eta_i = el.eta;
+      R eta_prev = (i > 0) ? s.lens[i - 1].eta : R(0);
+      R eta_t = (i > 0 && eta_prev != R(0)) ? eta_prev : R(1);
+      if (!refract(vnormalize(-r.d), n, eta_i / eta_t, &w)) return false;
+      r.d = w;
+    }
+  }
+  *out = flip_z(r);
+  return true;
+}
+// generate_ray camera.rs:534-580 (weight; ray in world space)
+template <typename R> RRT_DEV R generate_ray(const SceneDev<R>& s, R pfx, R pfy, R lx, R ly, RayT<R>* ray) {
+  R sx = pfx / (R)s.xres, sy = pfy / (R)s.yres;
+  R p2x = s.extent[0] * (R(1) - sx) + s.extent[2] * sx, p2y = s.extent[1] * (R(1) - sy) + s.extent[3] * sy;
+  V3<R> p_film(-p2x, p2y, R(0));
+  // sample_exit_pupil :492-521 — `(r / (diag/2)) as usize * 64` (Q6) is 0 unless r >= diag/2, then clamps to 63
+  R r_film = sqrt(p_film.x * p_film.x + p_film.y * p_film.y);
+  const R* pb = (r_film / (s.diagonal / R(2)) >= R(1)) ? s.pupil63 : s.pupil0;
+  R plx = pb[0] * (R(1) - lx) + pb[2] * lx, ply = pb[1] * (R(1) - ly) + pb[3] * ly;
+  R sin_t = r_film != R(0) ? p_film.y / r_film : R(0), cos_t = r_film != R(0) ? p_film.x / r_film : R(1);
+  R area = (pb[2] - pb[0]) * (pb[3] - pb[1]);
+  V3<R> p_rear(cos_t * plx - sin_t * ply, sin_t * plx + cos_t * ply, s.lens[s.n_lens - 1].thickness);
+  RayT<R> r_film_ray;
+  r_film_ray.o = p_film;
+  r_film_ray.d = vnormalize(p_rear - p_film);
+  RayT<R> r;
+  if (!trace_from_film(s, r_film_ray, &r)) return R(0);
+  // camera_to_world.t(ray) (double normalise), then ray.d.normalize()
+  ray->o = aff_pt(s.cam_m, r.o);
+  ray->d = vnormalize(vnormalize(vnormalize(aff_vec(s.cam_m, r.d))));
+  R cos_theta = vnormalize(r_film_ray.d).z;
+  R cos4 = (cos_theta * cos_theta) * (cos_theta * cos_theta);
+  if (s.simple_weighting) return cos4 * area / ((s.pupil0[2] - s.pupil0[0]) * (s.pupil0[3] - s.pupil0[1]));
+  R rz = s.lens[s.n_lens - 1].thickness;
+  return (s.shutter_close - s.shutter_open) * (cos4 * area) / rz * rz;
+}
+// generate_ray_differential camera.rs:582-628: the auxiliary rays only decide whether the weight survives
+template <typename R> RRT_DEV R generate_ray_differential(const SceneDev<R>& s, R pfx, R pfy, R lx, R ly, RayT<R>* ray) {
+  R wt = generate_ray(s, pfx, pfy, lx, ly, ray);
+  if (wt == R(0)) return R(0);
+  RayT<R> aux;
+  R wtx = generate_ray(s, pfx + R(0.05), pfy, lx, ly, &aux);
+  if (wtx == R(0)) wtx = generate_ray(s, pfx + R(-0.05), pfy, lx, ly, &aux);
+  if (wtx == R(0)) return R(0);
+  R wty = generate_ray(s, pfx, pfy + R(0.05), lx, ly, &aux);
+  if (wty == R(0)) wty = generate_ray(s, pfx, pfy + R(-0.05), lx, ly, &aux);
+  if (wty == R(0)) return R(0);
+  return wt;
+}
+
+// ---- BxDFs (reflection.rs, microfacet.rs) ---------------------------------------------------------------------
+enum : uint32_t { BXDF_REFLECTION = 1, BXDF_TRANSMISSION = 2, BXDF_DIFFUSE = 4, BXDF_GLOSSY = 8, BXDF_SPECULAR = 16, BXDF_ALL = 31, BXDF_NONE = 0 };
+enum : uint32_t { LOBE_LAMBERT = 0, LOBE_OREN_NAYAR, LOBE_MICROFACET, LOBE_SPEC_REFL, LOBE_DEBUG_DIFFUSE, LOBE_DEBUG_SPECULAR };
+enum : uint32_t { FR_NOOP = 0, FR_DIELECTRIC, FR_CONDUCTOR };
+
+template <typename R> RRT_DEV R cos_theta(V3<R> w) { return w.z; }
+template <typename R> RRT_DEV R cos2_theta(V3<R> w) { return w.z * w.z; }
+template <typename R> RRT_DEV R abs_cos_theta(V3<R> w) { return rabs(w.z); }
+template <typename R> RRT_DEV R sin2_theta(V3<R> w) { return rmax(R(0), R(1) - cos2_theta(w)); }
+template <typename R> RRT_DEV R sin_theta(V3<R> w) { return sqrt(sin2_theta(w)); }
+template <typename R> RRT_DEV R tan_theta(V3<R> w) { return sin_theta(w) / cos_theta(w); }
+template <typename R> RRT_DEV R tan2_theta(V3<R> w) { return sin2_theta(w) / cos2_theta(w); }
+template <typename R> RRT_DEV R cos_phi(V3<R> w) { R st = sin_theta(w); return st == R(0) ? R(1) : clampr(w.x / st, R(-1), R(1)); }
+template <typename R> RRT_DEV R sin_phi(V3<R> w) { R st = sin_theta(w); return st == R(0) ? R(0) : clampr(w.y / st, R(-1), R(1)); }
+template <typename R> RRT_DEV bool same_hemisphere(V3<R> w, V3<R> wp) { return w.z * wp.z > R(0); }
+template <typename R> RRT_DEV V3<R> reflect(V3<R> wo, V3<R> n) { return -wo + n * R(2) * dot(wo, n); }
+
+template <typename R> RRT_DEV R fr_dielectric(R cos_i, R eta_i, R eta_t) {  // reflection.rs:145-168
+  cos_i = clampr(cos_i, R(-1), R(1));
+  if (!(cos_i > R(0))) { R t = eta_i; eta_i = eta_t; eta_t = t; cos_i = rabs(cos_i); }
+  R sin_i = sqrt(rmax(R(0), R(1) - cos_i * cos_i));
+  R sin_t = eta_i / eta_t * sin_i;
+  if (sin_t >= R(1)) return R(1);
+  R cos_t = sqrt(rmax(R(0), R(1) - sin_t * sin_t));
+  R r_parl = ((eta_t * cos_i) - (eta_i * cos_t)) / ((eta_t * cos_i) + (eta_i * cos_t));
+  R r_perp = ((eta_i * cos_i) - (eta_t * cos_t)) / ((eta_i * cos_i) + (eta_t * cos_t));
+  return (r_parl * r_parl + r_perp * r_perp) / R(2);
+}
+template <typename R> RRT_DEV Rgb<R> fr_conductor(R cos_i_in, Rgb<R> eta_i, Rgb<R> eta_t, Rgb<R> k) {  // reflection.rs:170-195
+  R cos_i = clampr(cos_i_in, R(-1), R(1));
+  Rgb<R> eta = eta_t / eta_i, eta_k = k / eta_i;
+  R cos2 = cos_i * cos_i, sin2 = R(1) - cos2;
+  Rgb<R> eta2 = eta * eta, eta_k2 = eta_k * eta_k;
+  Rgb<R> t0 = eta2 - eta_k2 - Rgb<R>(sin2);
+  Rgb<R> a2_plus_b2 = rgb_sqrt(t0 * t0 + eta2 * eta_k2 * Rgb<R>(R(4)));
+  Rgb<R> t1 = a2_plus_b2 + Rgb<R>(cos2);
+  Rgb<R> a = rgb_sqrt((a2_plus_b2 + t0) * R(0.5));
+  Rgb<R> t2 = a * R(2) * cos_i;
+  Rgb<R> rs = (t1 - t2) / (t1 + t2);
+  Rgb<R> t3 = a2_plus_b2 * cos2 + Rgb<R>(sin2 * sin2);
+  Rgb<R> t4 = t2 * sin2;
+  Rgb<R> rp = rs * (t3 - t4) / (t3 + t4);
+  return (rp + rs) * Rgb<R>(R(0.5));
+}
+
+template <typename R>
+struct Lobe {
+  uint32_t kind, type, fr;
+  Rgb<R> r;
+  R a, b;              // OrenNayar A, B
+  R alpha_x, alpha_y;  // TrowbridgeReitz, sample_visible_area = true
+  Rgb<R> eta_i, eta_t, k;
+};
+
+// TrowbridgeReitzDistribution microfacet.rs:253-425
+template <typename R> RRT_DEV R tr_d(const Lobe<R>& l, V3<R> wh) {
+  R tan2 = tan2_theta(wh);
+  if (isinf(tan2)) return R(0);
+  R cos4 = cos2_theta(wh) * cos2_theta(wh);
+  R cp = cos_phi(wh), sp = sin_phi(wh);
+  R e = ((cp * cp) / (l.alpha_x * l.alpha_x) + (sp * sp) / (l.alpha_y * l.alpha_y)) * tan2;
+  return R(1) / (R(RRT_PI) * l.alpha_x * l.alpha_y * cos4 * (R(1) + e) * (R(1) + e));
+}
+template <typename R> RRT_DEV R tr_lambda(const Lobe<R>& l, V3<R> w) {
+  R abs_tan = rabs(tan_theta(w));
+  if (isinf(abs_tan)) return R(0);
+  R cp = cos_phi(w), sp = sin_phi(w);
+  R alpha = sqrt((cp * cp) * (l.alpha_x * l.alpha_x) + (sp * sp) * (l.alpha_y * l.alpha_y));
+  R a2t2 = (alpha * abs_tan) * (alpha * abs_tan);
+  return (R(-1) + R(sqrt(R(1) + a2t2))) / R(2);
+}
+template <typename R> RRT_DEV R tr_g1(const Lobe<R>& l, V3<R> w) { return R(1) / (R(1) + tr_lambda(l, w)); }
+template <typename R> RRT_DEV R tr_g(const Lobe<R>& l, V3<R> wo, V3<R> wi) { return R(1) / (R(1) + tr_lambda(l, wo) + tr_lambda(l, wi)); }
+template <typename R> RRT_DEV R tr_pdf(const Lobe<R>& l, V3<R> wo, V3<R> wh) { return tr_d(l, wh) * tr_g1(l, wo) * absdot(wo, wh) / abs_cos_theta(wo); }
+template <typename R> RRT_DEV void tr_sample_11(R cos_t, R u1, R u2, R* slope_x, R* slope_y) {  // :268-323
+  if (cos_t > R(0.9999)) {
+    R r = sqrt(u1 / (R(1) - u1));
+    R phi = R(6.28318530718) * u2;
+    *slope_x = r * R(cos(phi));
+    *slope_y = r * R(sin(phi));
+    return;
+  }
+  R sin_t = sqrt(rmax(R(0), R(1) - cos_t * cos_t));
+  R tan_t = sin_t / cos_t;
+  R a = R(1) / tan_t;
+  R g1 = R(2) / (R(1) + R(sqrt(R(1) + R(1) / (a * a))));
+  a = R(2) * u1 / g1 - R(1);
+  R tmp = R(1) / (a * a - R(1));
+  if (tmp > R(1e10)) tmp = R(1e10);
+  R b = tan_t;
+  R d = sqrt(rmax(b * b * tmp * tmp - (a * a - b * b) * tmp, R(0)));
+  R sx1 = b * tmp - d, sx2 = b * tmp + d;
+  *slope_x = (a < R(0) || sx2 > R(1) / tan_t) ? sx1 : sx2;
+  R sg, nu2;
+  if (u2 > R(0.5)) { sg = R(1); nu2 = R(2) * (u2 - R(0.5)); } else { sg = R(-1); nu2 = R(2) * (R(0.5) - u2); }
+  R z = (nu2 * (nu2 * (nu2 * R(0.27385) - R(0.73369)) + R(0.46341))) /
+        (nu2 * (nu2 * (nu2 * R(0.093073) + R(0.309420)) - R(1)) + R(0.597999));
+  *slope_y = sg * z * R(sqrt(R(1) + *slope_x * *slope_x));
+}
+template <typename R> RRT_DEV V3<R> tr_sample(V3<R> wi, R ax, R ay, R u1, R u2) {  // :325-363
+  V3<R> ws = vnormalize(V3<R>(ax * wi.x, ay * wi.y, wi.z));
+  R sx = 0, sy = 0;
+  tr_sample_11(cos_theta(ws), u1, u2, &sx, &sy);
+  R tmp = cos_phi(ws) * sx - sin_phi(ws) * sy;
+  sy = sin_phi(ws) * sx + cos_phi(ws) * sy;
+  sx = tmp;
+  sx *= ax; sy *= ay;
+  return vnormalize(V3<R>(-sx, -sy, R(1)));
+}
+template <typename R> RRT_DEV V3<R> tr_sample_wh(const Lobe<R>& l, V3<R> wo, R u0, R u1) {  // :387-421
+  if (wo.z < R(0)) return -tr_sample(-wo, l.alpha_x, l.alpha_y, u0, u1);
+  return tr_sample(wo, l.alpha_x, l.alpha_y, u0, u1);
+}
+template <typename R> RRT_DEV Rgb<R> fresnel_eval(const Lobe<R>& l, R cos_i) {  // reflection.rs:599-615
+  if (l.fr == FR_NOOP) return Rgb<R>(R(1));
+  if (l.fr == FR_DIELECTRIC) return Rgb<R>(fr_dielectric(cos_i, l.eta_i.r, l.eta_t.r));
+  return fr_conductor(rabs(cos_i), l.eta_i, l.eta_t, l.k);
+}
+template <typename R> RRT_DEV Rgb<R> lobe_f(const Lobe<R>& l, V3<R> wo, V3<R> wi) {
+  switch (l.kind) {
+    case LOBE_LAMBERT: return l.r / R(RRT_PI);
+    case LOBE_OREN_NAYAR: {  // reflection.rs:917-941
+      R sin_i = sin_theta(wi), sin_o = sin_theta(wo), max_cos = R(0);
+      if (sin_i > R(1e-4) && sin_o > R(1e-4)) {
+        R d_cos = cos_phi(wi) * cos_phi(wo) + sin_phi(wi) * sin_phi(wo);
+        max_cos = rmax(d_cos, R(0));
+      }
+      R sin_alpha, tan_beta;
+      if (abs_cos_theta(wi) > abs_cos_theta(wo)) { sin_alpha = sin_o; tan_beta = sin_i / abs_cos_theta(wi); }
+      else { sin_alpha = sin_i; tan_beta = sin_o / abs_cos_theta(wo); }
+      return l.r / R(RRT_PI) * (l.a + l.b * max_cos * sin_alpha * tan_beta);
+    }
+    case LOBE_MICROFACET: {  // reflection.rs:971-992
+      R cos_o = abs_cos_theta(wo), cos_i = abs_cos_theta(wi);
+      V3<R> wh = wi + wo;
+      if (cos_i == R(0) || cos_o == R(0)) return Rgb<R>();
+      if (wh.x == R(0) && wh.y == R(0) && wh.z == R(0)) return Rgb<R>();
+      wh = vnormalize(wh);
+      Rgb<R> f = fresnel_eval(l, dot(wi, faceforward(wh, V3<R>(R(0), R(0), R(1)))));
+      return l.r * tr_d(l, wh) * tr_g(l, wo, wi) * f / (R(4) * cos_i * cos_o);
+    }
+    case LOBE_DEBUG_DIFFUSE: return Rgb<R>(R(0), R(1), R(0));
+    case LOBE_DEBUG_SPECULAR: return Rgb<R>(R(0), R(0), R(1));
+    default: return Rgb<R>();  // SpecularReflection::f
+  }
+}
+template <typename R> RRT_DEV R lobe_pdf(const Lobe<R>& l, V3<R> wo, V3<R> wi) {
+  if (l.kind == LOBE_MICROFACET) {  // reflection.rs:1019-1025
+    if (!same_hemisphere(wo, wi)) return R(0);
+    V3<R> wh = vnormalize(wo + wi);
+    return tr_pdf(l, wo, wh) / (R(4) * dot(wo, wh));
+  }
+  if (l.kind == LOBE_SPEC_REFL) return R(0);
+  return same_hemisphere(wo, wi) ? abs_cos_theta(wi) / R(RRT_PI) : R(0);  // BxDF::pdf default :492-498
+}
+template <typename R> RRT_DEV Rgb<R> lobe_sample_f(const Lobe<R>& l, V3<R> wo, V3<R>* wi, R u0, R u1, R* pdf) {
+  if (l.kind == LOBE_MICROFACET) {  // reflection.rs:993-1018
+    if (wo.z == R(0)) return Rgb<R>();
+    V3<R> wh = tr_sample_wh(l, wo, u0, u1);
+    if (dot(wo, wh) < R(0)) return Rgb<R>();
+    *wi = reflect(wo, wh);
+    if (!same_hemisphere(wo, *wi)) return Rgb<R>();
+    *pdf = tr_pdf(l, wo, wh) / (R(4) * dot(wo, wh));
+    return lobe_f(l, wo, *wi);
+  }
+  if (l.kind == LOBE_SPEC_REFL) {  // reflection.rs:639-650
+    *wi = V3<R>(-wo.x, -wo.y, wo.z);
+    *pdf = R(1);
+    return fresnel_eval(l, cos_theta(*wi)) * l.r / abs_cos_theta(*wi);
+  }
+  *wi = cosine_sample_hemisphere(u0, u1);  // BxDF::sample_f default :427-443
+  if (wo.z < R(0)) wi->z *= R(-1);
+  *pdf = lobe_pdf(l, wo, *wi);
+  return lobe_f(l, wo, *wi);
+}
+template <typename R> RRT_DEV R roughness_to_alpha(R roughness) {  // microfacet.rs:12-20
+  roughness = rmax(roughness, R(1e-3));
+  R x = log(roughness);
+  return R(1.62142) + R(0.819955) * x + R(0.1734) * x * x + R(0.0171201) * x * x * x + R(0.000640711) * x * x * x * x;
+}
+
+// Bsdf reflection.rs:205-405; at most two lobes for the in-scope materials
+template <typename R>
+struct Bsdf {
+  V3<R> ns, ng, ss, ts;
+  Lobe<R> lobes[2];
+  int n;
+
+  RRT_DEV static bool match(const Lobe<R>& l, uint32_t flags) { return (l.type & flags) == l.type; }
+  RRT_DEV int num_components(uint32_t flags) const { int c = 0; for (int i = 0; i < n; i++) if (match(lobes[i], flags)) c++; return c; }
+  RRT_DEV V3<R> to_local(V3<R> v) const { return {dot(v, ss), dot(v, ts), dot(v, ns)}; }
+  RRT_DEV V3<R> to_world(V3<R> v) const {
+    return {ss.x * v.x + ts.x * v.y + ns.x * v.z, ss.y * v.x + ts.y * v.y + ns.y * v.z, ss.z * v.x + ts.z * v.y + ns.z * v.z};
+  }
+  RRT_DEV Rgb<R> f(V3<R> wo_w, V3<R> wi_w, uint32_t flags) const {  // :252-268
+    V3<R> wi = to_local(wi_w), wo = to_local(wo_w);
+    if (wo.z == R(0)) return Rgb<R>();
+    bool refl = dot(wi_w, ng) * dot(wo_w, ng) > R(0);
+    Rgb<R> r;
+    for (int i = 0; i < n; i++) {
+      const Lobe<R>& l = lobes[i];
+      if (match(l, flags) && ((refl && (l.type & BXDF_REFLECTION)) || (!refl && (l.type & BXDF_TRANSMISSION)))) r = r + lobe_f(l, wo, wi);
+    }
+    return r;
+  }
+  RRT_DEV R pdf(V3<R> wo_w, V3<R> wi_w, uint32_t flags) const {  // :382-404
+    if (n == 0) return R(0);
+    V3<R> wo = to_local(wo_w), wi = to_local(wi_w);
+    if (wo.z == R(0)) return R(0);
+    R p = R(0);
+    int matching = 0;
+    for (int i = 0; i < n; i++) if (match(lobes[i], flags)) { matching++; p += lobe_pdf(lobes[i], wo, wi); }
+    return matching > 0 ? p / (R)matching : R(0);
+  }
+  // sample_f :302-381 (Q21). *pdf_out / *sampled keep the caller's values on the wo.z == 0 early-out.
+  RRT_DEV Rgb<R> sample_f(V3<R> wo_w, V3<R>* wi_w, R u0, R u1, R* pdf_out, uint32_t flags, uint32_t* sampled) const {
+    int matching = num_components(flags);
+    if (matching == 0) { *pdf_out = R(0); *sampled = BXDF_NONE; return Rgb<R>(); }
+    R fl = floor(u0 * (R)matching);
+    int comp = (fl != fl || fl <= R(0)) ? 0 : (int)fl;
+    if (comp > matching) comp = matching;
+    int count = comp, chosen = -1;
+    for (int i = 0; i < n; i++)
+      if (match(lobes[i], flags)) { if (count == 0) { chosen = i; break; } count--; }
+    if (chosen < 0) { *pdf_out = R(0); *sampled = BXDF_NONE; return Rgb<R>(); }  // reference: expect() panic (u0 >= 1 only)
+    const Lobe<R>& bx = lobes[chosen];
+    R ur0 = rmin(u0 * (R)matching - (R)comp, Const<R>::one_minus_eps);
+    V3<R> wi, wo = to_local(wo_w);
+    if (wo.z == R(0)) return Rgb<R>();
+    *pdf_out = R(0);
+    *sampled = bx.type;
+    Rgb<R> f = lobe_sample_f(bx, wo, &wi, ur0, u1, pdf_out);
+    if (*pdf_out == R(0)) { *sampled = BXDF_NONE; return Rgb<R>(); }
+    *wi_w = to_world(wi);
+    if (!(bx.type & BXDF_REFLECTION) && matching > 1)
+      for (int i = 0; i < n; i++) if (i != chosen && match(lobes[i], flags)) *pdf_out += lobe_pdf(lobes[i], wo, wi);
+    if (matching > 1) *pdf_out /= (R)matching;
+    return f;
+  }
+};
+
+// Material::compute_scattering_functions (matte.rs:35-60, plastic.rs:42-73, metal.rs:48-89, mirror.rs:27-47,
+// debug_material.rs:37-48) with constant textures
+template <typename R> RRT_DEV void build_lobes(const Material<R>& m, Bsdf<R>* b) {
+  b->n = 0;
+  switch (m.type) {
+    case 0: {  // MatteMaterial
+      Rgb<R> r = rgb_clamp0(Rgb<R>(m.kd));
+      R sig = clampr(m.sigma, R(0), R(90));
+      if (!r.is_black()) {
+        Lobe<R>& l = b->lobes[b->n++];
+        l.type = BXDF_DIFFUSE | BXDF_REFLECTION; l.r = r; l.fr = FR_NOOP;
+        if (sig == R(0)) l.kind = LOBE_LAMBERT;
+        else {
+          l.kind = LOBE_OREN_NAYAR;
+          R sr = (R(RRT_PI) / R(180)) * sig;
+          R sigma2 = sr * sr;
+          l.a = R(1) - (sigma2 / (R(2) * (sigma2 + R(0.33))));
+          l.b = R(0.45) * sigma2 / (sigma2 + R(0.09));
+        }
+      }
+      break;
+    }
+    case 1: {  // PlasticMaterial (specular lobe gated on kd: Q31)
+      Rgb<R> kd = rgb_clamp0(Rgb<R>(m.kd)), ks = rgb_clamp0(Rgb<R>(m.ks));
+      if (!kd.is_black()) {
+        Lobe<R>& l = b->lobes[b->n++];
+        l.kind = LOBE_LAMBERT; l.type = BXDF_DIFFUSE | BXDF_REFLECTION; l.r = kd; l.fr = FR_NOOP;
+        R rough = m.roughness;
+        if (m.remap_roughness) rough = roughness_to_alpha(rough);
+        Lobe<R>& s = b->lobes[b->n++];
+        s.kind = LOBE_MICROFACET; s.type = BXDF_GLOSSY | BXDF_REFLECTION; s.r = ks; s.alpha_x = rough; s.alpha_y = rough;
+        s.fr = FR_DIELECTRIC; s.eta_i = Rgb<R>(R(1.5)); s.eta_t = Rgb<R>(R(1));
+      }
+      break;
+    }
+    case 2: {  // MetalMaterial
+      R ur = m.u_roughness, vr = m.v_roughness;
+      if (m.remap_roughness) { ur = roughness_to_alpha(ur); vr = roughness_to_alpha(vr); }
+      Lobe<R>& l = b->lobes[b->n++];
+      l.kind = LOBE_MICROFACET; l.type = BXDF_GLOSSY | BXDF_REFLECTION; l.r = Rgb<R>(R(1)); l.alpha_x = ur; l.alpha_y = vr;
+      l.fr = FR_CONDUCTOR; l.eta_i = Rgb<R>(R(1)); l.eta_t = Rgb<R>(m.eta); l.k = Rgb<R>(m.k);
+      break;
+    }
+    case 3: {  // MirrorMaterial
+      Rgb<R> r = rgb_clamp0(Rgb<R>(m.kr));
+      if (!r.is_black()) {
+        Lobe<R>& l = b->lobes[b->n++];
+        l.kind = LOBE_SPEC_REFL; l.type = BXDF_REFLECTION | BXDF_SPECULAR; l.r = r; l.fr = FR_NOOP;
+      }
+      break;
+    }
+    default: {  // DebugMaterial
+      Lobe<R>& a = b->lobes[b->n++];
+      a.kind = LOBE_DEBUG_DIFFUSE; a.type = BXDF_DIFFUSE | BXDF_REFLECTION; a.fr = FR_NOOP;
+      Lobe<R>& c = b->lobes[b->n++];
+      c.kind = LOBE_DEBUG_SPECULAR; c.type = BXDF_SPECULAR | BXDF_REFLECTION; c.fr = FR_NOOP;
+      break;
+    }
+  }
+}
+
+}  // namespace rrtd

@@ -1,0 +1,127 @@
+// Device-side data layout (HBM, SoA) for the wavefront path tracer. gfx950 only.
+//
+// Everything the kernels read is flattened to world space and stored in *traversal order* (ordered_prims
+// of bvh.rs:336-357), so a leaf's primitives are contiguous: nodes[i].offset indexes tri arrays directly.
+#pragma once
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+
+namespace rrtd {
+
+// LinearBVHNode bvh.rs:103-109, narrowed: f32 = 32 B (bounds rounded outward from the f64 build), f64 = 64 B.
+template <typename R>
+struct alignas(sizeof(R) * 8) Node {
+  R bmin[3];
+  R bmax[3];
+  uint32_t offset;   // leaf: first triangle (traversal order); interior: second child
+  uint32_t meta;     // n_primitives << 2 | axis
+  // f64: 48 + 8 = 56 -> padded to 64 by alignas
+};
+
+// One triangle = 3 world-space vertices + 3 words (48 B in f32). Read by the traversal kernels.
+template <typename R>
+struct alignas(16) Tri {
+  R p0[3], p1[3], p2[3];
+  uint32_t material;   // index into materials
+  uint32_t shade;      // index into TriShade (0xffffffff: no normals / uvs -> defaults)
+  uint32_t plane;      // id shared by exactly coplanar triangles (host, see plane_ids()); used by self_prim()
+};
+
+// Optional per-triangle shading attributes (meshes with vn / vt), world space.
+template <typename R>
+struct TriShade {
+  R n[3][3];
+  R uv[3][2];
+  uint32_t has_n, has_uv;  // mesh_has_* of rrt_tri (0,1,2)
+};
+
+template <typename R>
+struct Material {
+  int32_t type, remap_roughness;
+  R kd[3], ks[3], kr[3], eta[3], k[3];
+  R sigma, roughness, u_roughness, v_roughness;
+};
+
+template <typename R>
+struct Light {
+  int32_t type, shape_type;
+  R spectrum[3];
+  R p_light[3];
+  R area;
+  // sphere light shape (object space + transform) / triangle light shape (raw mesh vertices, Q13)
+  R m[12], mi[12];                 // obj_to_world rows 0..2 (affine), and inverse
+  R radius, z_min, z_max, theta_min, theta_max, phi_max;
+  R tp[3][3];                      // triangle vertices
+  R tn[3][3];                      // triangle vertex normals (if tri_has_n)
+  uint32_t tri_has_n;
+};
+
+template <typename R>
+struct LensElem { R curvature_radius, thickness, eta, aperture_radius; };
+
+struct HaltonDim {   // one entry per sampler dimension >= 2
+  uint32_t base;
+  uint32_t perm_offset;   // PRIME_SUMS[dim]
+  uint64_t magic;         // floor(2^40 / base) + 1 : exact a / base for a < 2^26, base <= 8192
+};
+
+template <typename R>
+struct SceneDev {
+  const Node<R>* nodes;
+  const Tri<R>* tris;
+  const TriShade<R>* shades;
+  const Material<R>* materials;
+  const Light<R>* lights;
+  const R* light_cdf;          // Distribution1D([1; n]).cdf, n_lights + 1 entries
+  uint32_t n_nodes, n_tris, n_lights;
+  R light_pick_pdf;            // 1 / (func_int * n)
+  uint32_t stack_depth;        // >= bvh depth + 1
+  uint32_t flags;
+  // camera
+  const LensElem<R>* lens;
+  int32_t n_lens, simple_weighting;
+  R cam_m[12];                 // camera_to_world rows 0..2
+  R pupil0[4], pupil63[4];
+  R shutter_open, shutter_close;
+  // film
+  int32_t xres, yres;
+  R diagonal, extent[4];
+  R max_sample_luminance;
+  // sampler
+  const HaltonDim* hdims;
+  const uint16_t* perms;
+  uint32_t nsamp, sample_at_center;
+  uint32_t base_exp0, base_exp1, base_scale0, base_scale1, stride, mult_inv0, mult_inv1;
+  uint32_t fast_div;           // all sample indices < 2^26
+  // integrator
+  int32_t integrator, max_depth, light_strategy;
+  R rr_threshold;
+};
+
+// Wavefront pools (SoA over path slots). One slot = one camera sample of the current pass.
+template <typename R>
+struct Pools {
+  // rays for the closest-hit kernel (also the public rrt_rays layout)
+  R *ox, *oy, *oz, *dx, *dy, *dz, *tmax;
+  int32_t* skip;         // triangle (traversal order) a spawned ray starts on, -1 = none (see self_prim())
+  // hits
+  R *ht, *hu, *hv;
+  int32_t* hprim;
+  // shadow rays + pending contribution
+  R *sox, *soy, *soz, *sdx, *sdy, *sdz, *stmax;
+  R *ldr, *ldg, *ldb;
+  int32_t* sskip;
+  // path state
+  uint32_t* pixel;       // pixel index inside the frame (y * xres + x)
+  uint32_t* hindex;      // Halton global sample index
+  uint32_t* dim_bounce;  // dimension counter (low 16) | bounces (high 16)
+  R *br, *bg, *bb;       // beta
+  R *lr, *lg, *lb;       // L
+  R* weight;             // camera ray weight
+  R *pfx, *pfy;          // p_film
+  // queues
+  uint32_t *q_active, *q_next, *q_shadow;
+  uint32_t* counters;    // [0] active, [1] next, [2] shadow, [3] camera rays, [4..] stats
+};
+
+}  // namespace rrtd

@@ -295,16 +295,20 @@ struct Loader {
       s.positions.insert(s.positions.end(), m.p.begin(), m.p.end());
       s.normals.insert(s.normals.end(), m.n.begin(), m.n.end());
       s.uvs.insert(s.uvs.end(), m.uv.begin(), m.uv.end());
+      // Triangle::new triangle.rs:73-111: n / uv index triples are [0,0,0] unless both the attribute array
+      // and its index array are non-empty. mesh_has_* : 0 = attribute array empty, 1 = array and indices
+      // present, 2 = array present but no indices (index 0 used three times).
       bool has_n = !m.n.empty() && !m.ni.empty(), has_uv = !m.uv.empty() && !m.uvi.empty();
       MeshEntry me{(uint32_t)s.tris.size(), (uint32_t)(m.vi.size() / 3)};
       for (size_t t = 0; t < m.vi.size() / 3; t++) {
         rrt_tri tri{};
         for (int k = 0; k < 3; k++) {
           tri.v[k] = vbase + m.vi[3 * t + k];
-          tri.n[k] = has_n ? nbase + m.ni[3 * t + k] : 0;
-          tri.uv[k] = has_uv ? uvbase + m.uvi[3 * t + k] : 0;
+          tri.n[k] = has_n ? nbase + m.ni[3 * t + k] : nbase;
+          tri.uv[k] = has_uv ? uvbase + m.uvi[3 * t + k] : uvbase;
         }
-        tri.mesh_has_n = has_n; tri.mesh_has_uv = has_uv;
+        tri.mesh_has_n = m.n.empty() ? 0 : (has_n ? 1 : 2);
+        tri.mesh_has_uv = m.uv.empty() ? 0 : (has_uv ? 1 : 2);
         s.tris.push_back(tri);
       }
       meshes[obj_name] = me;

@@ -1,0 +1,257 @@
+"""GPU parity tests: the HIP path (through the C ABI) against the f64 oracle on the same seeded inputs.
+
+Bars: index/integer outputs (winning triangle, occlusion bits, filter-weight sums, node/prim counters)
+bit-exact in f64 mode; floating point within the tolerance written next to each assert. The fp32 product
+path is held to statistical closeness because a path's discrete decisions (which triangle, which lobe,
+roulette) flip for O(1e-5) of samples under fp32 rounding.
+
+The device flattens rigid instances to world space (the reference transforms the ray per primitive). The two
+evaluations agree except on exact ties (a hit on a face coplanar with a flat leaf box: gap of ~1e-16), which
+each breaks by its own last-bit rounding. The f64 device mode is therefore compared bit-for-bit with the
+oracle's flat=True evaluation; tests/test_oracle.py bounds how often flat and per-primitive evaluation differ
+and shows that every such ray is a tie.
+"""
+import numpy as np
+import pytest
+
+import oracle_lib as O
+from rs_ray_toy_amd import RRT_F32, RRT_F64, RRT_FIXED_BVH, Renderer, RrtPanic, RrtUnsupported, Scene, scenes
+
+pytestmark = pytest.mark.gpu
+
+
+@pytest.fixture(scope="module")
+def cfg2_scene(workdir):
+    cfg, root = scenes.cfg2(workdir, xres=128, yres=128, nsamp=9, max_depth=4)
+    return Scene.loads(cfg, root)
+
+
+@pytest.fixture(scope="module")
+def hf_scene(workdir):
+    cfg, root = scenes.cfg4(workdir, xres=96, yres=96, nsamp=5, max_depth=8, n=64)  # 8192 triangles
+    return Scene.loads(cfg, root, flags=RRT_FIXED_BVH)
+
+
+def _rays_for(scene, n, seed):
+    o, d, tmax = O.random_rays(scene, n, seed)
+    # half of the rays start on a surface, like spawned rays do (Q8: no origin offset)
+    ref = O.trace_closest(scene, o, d, tmax, want_geometry=True)
+    hit = ref["prim"] >= 0
+    rng = np.random.default_rng(seed + 1)
+    o2 = np.where(hit[:, None], ref["p"], o)
+    d2 = rng.normal(size=(n, 3))
+    d2 /= np.linalg.norm(d2, axis=1, keepdims=True)
+    skip = np.concatenate([np.full(n, -1, np.int32), np.where(hit, ref["prim"], -1).astype(np.int32)])
+    return np.concatenate([o, o2]), np.concatenate([d, d2]), np.concatenate([tmax, tmax]), skip
+
+
+@pytest.mark.parametrize("which", ["cfg2", "hf"])
+def test_trace_closest_f64_exact(which, cfg2_scene, hf_scene):
+    sc = cfg2_scene if which == "cfg2" else hf_scene
+    o, d, tmax, _ = _rays_for(sc, 4096, 11)
+    ref = O.trace_closest(sc, o, d, tmax, flat=True)
+    r = Renderer(sc, 0, RRT_F64)
+    got = r.trace_closest(o, d, tmax, counters=True)
+    r.close()
+    assert (ref["prim"] >= 0).sum() > 500
+    assert np.array_equal(got["prim"], ref["prim"])            # winning triangle incl. "last accepted wins" (Q10)
+    assert np.array_equal(got["nodes"], ref["nodes"])          # identical traversal: node / prim counters
+    assert np.array_equal(got["prims"], ref["prims"])
+    hit = ref["prim"] >= 0
+    # same operation order, IEEE f64 add/mul/div only, no FMA contraction on either side: bit-exact
+    assert np.array_equal(got["t"], ref["t"])
+    assert np.array_equal(got["u"][hit], ref["u"][hit]) and np.array_equal(got["v"][hit], ref["v"][hit])
+
+
+@pytest.mark.parametrize("which", ["cfg2", "hf"])
+def test_trace_closest_f32(which, cfg2_scene, hf_scene):
+    sc = cfg2_scene if which == "cfg2" else hf_scene
+    o, d, tmax, skip = _rays_for(sc, 4096, 5)
+    ref = O.trace_closest(sc, o, d, tmax)
+    r = Renderer(sc, 0, RRT_F32)
+    got = r.trace_closest(o, d, tmax, skip_prim=skip)          # fp32 excludes the triangle a ray starts on
+    r.close()
+    same = got["prim"] == ref["prim"]
+    # fp32: edge/grazing rays may pick the neighbour. cfg2's cubes have axis-aligned faces coplanar with flat
+    # leaf boxes: 23 % of its rays carry an exact tie that fp32 breaks at random (see test_oracle.py)
+    assert same.mean() > (0.97 if which == "cfg2" else 0.999), same.mean()
+    hit = same & (ref["prim"] >= 0)
+    np.testing.assert_allclose(got["t"][hit], ref["t"][hit], rtol=2e-4, atol=1e-4)
+
+
+@pytest.mark.parametrize("prec", [RRT_F64, RRT_F32])
+def test_trace_any(prec, hf_scene):
+    sc = hf_scene
+    o, d, tmax, skip = _rays_for(sc, 4096, 23)
+    tmax = np.full(len(tmax), 1.0 - 1e-4)                      # shadow rays keep t_max = 1 - SHADOW_EPSILON (Q9)
+    ref = O.trace_any(sc, o, d, tmax, flat=True)
+    r = Renderer(sc, 0, prec)
+    got = r.trace_any(o, d, tmax, skip_prim=skip if prec == RRT_F32 else None)
+    r.close()
+    assert ref["occluded"].sum() > 50
+    if prec == RRT_F64:
+        assert np.array_equal(got, ref["occluded"])
+    else:
+        assert (got == ref["occluded"]).mean() > 0.995
+
+
+@pytest.mark.parametrize("prec", [RRT_F64, RRT_F32])
+def test_camera_samples(prec, cfg2_scene):
+    sc = cfg2_scene
+    rect = (40, 50, 72, 66)
+    dims, rays, w = O.camera_samples(sc, rect, 1, 5)
+    r = Renderer(sc, 0, prec)
+    gd, gr, gw = r.camera_samples(rect, 1, 5)
+    r.close()
+    assert np.array_equal(gd, dims)                            # Halton dims are produced in f64 on the device: exact
+    assert 0.05 < (w > 0).mean() < 0.9
+    if prec == RRT_F64:
+        assert np.array_equal(gw > 0, w > 0)
+        np.testing.assert_allclose(gw, w, rtol=1e-11)
+        np.testing.assert_allclose(gr, rays, rtol=1e-10, atol=1e-10)
+    else:
+        assert ((gw > 0) == (w > 0)).mean() > 0.995           # aperture-edge lens traces can flip in fp32
+        both = (gw > 0) & (w > 0)
+        np.testing.assert_allclose(gw[both], w[both], rtol=1e-4)
+        np.testing.assert_allclose(gr[both], rays[both], rtol=1e-3, atol=2e-4)
+
+
+def _film_err(film, ref):
+    scale = np.abs(ref[..., :3]).max()
+    return np.abs(film[..., :3].astype(np.float64) - ref[..., :3]).max() / scale, scale
+
+
+RENDER_CASES = {
+    "cfg2_path": lambda wd: scenes.cfg2(wd, xres=96, yres=96, nsamp=9, max_depth=4),
+    "cfg3_path": lambda wd: scenes.cfg3(wd, xres=64, yres=64, nsamp=5, max_depth=5),
+    "cfg4_path": lambda wd: scenes.cfg4(wd, xres=64, yres=64, nsamp=5, max_depth=8, n=48),
+    "cfg5_path": lambda wd: scenes.cfg5(wd, xres=64, yres=64, nsamp=9, max_depth=16, n=48),
+}
+
+
+@pytest.mark.parametrize("case", sorted(RENDER_CASES))
+def test_render_f64_matches_oracle(case, workdir):
+    cfg, root = RENDER_CASES[case](workdir)
+    sc = Scene.loads(cfg, root, flags=RRT_FIXED_BVH if "cfg4" in case or "cfg5" in case else 0)
+    ref, st_ref = O.render(sc, stats=True, flat=True)
+    r = Renderer(sc, 0, RRT_F64)
+    film, st = r.render(stats=True)
+    r.close()
+    assert ref[..., :3].max() > 0
+    assert np.array_equal(film[..., 3], ref[..., 3])           # filter_weight_sum (Q1, Q2, Q3): exact
+    assert st.camera_rays == st_ref.camera_rays                # the reference's "rays generated" counter
+    diff = np.abs(film[..., :3] - ref[..., :3]).max(-1) / np.abs(ref[..., :3]).max()
+    # f64 device mode: same formulas and operation order; libm vs device sin/cos/log may differ in the last
+    # ulp. Bar: 1e-9 of the brightest pixel (a flipped discrete decision shows up as >= 1e-3).
+    if case == "cfg2_path":
+        # tie-prone geometry (axis-aligned faces coplanar with flat leaf boxes): a last-ulp difference in a
+        # sampled direction can break such a tie the other way; at most 0.5 % of pixels may carry one
+        assert (diff > 1e-9).mean() < 0.005, (diff > 1e-9).mean()
+    else:
+        assert diff.max() < 1e-9, diff.max()
+
+
+@pytest.mark.parametrize("case", sorted(RENDER_CASES))
+def test_render_f32_close_to_oracle(case, workdir):
+    cfg, root = RENDER_CASES[case](workdir)
+    sc = Scene.loads(cfg, root, flags=RRT_FIXED_BVH if "cfg4" in case or "cfg5" in case else 0)
+    ref = O.render(sc)
+    r = Renderer(sc, 0, RRT_F32)
+    film = r.render()
+    r.close()
+    assert np.array_equal(film[..., 3].astype(np.float64), ref[..., 3])
+    scale = np.abs(ref[..., :3]).max()
+    diff = np.abs(film[..., :3].astype(np.float64) - ref[..., :3]).max(-1) / scale
+    # fp32 tolerance (north_star: "pixel values within a stated fp32 tolerance"): every pixel within 1e-4 of the
+    # brightest pixel's value (observed <= 1.1e-5). cfg2's cubes have axis-aligned faces coplanar with flat leaf
+    # boxes, i.e. exact ties that any change of rounding breaks differently (the oracle's own two evaluation
+    # orders differ on 0.4 % of its pixels): there 98.5 % of pixels must be within 1e-3.
+    if case == "cfg2_path":
+        assert (diff < 1e-3).mean() > 0.985, (diff < 1e-3).mean()
+        assert np.median(diff) < 1e-5
+    else:
+        assert diff.max() < 1e-4, diff.max()
+
+
+def test_render_rect_and_passes_are_consistent(workdir):
+    """Tile partition (§8e): disjoint rects sum to the full frame; pool size (pass structure) does not matter."""
+    cfg, root = scenes.cfg2(workdir, xres=64, yres=64, nsamp=9, max_depth=4)
+    sc = Scene.loads(cfg, root)
+    r = Renderer(sc, 0, RRT_F64)
+    full = r.render()
+    parts = np.zeros_like(full)
+    for rect in ((0, 0, 64, 16), (0, 16, 64, 40), (0, 40, 64, 64)):
+        r.render(rect, film=parts)
+    r.set_option("max_paths", 1000)   # forces pixel groups and 1-sample passes
+    small = r.render()
+    r.close()
+    assert np.array_equal(parts, full)
+    np.testing.assert_allclose(small, full, rtol=1e-12, atol=1e-15)
+
+
+@pytest.mark.parametrize("integrator", ["Debug", "DirectLighting_all", "DirectLighting_one", "AO"])
+def test_other_integrators(integrator, workdir):
+    cfg, root = scenes.cfg2(workdir, xres=64, yres=64, nsamp=5)
+    if integrator == "Debug":
+        cfg["Integrator"] = {"integrator_type": "Debug", "max_depth": 5}
+    elif integrator == "AO":
+        cfg["Integrator"] = {"integrator_type": "AO"}
+    else:
+        cfg["Integrator"] = {"integrator_type": "DirectLighting", "light_strategy": integrator.split("_")[1], "max_depth": 5}
+    # one mirror cube exercises the specular_reflect chain
+    cfg["Aggregate"]["primitives"].append({"primitive_type": "triangle", "material_name": "mat_mirror", "obj_name": "cube_01",
+                                           "instances": [{"world_pos": [33.0, 0.5, 0.0], "rotation_axis": [1, 2, 3], "rotation_angle": 20}]})
+    for inst in cfg["Aggregate"]["primitives"][0]["instances"]:
+        inst["rotation_axis"] = [1.0, 2.0, 3.0]   # generic axes: no face stays axis-aligned, no box/face ties
+    sc = Scene.loads(cfg, root)
+    ref = O.render(sc, flat=True)
+    r = Renderer(sc, 0, RRT_F64)
+    film = r.render()
+    r.close()
+    assert np.array_equal(film[..., 3], ref[..., 3])
+    if integrator == "AO":
+        assert film[..., :3].max() == 0 and ref[..., :3].max() == 0   # ao.rs:62-64: bsdf is never built -> black
+        return
+    err, _ = _film_err(film, ref)
+    assert err < 1e-9, err
+
+
+def test_roundtrip_properties_full_size(workdir):
+    """Size-independent properties at BASELINE cfg4's full mesh size (100 352 triangles): (a) a closest hit's
+    point re-traced from the far side of the ray hits the same triangle or one in front of it never behind,
+    (b) any-hit with t_max = inf is implied by a closest hit for rays that do not start on a surface."""
+    cfg, root = scenes.cfg4(workdir, xres=64, yres=64, nsamp=3, n=224)
+    sc = Scene.loads(cfg, root, flags=RRT_FIXED_BVH)
+    assert sc.desc.n_prims == 100352
+    o, d, tmax = O.random_rays(sc, 200000, 3)
+    r = Renderer(sc, 0, RRT_F32)
+    got = r.trace_closest(o, d, tmax, counters=True)
+    occ = r.trace_any(o, d, tmax)
+    r.close()
+    hit = got["prim"] >= 0
+    assert hit.mean() > 0.3
+    assert np.all(got["t"][hit] > 0) and np.all(np.isfinite(got["t"][hit]))
+    assert np.all((got["u"][hit] >= 0) & (got["v"][hit] >= 0) & (got["u"][hit] + got["v"][hit] <= 1 + 1e-6))
+    assert np.all(got["nodes"] >= 1) and np.all(got["prims"][hit] >= 1)
+    # the any-hit test uses the reference's *different* triangle (E2 = p2 - p1, Q11), so implication is not
+    # exact; it holds for the overwhelming majority on a closed heightfield
+    assert occ[hit].mean() > 0.5
+    # sampled oracle check at full size
+    idx = np.random.default_rng(0).choice(len(tmax), 4000, replace=False)
+    ref = O.trace_closest(sc, o[idx], d[idx], tmax[idx])
+    assert (got["prim"][idx] == ref["prim"]).mean() > 0.999
+
+
+def test_unsupported_and_panics(workdir):
+    cfg, root = scenes.cfg1(workdir, xres=32, yres=32, nsamp=3)
+    sc = Scene.loads(cfg, root)
+    with pytest.raises(RrtUnsupported):
+        Renderer(sc, 0, RRT_F32)                                  # sphere primitives: oracle-only this round
+    cfg, root = scenes.cfg2(workdir, xres=32, yres=32, nsamp=3)
+    cfg["Integrator"] = {"integrator_type": "DirectLighting"}
+    cfg["lights"] = []
+    sc = Scene.loads(cfg, root)
+    r = Renderer(sc, 0, RRT_F32)
+    with pytest.raises(RrtPanic):
+        r.render()                                               # Q20: unbounded recursion in the reference
+    r.close()
