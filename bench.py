@@ -1,0 +1,208 @@
+#!/usr/bin/env python3
+"""bench.py — BASELINE.json headline: Mrays/s + achieved GB/s, 100k-triangle scene @ 1024^2, 256 spp, depth 8.
+
+One "step" = one full frame of BASELINE config 4 (procedural 100 352-triangle heightfield, Path integrator
+max_depth 8, HaltonSampler nsamp 257 = 256 effective spp, RealisticCamera) rendered by the HIP wavefront path.
+With N > 1 ranks (torchrun, one process per GPU) the film is partitioned into interleaved 16-row bands, every
+rank renders its bands into a device film, and one RCCL reduce over xGMI reassembles the image on rank 0
+(bands are disjoint, so the sum is a gather); that collective is inside the timed region. Total work is fixed:
+strong scaling.
+
+Inputs are resident in HBM before the timed region (scene upload + pool allocation happen in setup/warm-up).
+The JSON line carries `roofline` for the dominant kernel (k_closest: BVH traversal + triangle tests) and
+`cpu_baseline` (the f64 oracle on the host cores, bounded sample, rank 0 at N=1 only).
+"""
+import argparse
+import ctypes as C
+import json
+import os
+import sys
+import tempfile
+import time
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+sys.path.insert(0, ROOT)
+sys.path.insert(0, os.path.join(ROOT, "tests"))
+
+HBM_PEAK_GBS = 8000.0  # MI355X_MICROARCH.md: HBM3E peak 8.0 TB/s (6.3 TB/s measured streaming copy)
+
+
+def cpu_baseline(scene, target_seconds):
+    """The f64 oracle (a port: the reference itself is a nightly-only Rust crate that cannot be built here) on
+    this box's host cores, OpenMP over 16x16 tiles like the reference's rayon loop, sampler tables built once
+    ("fair" variant of BASELINE.md §2). Bounded sample: whole 16-row tile bands from the middle of the same
+    frame, at the full 256 spp, sized from a one-band calibration to take about `target_seconds`."""
+    import oracle_lib as O
+    W, H = scene.resolution
+    cores = os.cpu_count() or 1
+    mid = (H // 2) // 16 * 16
+    t0 = time.perf_counter()
+    _, st = O.render(scene, (0, mid, W, mid + 16), stats=True)
+    dt = time.perf_counter() - t0
+    bands = int(max(1, min((H - mid) // 16 - 1, round(target_seconds / max(dt, 1e-3)) - 1)))
+    q, rays, secs, rows = st.closest_queries + st.any_queries, st.camera_rays, dt, 16
+    if bands >= 1:
+        t0 = time.perf_counter()
+        _, st2 = O.render(scene, (0, mid + 16, W, mid + 16 + 16 * bands), stats=True)
+        dt2 = time.perf_counter() - t0
+        q += st2.closest_queries + st2.any_queries
+        rays += st2.camera_rays
+        secs += dt2
+        rows += 16 * bands
+    return {"value": round(q / secs / 1e6, 4), "unit": "Mrays/s", "cores": cores, "kind": "port",
+            "sample": "rows %d..%d of the same %dx%d frame at full spp/depth (%d ray queries, %.1f s, f64 oracle incl. the "
+                      "reference's BSDF-sampled MIS ray and final dead bounce)" % (mid, mid + rows, W, H, q, secs),
+            "camera_mrays_per_s": round(rays / secs / 1e6, 4), "est_full_frame_s": round(secs * H / rows, 1)}
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=3)
+    ap.add_argument("--warmup", type=int, default=1)
+    ap.add_argument("--res", type=int, default=1024)
+    ap.add_argument("--spp", type=int, default=256)
+    ap.add_argument("--depth", type=int, default=8)
+    ap.add_argument("--grid", type=int, default=224, help="heightfield cells per side (224 -> 100 352 triangles)")
+    ap.add_argument("--compat-bvh", action="store_true", help="reference-exact builder incl. Q26/Q27 (default: fixed-bvh)")
+    ap.add_argument("--cpu-seconds", type=float, default=15.0, help="target wall time of the cpu_baseline sample")
+    ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--max-paths", type=int, default=0)
+    args = ap.parse_args()
+
+    import numpy as np
+    import torch
+    import torch.distributed as dist
+
+    from rs_ray_toy_amd import RRT_F32, RRT_FIXED_BVH, Renderer, Scene, scenes
+    from rs_ray_toy_amd.partition import band_rects, reduce_film
+
+    rank = int(os.environ.get("RANK", "0"))
+    local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    if world != args.gpus:
+        if world == 1 and args.gpus > 1:
+            raise SystemExit("launch with torch.distributed.run --nproc-per-node N for --gpus N")
+    if not torch.cuda.is_available():
+        raise SystemExit("bench.py needs a GPU (no CPU fallback exists for the product path)")
+    torch.cuda.set_device(local_rank)
+    if world > 1:
+        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        dist.init_process_group("nccl", rank=rank, world_size=world, device_id=torch.device("cuda", local_rank))
+
+    # ---- setup (untimed): scene build on the host, upload, pools ------------------------------------------------
+    wd = tempfile.mkdtemp(prefix=f"rrt_bench_r{rank}_")
+    cfg, root = scenes.cfg4(wd, xres=args.res, yres=args.res, nsamp=args.spp + 1, max_depth=args.depth, n=args.grid)
+    flags = 0 if args.compat_bvh else RRT_FIXED_BVH
+    t0 = time.time()
+    scene = Scene.loads(cfg, root, flags=flags)
+    t_build = time.time() - t0
+    W, H = scene.resolution
+    r = Renderer(scene, local_rank, RRT_F32)
+    if args.max_paths:
+        r.set_option("max_paths", args.max_paths)
+    rects = band_rects(W, H, rank, world)
+    film = torch.zeros((H, W, 4), dtype=torch.float32, device=f"cuda:{local_rank}")
+
+    def step(collect=False):
+        film.zero_()
+        agg = None
+        for rect in rects:
+            st = r.render_device(rect, film.data_ptr(), stats=collect)
+            if collect:
+                if agg is None:
+                    agg = {k: 0 for k, _ in st._fields_}
+                for k, _ in st._fields_:
+                    agg[k] += getattr(st, k)
+        reduce_film(film, world)  # disjoint bands: the sum reassembles the frame on rank 0 (RCCL over xGMI)
+        return agg
+
+    def sync():
+        torch.cuda.synchronize()
+        if world > 1:
+            dist.barrier()
+        torch.cuda.synchronize()
+
+    # one counting frame (untimed): exact per-kernel ray / node / triangle-test counts for the byte model
+    r.set_option("count_traversal", 1)
+    counted = step(collect=True)
+    r.set_option("count_traversal", 0)
+    for _ in range(args.warmup):
+        step()
+    sync()
+    t0 = time.perf_counter()
+    for _ in range(args.steps):
+        step()
+    sync()
+    elapsed = time.perf_counter() - t0
+    # per-kernel durations with HIP events on the handle's stream (one extra frame, after the timed region)
+    timed = step(collect=True)
+    sync()
+
+    tt = torch.tensor([elapsed], dtype=torch.float64, device=f"cuda:{local_rank}")
+    keys = ["camera_samples", "camera_rays", "closest_queries", "any_queries", "closest_nodes", "closest_prims", "any_nodes", "any_prims", "closest_launches"]
+    counted["closest_launches"] = timed["closest_launches"]
+    cnt = torch.tensor([float(counted[k]) for k in keys] + [timed["ms_closest"], timed["ms_any"], timed["ms_shade"], timed["ms_raygen"], timed["ms_film"], timed["ms_total"]],
+                       dtype=torch.float64, device=f"cuda:{local_rank}")
+    if world > 1:
+        dist.all_reduce(tt, op=dist.ReduceOp.MAX)
+        mx = cnt.clone()
+        dist.all_reduce(cnt, op=dist.ReduceOp.SUM)
+        dist.all_reduce(mx, op=dist.ReduceOp.MAX)
+    else:
+        mx = cnt
+    elapsed = float(tt.item())
+    names = keys + ["ms_closest", "ms_any", "ms_shade", "ms_raygen", "ms_film", "ms_total"]
+    tot = dict(zip(names, cnt.tolist()))
+    mx_tot = dict(zip(names, mx.tolist()))
+
+    if rank == 0:
+        ms_per_step = elapsed / args.steps * 1e3
+        queries = tot["closest_queries"] + tot["any_queries"]
+        value = queries / (ms_per_step * 1e-3) / 1e6
+        # Roofline of the dominant kernel, k_closest. ALGORITHMIC bytes per closest query:
+        # 28 B ray in + 16 B hit out + 32 B per BVH node visited + 48 B per triangle tested; node / triangle
+        # counts are exact device counters of this very frame; duration = sum of the kernel's launches on the
+        # handle's stream (HIP events), so achieved = bytes per launch / average launch duration.
+        n_launch = max(1.0, tot["closest_launches"])
+        bytes_closest = tot["closest_queries"] * 44.0 + 32.0 * tot["closest_nodes"] + 48.0 * tot["closest_prims"]
+        # per-rank kernel time: ranks run concurrently, take the slowest rank's sum
+        ms_closest = mx_tot["ms_closest"]
+        achieved = (bytes_closest / world) / (ms_closest * 1e-3) / 1e9 if ms_closest > 0 else 0.0
+        traffic = None
+        pmc = os.path.join(ROOT, "profiles", "r1_pmc_closest.json")
+        if os.path.exists(pmc):
+            with open(pmc) as f:
+                traffic = json.load(f).get("hbm_bytes_per_launch")
+        roofline = {"kernel": "k_closest<float>", "bound": "hbm", "achieved": round(achieved, 2), "peak": HBM_PEAK_GBS, "unit": "GB/s",
+                    "frac": round(achieved / HBM_PEAK_GBS, 4), "traffic": traffic,
+                    "algorithmic_bytes_per_launch": round(bytes_closest / n_launch, 1),
+                    "avg_launch_ms": round(ms_closest * world / n_launch, 4), "launches": int(n_launch),
+                    "bytes_per_query": round(bytes_closest / max(1.0, tot["closest_queries"]), 1),
+                    "nodes_per_query": round(tot["closest_nodes"] / max(1.0, tot["closest_queries"]), 2),
+                    "tris_per_query": round(tot["closest_prims"] / max(1.0, tot["closest_queries"]), 2)}
+        cpu = None
+        if world == 1 and not args.no_cpu_baseline:
+            cpu = cpu_baseline(scene, args.cpu_seconds)
+        out = {
+            "metric": "Mrays/s (BVH ray queries, closest+any) @ 100k-tri heightfield 1024^2 256spp depth 8",
+            "value": round(value, 3), "unit": "Mrays/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
+            "ms_per_step": round(ms_per_step, 3), "higher_is_better": True, "scaling": "strong", "vs_baseline": None,
+            "dtype": "f32", "data": "synthetic",
+            "config": {"workload": "BASELINE cfg4: procedural heightfield %d triangles, %dx%d, %d spp, Path max_depth %d, HaltonSampler, RealisticCamera, box filter; %s BVH; film in interleaved 16-row bands, RCCL reduce to rank 0" % (
+                scene.desc.n_prims, W, H, args.spp, args.depth, "reference-exact (Q26/Q27)" if args.compat_bvh else "fixed-bvh"),
+                "triangles": int(scene.desc.n_prims), "bvh_nodes": int(scene.desc.n_bvh_nodes), "bvh_depth": int(scene.desc.bvh_depth)},
+            "roofline": roofline, "cpu_baseline": cpu,
+            "camera_mrays_per_s": round(tot["camera_rays"] / (ms_per_step * 1e-3) / 1e6, 3),
+            "camera_samples": int(tot["camera_samples"]), "camera_rays": int(tot["camera_rays"]),
+            "closest_queries": int(tot["closest_queries"]), "any_queries": int(tot["any_queries"]),
+            "kernel_ms_per_frame": {k: round(mx_tot[k], 3) for k in ("ms_raygen", "ms_closest", "ms_any", "ms_shade", "ms_film", "ms_total")},
+            "host_scene_build_s": round(t_build, 3),
+        }
+        print(json.dumps(out))
+    if world > 1:
+        dist.destroy_process_group()
+
+
+if __name__ == "__main__":
+    main()

@@ -229,9 +229,11 @@ typedef struct rrt_render_stats {
   uint64_t camera_samples;      /* W*H*(nsamp-1) in range                         */
   uint64_t camera_rays;         /* samples with weight>0: integrator/mod.rs:101   */
   uint64_t closest_queries, any_queries;
-  uint64_t nodes_visited, prims_tested;   /* when counting is enabled             */
+  uint64_t nodes_visited, prims_tested;   /* closest + any, when counting is enabled (count_traversal option) */
   double ms_total, ms_raygen, ms_closest, ms_any, ms_shade, ms_film;
   uint64_t closest_launches, any_launches;
+  uint64_t closest_nodes, closest_prims;  /* split of nodes_visited / prims_tested per kernel: the roofline's */
+  uint64_t any_nodes, any_prims;          /* algorithmic-byte model needs the closest-hit kernel's own counts */
 } rrt_render_stats;
 
 /* ---- host side: scene build (stays on the host in the north_star) -------- */

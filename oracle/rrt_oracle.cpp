@@ -681,7 +681,10 @@ bool scene_intersect(const Scene& sc, Ray* r, SI* si, HitInfo* hi, Counters* cnt
   if (d->n_bvh_nodes == 0) return false;
   V3 inv_dir(1.0 / r->d.x, 1.0 / r->d.y, 1.0 / r->d.z);
   int dir_is_neg[3] = {inv_dir.x < 0.0, inv_dir.y < 0.0, inv_dir.z < 0.0};
-  std::vector<uint32_t> stack(std::max<uint32_t>(64, d->bvh_depth + 2));
+  uint32_t stack_small[128];
+  std::vector<uint32_t> stack_big;
+  uint32_t* stack = stack_small;
+  if (d->bvh_depth + 2 > 128) { stack_big.resize(d->bvh_depth + 2); stack = stack_big.data(); }
   size_t to_visit = 0;
   uint32_t cur = 0;
   uint32_t nn = 0, np = 0;
@@ -724,7 +727,10 @@ bool scene_intersect_p(const Scene& sc, const Ray& r, Counters* cnt, uint32_t* n
   if (d->n_bvh_nodes == 0) return false;
   V3 inv_dir(1.0 / r.d.x, 1.0 / r.d.y, 1.0 / r.d.z);
   int dir_is_neg[3] = {inv_dir.x < 0.0, inv_dir.y < 0.0, inv_dir.z < 0.0};
-  std::vector<uint32_t> stack(std::max<uint32_t>(64, d->bvh_depth + 2));
+  uint32_t stack_small[128];
+  std::vector<uint32_t> stack_big;
+  uint32_t* stack = stack_small;
+  if (d->bvh_depth + 2 > 128) { stack_big.resize(d->bvh_depth + 2); stack = stack_big.data(); }
   size_t to_visit = 0;
   uint32_t cur = 0, nn = 0, np = 0;
   bool result = false;

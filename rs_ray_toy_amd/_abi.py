@@ -123,7 +123,9 @@ class RenderStats(C.Structure):
                 ("any_queries", C.c_uint64), ("nodes_visited", C.c_uint64), ("prims_tested", C.c_uint64),
                 ("ms_total", C.c_double), ("ms_raygen", C.c_double), ("ms_closest", C.c_double),
                 ("ms_any", C.c_double), ("ms_shade", C.c_double), ("ms_film", C.c_double),
-                ("closest_launches", C.c_uint64), ("any_launches", C.c_uint64)]
+                ("closest_launches", C.c_uint64), ("any_launches", C.c_uint64),
+                ("closest_nodes", C.c_uint64), ("closest_prims", C.c_uint64), ("any_nodes", C.c_uint64),
+                ("any_prims", C.c_uint64)]
 
 
 # every symbol include/rrt.h declares (tests/test_abi.py checks the library exports all of them)

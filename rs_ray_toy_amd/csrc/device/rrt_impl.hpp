@@ -319,6 +319,7 @@ class Handle : public HandleBase {
       stats->any_queries = ht[3];
       stats->nodes_visited = ht[0] + ht[5];
       stats->prims_tested = ht[1] + ht[6];
+      stats->closest_nodes = ht[0]; stats->closest_prims = ht[1]; stats->any_nodes = ht[5]; stats->any_prims = ht[6];
       stats->closest_launches = n_closest_launch;
       stats->any_launches = n_any_launch;
       float ms = 0;

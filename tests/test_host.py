@@ -1,0 +1,216 @@
+"""Host scene builder (loader, OBJ parser, BVH, Halton tables, camera init, resolve/PNG) against the reference's
+fixtures and the plain-Python restatement in oracle/host_ref.py. CPU only."""
+import json
+import os
+import sys
+
+import numpy as np
+import pytest
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, os.path.join(ROOT, "oracle"))
+import host_ref as HR  # noqa: E402
+
+from rs_ray_toy_amd import (RRT_FIXED_BVH, RrtError, RrtPanic, RrtUnsupported, Scene, resolve_rgba8, scenes,  # noqa: E402
+                            write_png)
+from rs_ray_toy_amd import _abi as A  # noqa: E402
+
+GOLDEN = os.path.join(ROOT, "tests", "golden")
+
+
+@pytest.fixture(scope="module")
+def sample_scene():
+    """tests/golden/scene.json + cube.obj are the reference's samples/ fixtures (data, loaded unmodified)."""
+    return Scene.load(os.path.join(GOLDEN, "scene.json"))
+
+
+def test_samples_scene_json_loads_unmodified(sample_scene):
+    d = sample_scene.desc
+    # SURVEY §7.3 golden: 36 instanced triangles (3 x cube.obj), 3 lights, 4 materials
+    assert (d.n_prims, d.n_tris, d.n_positions, d.n_normals, d.n_lights, d.n_materials) == (36, 12, 8, 6, 3, 4)
+    assert d.integrator.type == A.RRT_INT_DEBUG and d.sampler.type == A.RRT_SAMPLER_STRATIFIED
+    assert (d.film.xres, d.film.yres) == (640, 360) and d.film.filter_type == A.RRT_FILTER_BOX
+    assert d.film.diagonal == pytest.approx(0.02) and d.camera.n_elems == 13
+    # declared-but-unused textures load (ImageTexture's file is missing -> not registered, like the reference)
+    assert any("unsupported Element" in w for w in sample_scene.warnings)        # "o Cube", "s off"
+    # point lights sit at the origin whatever world_pos says (Q17)
+    assert all(list(d.lights[i].p_light) == [0.0, 0.0, 0.0] for i in range(3))
+    assert list(d.lights[1].spectrum) == [800.0, 0.0, 0.0]
+    # materials: Metal defaults are the copper constants derived in SURVEY §8c
+    m = d.materials[0]
+    assert m.type == A.RRT_MAT_METAL
+    np.testing.assert_allclose(list(m.eta), [0.19998972096819712, 0.922085788777433, 1.0998762520488314], rtol=0)
+    np.testing.assert_allclose(list(m.k), [3.9046381767086675, 2.4476332238684626, 2.1376510366555137], rtol=0)
+    assert d.materials[1].type == A.RRT_MAT_PLASTIC and list(d.materials[1].kd) == [0.25] * 3 and d.materials[1].roughness == 0.1
+    assert d.materials[2].type == A.RRT_MAT_MATTE and list(d.materials[2].kd) == [0.5] * 3
+
+
+def _prim_bounds(d):
+    P = np.array([d.positions[i] for i in range(3 * d.n_positions)]).reshape(-1, 3)
+    out = []
+    for i in range(d.n_prims):
+        pr = d.prims[i]
+        t = d.tris[pr.shape]
+        v = P[[t.v[0], t.v[1], t.v[2]]]
+        b = np.concatenate([v.min(0), v.max(0)])
+        if pr.instance >= 0:
+            b = HR.transform_bounds(list(d.xforms[pr.instance].m), b)
+        out.append(b)
+    return np.array(out)
+
+
+@pytest.mark.parametrize("flags", [0, RRT_FIXED_BVH])
+def test_bvh_matches_python_restatement(flags):
+    sc = Scene.load(os.path.join(GOLDEN, "scene.json"), flags=flags)
+    d = sc.desc
+    nodes, order = HR.build_bvh(_prim_bounds(d), d.max_prims_in_node, fix_slice=bool(flags & 1), fix_sah=bool(flags & 2))
+    assert d.n_bvh_nodes == len(nodes) and [d.prim_order[i] for i in range(d.n_prim_order)] == order
+    for i, (b, off, npr, axis) in enumerate(nodes):
+        n = d.bvh_nodes[i]
+        assert (n.offset, n.n_primitives, n.axis) == (off, npr, axis), i
+        np.testing.assert_allclose(list(n.bounds), b, rtol=0, atol=1e-12)
+    assert sorted(order) == list(range(36))       # small treelets: Q26 duplicates nothing here
+
+
+def test_bvh_reference_quirks_on_a_larger_mesh(tmp_path):
+    """Q26 (second child built from the same slice start) drops and duplicates triangles once treelets split."""
+    cfg, root = scenes.cfg4(str(tmp_path), xres=32, yres=32, nsamp=3, n=24)     # 1152 triangles
+    compat, fixed = Scene.loads(cfg, root, flags=0), Scene.loads(cfg, root, flags=RRT_FIXED_BVH)
+    oc = [compat.desc.prim_order[i] for i in range(compat.desc.n_prim_order)]
+    of = [fixed.desc.prim_order[i] for i in range(fixed.desc.n_prim_order)]
+    assert len(oc) == len(of) == 1152 and sorted(of) == list(range(1152))
+    assert len(set(oc)) < 1152                    # the reference-exact tree really loses triangles
+    nodes, order = HR.build_bvh(_prim_bounds(compat.desc), 4)
+    assert order == oc and len(nodes) == compat.desc.n_bvh_nodes
+    nodes, order = HR.build_bvh(_prim_bounds(fixed.desc), 4, True, True)
+    assert order == of and len(nodes) == fixed.desc.n_bvh_nodes
+
+
+def test_halton_tables(tmp_path):
+    for res in ((256, 256), (512, 512), (640, 360), (1024, 1024), (96, 40)):
+        cfg, root = scenes.cfg2(str(tmp_path), xres=res[0], yres=res[1], nsamp=7)
+        s = Scene.loads(cfg, root).desc.sampler
+        scales, exps, stride, minv = HR.halton_params(*res)
+        assert (list(s.base_scales), list(s.base_exponents), s.sample_stride, list(s.mult_inverse)) == (scales, exps, stride, minv)
+    # every film >= 128 px per side
+    assert (scales, exps, stride, minv) != ([128, 243], [7, 5], 31104, [59, 131])        # (96, 40) differs
+    assert HR.halton_params(1024, 1024) == ([128, 243], [7, 5], 31104, [59, 131])
+    # seeded digit permutations: each block is a permutation of 0..p-1, reproducible, seed-dependent
+    cfg, root = scenes.cfg2(str(tmp_path), xres=64, yres=64, nsamp=3)
+    a, b, c = Scene.loads(cfg, root), Scene.loads(cfg, root), Scene.loads(cfg, root, perm_seed=1)
+    pa = np.ctypeslib.as_array(a.desc.sampler.perms, (a.desc.sampler.n_perms,)).copy()
+    pb = np.ctypeslib.as_array(b.desc.sampler.perms, (b.desc.sampler.n_perms,))
+    pc = np.ctypeslib.as_array(c.desc.sampler.perms, (c.desc.sampler.n_perms,))
+    assert len(pa) == 3682913 and np.array_equal(pa, pb) and not np.array_equal(pa, pc)
+    off = 0
+    for p in (2, 3, 5, 7, 11, 13, 17, 19, 23, 29):
+        assert sorted(pa[off:off + p]) == list(range(p))
+        off += p
+
+
+def test_camera_init_matches_numpy_restatement(sample_scene):
+    d = sample_scene.desc
+    elems = [(e.curvature_radius, e.thickness, e.eta, e.aperture_radius) for e in (d.camera.elems[i] for i in range(13))]
+    # lens table ingest camera.rs:80-99: mm -> m, aperture diameter -> radius, stop clamped to its element's value
+    assert elems[0][0] == pytest.approx(0.07197476) and elems[5][0] == 0.0 and elems[5][3] == pytest.approx(17.512e-3 / 2)
+    # thick-lens focus (camera.rs:332-358) moved the film: rear thickness != lens_data's 0
+    assert 0.02 < elems[-1][1] < 0.04
+    for slab in (0, 63):
+        assert d.camera.exit_pupil_valid[slab] == 1
+        r0, r1 = slab / 64 * d.film.diagonal / 2, (slab + 1) / 64 * d.film.diagonal / 2
+        ref = HR.bound_exit_pupil(elems, r0, r1)
+        np.testing.assert_allclose(list(d.camera.exit_pupil_bounds[slab]), ref, rtol=0, atol=1e-12)
+    b0 = list(d.camera.exit_pupil_bounds[0])
+    assert b0[0] < 0 < b0[2] and (b0[0] + b0[2]) < 0     # Q7: expand() shifts the box by -delta
+
+
+def test_reference_test_realistic_camera_configuration(tmp_path):
+    """camera.rs:640-700: 320x180 film, 35 mm diagonal, the same 13-interface lens, aperture 1, focus 10."""
+    cfg, root = scenes.cfg2(str(tmp_path), xres=320, yres=180, nsamp=3)
+    cfg["Film"]["diagonal"] = 35
+    cfg["Camera"] = dict(scenes.CAMERA, aperture_diameter=1.0, focus_distance=10)
+    d = Scene.loads(cfg, root).desc
+    assert d.camera.n_elems == 13 and d.camera.elems[5].aperture_radius == pytest.approx(0.5e-3)
+
+
+def test_loader_error_behaviour(tmp_path):
+    cfg, root = scenes.cfg2(str(tmp_path), xres=32, yres=32, nsamp=3)
+    bad = dict(cfg); bad.pop("Aggregate")
+    with pytest.raises(RrtPanic, match="No Aggregate Config"):
+        Scene.loads(bad, root)
+    bad = json.loads(json.dumps(cfg)); bad["Camera"].pop("lens_data")
+    with pytest.raises(RrtPanic, match="lens_data"):
+        Scene.loads(bad, root)
+    bad = json.loads(json.dumps(cfg)); bad["Sampler"] = {"sampler_type": "Sobol"}
+    with pytest.raises(RrtPanic, match="Unsupported Sampler"):
+        Scene.loads(bad, root)
+    bad = json.loads(json.dumps(cfg)); bad["Integrator"] = {"integrator_type": "SPPM"}
+    with pytest.raises(RrtUnsupported):
+        Scene.loads(bad, root)
+    bad = json.loads(json.dumps(cfg)); bad["materials"].append({"material_type": "GlassMaterial", "material_name": "g"})
+    Scene.loads(bad, root)                                  # declared but unused: loads, like the reference
+    bad["Aggregate"]["primitives"][0]["material_name"] = "g"
+    with pytest.raises(RrtUnsupported, match="GlassMaterial"):
+        Scene.loads(bad, root)
+    with pytest.raises(RrtError):
+        Scene.loads("{ not json", root)
+    # unknown material / primitive types are skipped with a diagnostic, not fatal (renderprocess.rs:864,1290)
+    ok = json.loads(json.dumps(cfg)); ok["materials"].append({"material_type": "Velvet", "material_name": "v"})
+    ok["Aggregate"]["primitives"].append({"primitive_type": "cone"})
+    sc = Scene.loads(ok, root)
+    assert any("Unsupported Material Type Velvet" in w for w in sc.warnings) and any("Unsupported primitive_type! cone" in w for w in sc.warnings)
+    # integer-typed keys ignore non-integer JSON numbers (serde_json as_i64): xres 64.0 falls back to 1280
+    f = json.loads(json.dumps(cfg)); f["Film"]["xres"] = 64.0
+    assert Scene.loads(f, root).desc.film.xres == 1280
+    # constant-valued textures are folded; a non-constant one used by a material is refused loudly
+    t = json.loads(json.dumps(cfg))
+    t["rgb_texture"] = [{"texture_name": "red", "texture_type": "BilerpTexture", "v00": {"values": [0.8, 0.1, 0.1]}, "v01": {"values": [0.8, 0.1, 0.1]}},
+                        {"texture_name": "uv", "texture_type": "UVTexture"}]
+    t["materials"][2]["kd"] = "red"
+    assert list(Scene.loads(t, root).desc.materials[2].kd) == [0.8, 0.1, 0.1]
+    t["materials"][2]["kd"] = "uv"
+    with pytest.raises(RrtUnsupported, match="non-constant"):
+        Scene.loads(t, root)
+
+
+def test_objparser_rules(tmp_path):
+    obj = tmp_path / "m.obj"
+    obj.write_text("# comment\n#nospace is an unsupported element\nv 0 0 0\nv 1 0 0\nv 0 1 0\nv 0 0 1\nvt 0.5 0.5\n"
+                   "f 1 2 3\nf 1/1 2/1 3/1 4/1\ng group\nf 2//9 3//9 4//9\n")
+    cfg, root = scenes.cfg2(str(tmp_path), xres=32, yres=32, nsamp=3)
+    cfg["objs"] = [{"filename": "./m.obj", "obj_name": "cube_01"}]
+    with pytest.raises(RrtPanic, match="uv_indices"):       # mixed faces with / without vt: objparser.rs:63 assert
+        Scene.loads(cfg, root)
+    obj.write_text("v 0 0 0\nv 1 0 0\nv 0 1 0\nv 0 0 1\nf 1 2 3 4\nf 2//9 3//9 4//9\nx y z\n")
+    sc = Scene.loads(cfg, root)
+    assert sc.desc.n_tris == 2                               # quads keep their first three vertices; vn index 9 ignored
+    assert sum("unsupported Element" in w for w in sc.warnings) == 1
+    obj.write_text("v 0 0 0\nv 1 0 0\nv 0 1 0\nf 0 1 2\n")
+    with pytest.raises(RrtPanic, match="underflow"):        # `i - 1` on index 0
+        Scene.loads(cfg, root)
+    obj.write_text("v 0 0\n")
+    # parse error -> diagnostic, mesh missing -> primitive skipped -> empty aggregate -> bvh.rs:319 assert
+    with pytest.raises(RrtPanic, match="primitives.len"):
+        Scene.loads(cfg, root)
+
+
+def test_resolve_and_png(tmp_path):
+    from PIL import Image
+    film = np.zeros((2, 3, 4))
+    # XYZ of rgb (0.5, 0.25, 1.0) summed over 4 samples, filter_weight_sum = 3 * 4 (Q3)
+    rgb = np.array([0.5, 0.25, 1.0]) * 4
+    M = np.array([[0.412453, 0.357580, 0.180423], [0.212671, 0.715160, 0.072169], [0.019334, 0.119193, 0.950227]])
+    film[0, 0, :3] = M @ rgb
+    film[0, 0, 3] = 12
+    film[1, 2, :3] = M @ np.array([1e-3, 1e-3, 1e-3]); film[1, 2, 3] = 3
+    out = resolve_rgba8(film, 1.0)
+
+    def q(v):
+        g = 12.92 * v if v <= 0.0031308 else 1.055 * v ** (1 / 2.4) - 0.055
+        return int(min(255.0, max(0.0, 255 * g + 0.5)))
+    assert list(out[0, 0]) == [q(0.5 / 3), q(0.25 / 3), q(1.0 / 3), 255]
+    assert list(out[1, 2]) == [q(1e-3 / 3)] * 3 + [255] and list(out[0, 1]) == [0, 0, 0, 255]
+    assert np.array_equal(resolve_rgba8(film.astype(np.float32), 1.0), out)
+    p = str(tmp_path / "o.png")
+    write_png(p, out)
+    assert np.array_equal(np.array(Image.open(p)), out)

