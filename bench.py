@@ -101,19 +101,12 @@ def main():
     r = Renderer(scene, local_rank, RRT_F32)
     if args.max_paths:
         r.set_option("max_paths", args.max_paths)
-    rects = band_rects(W, H, rank, world)
     film = torch.zeros((H, W, 4), dtype=torch.float32, device=f"cuda:{local_rank}")
 
     def step(collect=False):
         film.zero_()
-        agg = None
-        for rect in rects:
-            st = r.render_device(rect, film.data_ptr(), stats=collect)
-            if collect:
-                if agg is None:
-                    agg = {k: 0 for k, _ in st._fields_}
-                for k, _ in st._fields_:
-                    agg[k] += getattr(st, k)
+        st = r.render_bands_device(rank, world, film.data_ptr(), stats=collect)
+        agg = {k: getattr(st, k) for k, _ in st._fields_} if collect else None
         reduce_film(film, world)  # disjoint bands: the sum reassembles the frame on rank 0 (RCCL over xGMI)
         return agg
 

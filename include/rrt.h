@@ -281,7 +281,13 @@ int rrt_camera_samples(rrt_handle*, const int32_t rect[4], uint64_t s0, uint64_t
 int rrt_render_rect(rrt_handle*, const int32_t rect[4], void* film_xyzw, int film_mem,
                     rrt_render_stats* stats /* may be NULL */);
 
-/* wavefront pool sizing: max paths in flight per pass (0 = default) */
+/* Multi-GPU film partition: the same, for the rows of the interleaved 16-row tile bands b with
+ * b % world == rank (tile height of integrator/mod.rs:55), rendered as one pixel set. Disjoint across ranks under
+ * the box filter, so summing the ranks' films (one RCCL reduce) reassembles Film::pixels. */
+int rrt_render_bands(rrt_handle*, int rank, int world, void* film_xyzw, int film_mem, rrt_render_stats* stats);
+
+/* handle options: "max_paths" (wavefront pool slots), "count_traversal" (per-kernel node/triangle counters),
+ * "persistent_traversal" (0 = generic traversal kernels) */
 int rrt_set_option(rrt_handle*, const char* key, double value);
 
 const char* rrt_last_error(void);

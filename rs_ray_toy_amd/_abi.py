@@ -147,6 +147,7 @@ PROTOTYPES = {
     "rrt_camera_samples": (C.c_int, [C.c_void_p, C.POINTER(C.c_int32), C.c_uint64, C.c_uint64, C.c_void_p,
                                      C.c_void_p, C.c_void_p]),
     "rrt_render_rect": (C.c_int, [C.c_void_p, C.POINTER(C.c_int32), C.c_void_p, C.c_int, C.POINTER(RenderStats)]),
+    "rrt_render_bands": (C.c_int, [C.c_void_p, C.c_int, C.c_int, C.c_void_p, C.c_int, C.POINTER(RenderStats)]),
     "rrt_set_option": (C.c_int, [C.c_void_p, C.c_char_p, C.c_double]),
     "rrt_last_error": (C.c_char_p, []),
     "rrt_version": (C.c_char_p, []),

@@ -165,6 +165,19 @@ class Renderer:
         _check(A.lib().rrt_render_rect(self._h, r, film.ctypes.data, A.RRT_MEM_HOST, C.byref(st) if stats else None))
         return (film, st) if stats else film
 
+    def render_bands_device(self, rank, world, film_ptr, stats=True):
+        """This rank's interleaved 16-row bands (partition.py) into a device film (+=)."""
+        st = A.RenderStats()
+        _check(A.lib().rrt_render_bands(self._h, rank, world, film_ptr, A.RRT_MEM_DEVICE, C.byref(st) if stats else None))
+        return st
+
+    def render_bands(self, rank, world, film=None):
+        W, H = self.scene.resolution
+        if film is None:
+            film = np.zeros((H, W, 4), self.dtype)
+        _check(A.lib().rrt_render_bands(self._h, rank, world, film.ctypes.data, A.RRT_MEM_HOST, None))
+        return film
+
     def render_device(self, rect, film_ptr, stats=True):
         st = A.RenderStats()
         r = (C.c_int32 * 4)(*rect)

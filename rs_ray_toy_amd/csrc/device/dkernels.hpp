@@ -7,7 +7,7 @@
 namespace rrtd {
 
 constexpr int kBlock = 256;
-enum { C_ACTIVE = 0, C_NEXT = 1, C_SHADOW = 2, C_CAMERA_RAYS = 3, C_ERROR = 4, C_CLOSEST_Q = 5, C_ANY_Q = 6, C_NODES = 8, C_PRIMS = 10, C_COUNT = 16 };
+enum { C_ACTIVE = 0, C_NEXT = 1, C_SHADOW = 2, C_CAMERA_RAYS = 3, C_ERROR = 4, C_WORK_CLOSEST = 5, C_WORK_SHADOW = 6, C_WORK_AUX = 7, C_COUNT = 16 };
 enum { ERR_SHADING_NORMAL = 1, ERR_STACK = 2, ERR_BETA = 4 };
 
 // ------------------------------------------------------------------------------------------------------------
@@ -51,7 +51,7 @@ RRT_DEV bool tri_closest(const Tri<R>& t, const RayCtx<R>& r, R* th, R* uh, R* v
   V3<R> P = cross(r.d, E2);
   R a = dot(E1, P);
   if (a > R(-0.0000001) && a < R(0.0000001)) return false;
-  R f = R(1) / a;
+  R f = rcp_r(a);
   V3<R> T = r.o - p0;
   R u = f * dot(T, P);
   if (u < R(0) || u > R(1)) return false;
@@ -71,7 +71,7 @@ RRT_DEV bool tri_any(const Tri<R>& t, const RayCtx<R>& r) {
   V3<R> P = cross(r.d, E2);
   R a = dot(E1, P);
   if (a > R(-0.0000001) && a < R(0.0000001)) return false;
-  R f = R(1) / a;
+  R f = rcp_r(a);
   V3<R> T = r.o - p0;
   R u = f * dot(T, P);
   if (u < R(0) || u > R(1)) return false;
@@ -247,17 +247,27 @@ struct PassDesc {
   int32_t rx0, ry0, rw;        // rect origin / width the pixel group is enumerated in
   uint32_t pix_begin, npix;    // pixel group [pix_begin, pix_begin + npix) in rect-linear order
   uint32_t s_begin, ns;        // sample_num range [s_begin, s_begin + ns)
+  // interleaved row bands (multi-GPU film partition): local row r -> y = ry0 + ((r / band_h) * n_ranks + rank) * band_h + r % band_h
+  uint32_t band_h, n_ranks, rank;
 };
+RRT_DEV void pass_pixel(const PassDesc& pd, uint32_t lin, uint32_t* px, uint32_t* py) {
+  const uint32_t row = lin / (uint32_t)pd.rw;
+  *px = (uint32_t)pd.rx0 + lin % (uint32_t)pd.rw;
+  *py = (uint32_t)pd.ry0 + ((row / pd.band_h) * pd.n_ranks + pd.rank) * pd.band_h + row % pd.band_h;
+}
 
+// Stage 1 (every slot): Halton index + dims 0..3, film point, lens sample, and the *main* lens trace
+// (generate_ray, camera.rs:534-580). About 70 % of the samples die here (lens samples are drawn in [0.5,1.5)^2,
+// Q5); the survivors are compacted into q_next so that stage 2 runs with full lanes.
 template <typename R>
-__global__ void __launch_bounds__(kBlock) k_raygen(SceneDev<R> s, Pools<R> p, PassDesc pd, double* dbg_dims, double* dbg_ray, double* dbg_w) {
+__global__ void __launch_bounds__(kBlock) k_raygen(SceneDev<R> s, Pools<R> p, PassDesc pd, double* dbg_dims) {
   const uint32_t slot = blockIdx.x * blockDim.x + threadIdx.x;
   const uint32_t total = pd.npix * pd.ns;
   bool alive = false;
   if (slot < total) {
     const uint32_t pl = slot % pd.npix, sl = slot / pd.npix;
-    const uint32_t lin = pd.pix_begin + pl;
-    const uint32_t px = (uint32_t)pd.rx0 + lin % (uint32_t)pd.rw, py = (uint32_t)pd.ry0 + lin / (uint32_t)pd.rw;
+    uint32_t px, py;
+    pass_pixel(pd, pd.pix_begin + pl, &px, &py);
     const uint32_t sample_num = pd.s_begin + sl;
     const uint32_t index = halton_pixel_offset(s, px, py) + sample_num * s.stride;
     const double d0 = halton_dim(s, index, 0), d1 = halton_dim(s, index, 1), d2 = halton_dim(s, index, 2), d3 = halton_dim(s, index, 3);
@@ -265,12 +275,12 @@ __global__ void __launch_bounds__(kBlock) k_raygen(SceneDev<R> s, Pools<R> p, Pa
     const R pfx = (R)px + to_real<R>(d0), pfy = (R)py + to_real<R>(d1);
     const R lx = to_real<R>(d2) + R(0.5), ly = to_real<R>(d3) + R(0.5);  // Q5
     RayT<R> ray;
-    const R w = generate_ray_differential(s, pfx, pfy, lx, ly, &ray);
-    alive = w > R(0);
+    const R w = generate_ray(s, pfx, pfy, lx, ly, &ray);
+    alive = w != R(0);
     p.pixel[slot] = py * (uint32_t)s.xres + px;
     p.hindex[slot] = index;
     p.dim_bounce[slot] = 5u;
-    p.weight[slot] = w;
+    p.weight[slot] = alive ? w : R(0);
     p.pfx[slot] = pfx; p.pfy[slot] = pfy;
     p.lr[slot] = R(0); p.lg[slot] = R(0); p.lb[slot] = R(0);
     p.br[slot] = R(1); p.bg[slot] = R(1); p.bb[slot] = R(1);
@@ -279,21 +289,58 @@ __global__ void __launch_bounds__(kBlock) k_raygen(SceneDev<R> s, Pools<R> p, Pa
       p.dx[slot] = ray.d.x; p.dy[slot] = ray.d.y; p.dz[slot] = ray.d.z;
       p.tmax[slot] = Const<R>::inf;
       p.skip[slot] = -1;
+      p.sox[slot] = lx; p.soy[slot] = ly;   // lens sample parked in the (idle) shadow-ray arrays for stage 2
     }
     if (dbg_dims) {
       double* dd = dbg_dims + 5 * (size_t)(pl * pd.ns + sl);   // [pixel][sample]
       dd[0] = d0; dd[1] = d1; dd[2] = d2; dd[3] = d3; dd[4] = halton_dim(s, index, 4);
-      double* rr = dbg_ray + 6 * (size_t)(pl * pd.ns + sl);
-      rr[0] = alive ? (double)ray.o.x : 0.0; rr[1] = alive ? (double)ray.o.y : 0.0; rr[2] = alive ? (double)ray.o.z : 0.0;
-      rr[3] = alive ? (double)ray.d.x : 0.0; rr[4] = alive ? (double)ray.d.y : 0.0; rr[5] = alive ? (double)ray.d.z : 0.0;
-      dbg_w[pl * pd.ns + sl] = (double)w;
     }
+  }
+  const uint32_t q = wave_push(&p.counters[C_NEXT], alive);
+  if (alive) p.q_next[q] = slot;
+}
+
+// Stage 2 (survivors): the auxiliary rays of generate_ray_differential (camera.rs:582-628) at p_film +- 0.05 px in
+// x then y. Only whether they make it through the lens is observable (the differentials feed texture filtering,
+// and only constant textures are in scope): a sample whose x or y pair both fail gets weight 0.
+template <typename R>
+__global__ void __launch_bounds__(kBlock) k_raygen_aux(SceneDev<R> s, Pools<R> p) {
+  const uint32_t i = blockIdx.x * blockDim.x + threadIdx.x;
+  const uint32_t n = p.counters[C_NEXT];
+  bool alive = false;
+  uint32_t slot = 0;
+  if (i < n) {
+    slot = p.q_next[i];
+    const R pfx = p.pfx[slot], pfy = p.pfy[slot], lx = p.sox[slot], ly = p.soy[slot];
+    RayT<R> aux;
+    R wtx = generate_ray(s, pfx + R(0.05), pfy, lx, ly, &aux);
+    if (wtx == R(0)) wtx = generate_ray(s, pfx + R(-0.05), pfy, lx, ly, &aux);
+    R wty = R(0);
+    if (wtx != R(0)) {
+      wty = generate_ray(s, pfx, pfy + R(0.05), lx, ly, &aux);
+      if (wty == R(0)) wty = generate_ray(s, pfx, pfy + R(-0.05), lx, ly, &aux);
+    }
+    alive = wtx != R(0) && wty != R(0) && p.weight[slot] > R(0);   // `if ray_weight > 0.0` integrator/mod.rs:100
+    if (!(wtx != R(0) && wty != R(0))) p.weight[slot] = R(0);
   }
   const bool enqueue = alive && s.integrator != 3;  // AOIntegrator::li returns 0 before drawing (ao.rs:62-64)
   const uint32_t q = wave_push(&p.counters[C_ACTIVE], enqueue);
   if (enqueue) p.q_active[q] = slot;
-  const uint32_t cr = wave_push(&p.counters[C_CAMERA_RAYS], alive);
-  (void)cr;
+  (void)wave_push(&p.counters[C_CAMERA_RAYS], alive);
+}
+
+// debug / unit-test surface of rrt_camera_samples: rays + weights of a pass, [pixel][sample] order
+template <typename R>
+__global__ void __launch_bounds__(kBlock) k_camera_dump(Pools<R> p, PassDesc pd, double* dbg_ray, double* dbg_w) {
+  const uint32_t slot = blockIdx.x * blockDim.x + threadIdx.x;
+  if (slot >= pd.npix * pd.ns) return;
+  const uint32_t pl = slot % pd.npix, sl = slot / pd.npix;
+  const double w = (double)p.weight[slot];
+  const bool alive = w > 0.0;
+  double* rr = dbg_ray + 6 * (size_t)(pl * pd.ns + sl);
+  rr[0] = alive ? (double)p.ox[slot] : 0.0; rr[1] = alive ? (double)p.oy[slot] : 0.0; rr[2] = alive ? (double)p.oz[slot] : 0.0;
+  rr[3] = alive ? (double)p.dx[slot] : 0.0; rr[4] = alive ? (double)p.dy[slot] : 0.0; rr[5] = alive ? (double)p.dz[slot] : 0.0;
+  dbg_w[pl * pd.ns + sl] = w;
 }
 
 // ------------------------------------------------------------------------------------------------------------
@@ -682,7 +729,10 @@ __global__ void __launch_bounds__(kBlock) k_shade_specular(SceneDev<R> s, Pools<
 static __global__ void k_rotate(uint32_t* c, int what) {
   if (what == 0) { c[C_ACTIVE] = c[C_NEXT]; c[C_NEXT] = 0; c[C_SHADOW] = 0; }
   else if (what == 1) { c[C_SHADOW] = 0; }
+  else if (what == 3) { /* only the work counters */ }
+  else if (what == 4) { c[C_NEXT] = 0; }
   else { c[C_ACTIVE] = 0; c[C_NEXT] = 0; c[C_SHADOW] = 0; }
+  c[C_WORK_CLOSEST] = 0; c[C_WORK_SHADOW] = 0; c[C_WORK_AUX] = 0;
 }
 static __global__ void k_accumulate_counts(uint32_t* c, unsigned long long* totals) {
   // totals[2] closest queries, totals[3] shadow queries, totals[4] camera rays

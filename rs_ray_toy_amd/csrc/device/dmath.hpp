@@ -25,6 +25,9 @@ template <> struct Const<double> {
 #define RRT_PI_OVER_4 0.78539816339744830961
 
 template <typename R> RRT_DEV R rsqrt_(R x) { return sqrt(x); }
+// 1/a of the Moller-Trumbore tests: exact division in the f64 parity mode, v_rcp_f32 (1 ulp) in the fp32 product
+RRT_DEV double rcp_r(double a) { return 1.0 / a; }
+RRT_DEV float rcp_r(float a) { return __builtin_amdgcn_rcpf(a); }
 template <typename R> RRT_DEV R rabs(R x) { return fabs(x); }
 template <typename R> RRT_DEV R rmax(R a, R b) { return fmax(a, b); }   // Rust f64::max
 template <typename R> RRT_DEV R rmin(R a, R b) { return fmin(a, b); }

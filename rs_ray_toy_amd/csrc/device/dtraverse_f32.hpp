@@ -1,0 +1,371 @@
+// fp32 production traversal kernels for gfx950.
+//
+// Layout: interior nodes are re-packed on the host into 64-byte "pair" nodes that hold BOTH children's boxes
+// (first child = linear index + 1, second child = LinearBVHNode::offset, bvh.rs:728-751), so one step of the
+// walk costs one dependent 64 B fetch instead of two dependent 32 B fetches. The reference tests the second
+// child's box later, with the t_max left by the first subtree; here it is tested together with the first one
+// and pushed with its entry distance, and the one t_max-dependent comparison (`t_min < ray.t_max`,
+// geometry.rs:1799) is repeated at pop time. t_max only shrinks, and every other part of the box test does not
+// depend on it, so each ray makes exactly the decisions BVHAccel::intersect / intersect_p make, in the same
+// order (near child by split-axis sign, leaf triangles in ordered_prims order, every accepted hit overwrites the
+// previous one: Q10) — results are bit-identical to the generic kernels in dkernels.hpp (tests compare them).
+//
+// What bounds these kernels on MI355X is the vector L1 (TCP): every lane's 16 B fetch of its own node touches a
+// different cache line, and the TCP retires about one line per clock per CU, so time ~ (lines touched) / (CUs x clk).
+// Hence (a) the top kTreeletNodes pair nodes (BFS order: the levels every ray walks) are staged in LDS once per
+// workgroup and read with ds_read_b128 — no TCP traffic for them; (b) the traversal stack lives in LDS
+// ([entry][thread], conflict-free), entries beyond kStackLds spill to a strided global array; (c) workgroups are
+// persistent (grid-stride over the ray queue), so the treelet is loaded once per workgroup, not once per 512 rays.
+#pragma once
+#include "dkernels.hpp"
+
+namespace rrtd {
+
+constexpr int kTravBlock = 512;     // 8 waves share one LDS copy of the treelet
+constexpr int kStackLds = 8;        // LDS stack entries per thread (8 B each); deeper entries spill to global
+constexpr int kTreeletNodes = 512;  // top of the tree (BFS order) staged in LDS: 512 pair nodes = 32 KB
+
+struct alignas(64) PairNode {
+  float b0min[3], b0max[3];   // first child's box (linear index + 1)
+  float b1min[3], b1max[3];   // second child's box
+  uint32_t ref0, ref1;        // interior child: PairNode index; leaf child: first triangle
+  uint32_t meta;              // bits 0-1 split axis, bits 2-13 n_prims of child 0 (0 = interior), bits 14-25 of child 1
+  uint32_t pad;
+};
+
+struct F4 { float x, y, z, w; };
+RRT_DEV F4 ld4(const float* p) { const float4 v = *reinterpret_cast<const float4*>(p); return {v.x, v.y, v.z, v.w}; }
+
+struct LaneRay {
+  float ox, oy, oz, dx, dy, dz, ix, iy, iz, tmax;
+  uint32_t neg;       // bit k: inv_dir[k] < 0
+  uint32_t skip_plane;
+};
+
+// Bounds3::intersect_p geometry.rs:1767-1800, split: everything except the `t_min < ray.t_max` comparison.
+// Returns false when the slabs miss or t_max <= 0; *tmin_out is the entry distance compared against ray.t_max.
+// Straight-line form of the reference's sequence of ifs: the same comparisons on the same values (a comparison
+// with NaN is false in both), evaluated unconditionally instead of returning early.
+RRT_DEV bool box_slabs_f32(float bminx, float bminy, float bminz, float bmaxx, float bmaxy, float bmaxz, const LaneRay& r, float* tmin_out) {
+  const float g = 1.0f + 2.0f * ((3.0f * 5.9604645e-8f) / (1.0f - 3.0f * 5.9604645e-8f));
+  const bool nx = r.neg & 1u, ny = r.neg & 2u, nz = r.neg & 4u;
+  float t_min = ((nx ? bmaxx : bminx) - r.ox) * r.ix;
+  float t_max = ((nx ? bminx : bmaxx) - r.ox) * r.ix;
+  const float ty_min = ((ny ? bmaxy : bminy) - r.oy) * r.iy;
+  float ty_max = ((ny ? bminy : bmaxy) - r.oy) * r.iy;
+  t_max *= g;
+  ty_max *= g;
+  const bool miss_xy = (t_min > ty_max) | (ty_min > t_max);
+  t_min = (ty_min > t_min) ? ty_min : t_min;
+  t_max = (ty_max < t_max) ? ty_max : t_max;
+  const float tz_min = ((nz ? bmaxz : bminz) - r.oz) * r.iz;
+  float tz_max = ((nz ? bminz : bmaxz) - r.oz) * r.iz;
+  tz_max *= g;
+  const bool miss_z = (t_min > tz_max) | (tz_min > t_max);
+  t_min = (tz_min > t_min) ? tz_min : t_min;
+  t_max = (tz_max < t_max) ? tz_max : t_max;
+  *tmin_out = t_min;
+  return !(miss_xy | miss_z) & (t_max > 0.0f);
+}
+
+// Moller-Trumbore of Triangle::intersect (ANY = false, E2 = p2 - p0) / intersect_p (ANY = true, E2 = p2 - p1: Q11)
+template <bool ANY>
+RRT_DEV bool tri_test_f32(const float* tp, const LaneRay& r, float* th, float* uh, float* vh) {
+  const F4 q0 = ld4(tp), q1 = ld4(tp + 4), q2 = ld4(tp + 8);
+  const V3<float> p0(q0.x, q0.y, q0.z), p1(q0.w, q1.x, q1.y), p2(q1.z, q1.w, q2.x);
+  const V3<float> D(r.dx, r.dy, r.dz), O(r.ox, r.oy, r.oz);
+  const V3<float> E1 = p1 - p0, E2 = ANY ? (p2 - p1) : (p2 - p0);
+  const V3<float> P = cross(D, E2);
+  const float a = dot(E1, P);
+  const float f = rcp_r(a);
+  const V3<float> T = O - p0;
+  const float u = f * dot(T, P);
+  const V3<float> Q = cross(T, E1);
+  const float v = f * dot(D, Q);
+  const float tt = f * dot(E2, Q);
+  // the reference's rejections (triangle.rs:182-201 / 245-264), same comparisons, evaluated together
+  const bool reject = (__float_as_uint(q2.w) == r.skip_plane) | ((a > -0.0000001f) & (a < 0.0000001f)) | (u < 0.0f) | (u > 1.0f) | (v < 0.0f) |
+                      ((u + v) > 1.0f) | (tt < 0.0000001f);
+  *th = tt; *uh = u; *vh = v;
+  return !reject;
+}
+
+struct TravScene {
+  const PairNode* pairs;     // interior nodes, pre-order
+  const float* tris;         // Tri<float> array viewed as 12 floats per triangle
+  float root_box[6];
+  uint32_t root_ref, root_n; // root_n > 0: the root itself is a leaf
+  uint32_t n_nodes;
+  uint32_t n_treelet;        // pair nodes [0, n_treelet) are the BFS top of the tree (host renumbering)
+  uint32_t* overflow;        // stack entries >= kStackLds: [entry][thread of the launch], 2 words each
+  uint32_t overflow_stride;
+};
+
+// ANY = false: closest hit for rays in the pool's ray arrays -> pool hit arrays (through `queue` if given).
+// ANY = true : shadow rays (pool shadow arrays) -> L += Ld when unoccluded; with `occluded` != nullptr the rays
+//              are the pool's closest-ray arrays and the verdict is written to occluded[i] (public rrt_trace_any).
+template <bool ANY>
+__global__ void __launch_bounds__(kTravBlock) k_trace_pairs_f32(TravScene ts, Pools<float> p, const uint32_t* queue, const uint32_t* count,
+                                                                 uint32_t n_fixed, uint8_t* occluded, uint32_t n_lo, uint32_t n_hi) {
+  {  // queue-size regime of this kernel (the other traversal kernel is launched next to it for the other regime)
+    const uint32_t nn = count ? *count : n_fixed;
+    if (nn < n_lo || nn >= n_hi) return;
+  }
+  __shared__ float4 treelet[kTreeletNodes * 4];
+  __shared__ uint32_t stk_id[kStackLds * kTravBlock];
+  __shared__ float stk_t[kStackLds * kTravBlock];
+  const uint32_t tid = threadIdx.x;
+  for (uint32_t i = tid; i < ts.n_treelet * 4u; i += kTravBlock) treelet[i] = reinterpret_cast<const float4*>(ts.pairs)[i];
+  __syncthreads();
+  const uint32_t n = count ? *count : n_fixed;
+  for (uint32_t gid = blockIdx.x * kTravBlock + tid; gid < n; gid += gridDim.x * kTravBlock) {
+  const uint32_t slot = queue ? queue[gid] : gid;
+  LaneRay r;
+  int sk;
+  if (ANY && !occluded) {
+    r.ox = p.sox[slot]; r.oy = p.soy[slot]; r.oz = p.soz[slot]; r.dx = p.sdx[slot]; r.dy = p.sdy[slot]; r.dz = p.sdz[slot];
+    r.tmax = p.stmax[slot]; sk = p.sskip[slot];
+  } else {
+    r.ox = p.ox[slot]; r.oy = p.oy[slot]; r.oz = p.oz[slot]; r.dx = p.dx[slot]; r.dy = p.dy[slot]; r.dz = p.dz[slot];
+    r.tmax = p.tmax[slot]; sk = p.skip[slot];
+  }
+  r.skip_plane = sk >= 0 ? __float_as_uint(ts.tris[(size_t)sk * 12 + 11]) : 0xffffffffu;
+  r.ix = 1.0f / r.dx; r.iy = 1.0f / r.dy; r.iz = 1.0f / r.dz;
+  r.neg = (r.ix < 0.0f ? 1u : 0u) | (r.iy < 0.0f ? 2u : 0u) | (r.iz < 0.0f ? 4u : 0u);
+
+  int hit = -1;
+  float hu = 0.0f, hv = 0.0f;
+  bool found = false;
+  uint32_t sp = 0;
+
+  auto push = [&](uint32_t ref, uint32_t nprims, float tmin) {   // id word: ref | leaf flag; leaf count in the low bits of a second use
+    const uint32_t id = nprims ? (0x80000000u | (nprims << 19) | ref) : ref;   // ref < 2^19 checked on the host when n_prims is packed
+    if (sp < (uint32_t)kStackLds) { stk_id[sp * kTravBlock + tid] = id; stk_t[sp * kTravBlock + tid] = tmin; }
+    else { uint32_t* o = ts.overflow + ((size_t)(sp - kStackLds) * ts.overflow_stride + gid) * 2; o[0] = id; o[1] = __float_as_uint(tmin); }
+    sp++;
+  };
+  auto leaf = [&](uint32_t first, uint32_t cnt) {   // every triangle, in order; each accepted hit overwrites (Q10)
+    for (uint32_t i = 0; i < cnt; i++) {
+      float t, u, v;
+      if (tri_test_f32<ANY>(ts.tris + (size_t)(first + i) * 12, r, &t, &u, &v)) {
+        if (ANY) { found = true; return; }
+        r.tmax = t; hit = (int)(first + i); hu = u; hv = v;
+      }
+    }
+  };
+
+  // Per-lane state machine: NODE(cur) -> walk; LEAF(lf, ln) -> triangle tests; DONE. The wave alternates between
+  // "every lane walks interior nodes until it holds a leaf" and "every lane tests its leaf" (while-while), so the
+  // long triangle-test path is executed once per round instead of in almost every iteration.
+  enum { ST_NODE = 0, ST_LEAF = 1, ST_DONE = 2 };
+  uint32_t cur = 0, lf = 0, ln = 0;
+  int state = ST_DONE;
+  auto pop = [&]() {   // re-checks the one comparison that depends on the current t_max
+    state = ST_DONE;
+    while (sp > 0) {
+      sp--;
+      uint32_t id; float tmin;
+      if (sp < (uint32_t)kStackLds) { id = stk_id[sp * kTravBlock + tid]; tmin = stk_t[sp * kTravBlock + tid]; }
+      else { const uint32_t* o = ts.overflow + ((size_t)(sp - kStackLds) * ts.overflow_stride + gid) * 2; id = o[0]; tmin = __uint_as_float(o[1]); }
+      if (!(tmin < r.tmax)) continue;
+      if (id & 0x80000000u) { lf = id & 0x7ffffu; ln = (id >> 19) & 0xfffu; state = ST_LEAF; }
+      else { cur = id; state = ST_NODE; }
+      return;
+    }
+  };
+  {
+    float tmin;
+    if (ts.n_nodes != 0 && box_slabs_f32(ts.root_box[0], ts.root_box[1], ts.root_box[2], ts.root_box[3], ts.root_box[4], ts.root_box[5], r, &tmin) && tmin < r.tmax) {
+      if (ts.root_n) { lf = ts.root_ref; ln = ts.root_n; state = ST_LEAF; }
+      else { cur = ts.root_ref; state = ST_NODE; }
+    }
+  }
+  while (__ballot(state != ST_DONE) != 0ull) {
+    while (state == ST_NODE) {
+      F4 a, b, c, d;
+      if (cur < ts.n_treelet) {
+        const float4 v0 = treelet[cur * 4], v1 = treelet[cur * 4 + 1], v2 = treelet[cur * 4 + 2], v3 = treelet[cur * 4 + 3];
+        a = {v0.x, v0.y, v0.z, v0.w}; b = {v1.x, v1.y, v1.z, v1.w}; c = {v2.x, v2.y, v2.z, v2.w}; d = {v3.x, v3.y, v3.z, v3.w};
+      } else {
+        const float* np = reinterpret_cast<const float*>(ts.pairs + cur);
+        a = ld4(np); b = ld4(np + 4); c = ld4(np + 8); d = ld4(np + 12);
+      }
+      const uint32_t ref0 = __float_as_uint(d.x), ref1 = __float_as_uint(d.y), meta = __float_as_uint(d.z);
+      const uint32_t n0 = (meta >> 2) & 0xfffu, n1 = (meta >> 14) & 0xfffu;
+      float t0, t1;
+      const bool h0 = box_slabs_f32(a.x, a.y, a.z, a.w, b.x, b.y, r, &t0) && t0 < r.tmax;
+      const bool h1 = box_slabs_f32(b.z, b.w, c.x, c.y, c.z, c.w, r, &t1) && t1 < r.tmax;
+      const bool second_first = (r.neg >> (meta & 3u)) & 1u;   // dir_is_neg[axis]: the reference visits the second child first
+      const bool hn = second_first ? h1 : h0, hf = second_first ? h0 : h1;
+      const uint32_t refn = second_first ? ref1 : ref0, reff = second_first ? ref0 : ref1;
+      const uint32_t nn = second_first ? n1 : n0, nf = second_first ? n0 : n1;
+      const float tf = second_first ? t0 : t1;
+      if (hf) push(reff, nf, tf);
+      if (hn) {
+        if (nn) { lf = refn; ln = nn; state = ST_LEAF; }
+        else cur = refn;
+      } else pop();
+    }
+    if (state == ST_LEAF) {
+      leaf(lf, ln);
+      if (ANY && found) state = ST_DONE;
+      else pop();
+    }
+  }
+  if (ANY) {
+    if (occluded) occluded[gid] = found ? 1 : 0;
+    else if (!found) { p.lr[slot] += p.ldr[slot]; p.lg[slot] += p.ldg[slot]; p.lb[slot] += p.ldb[slot]; }
+  } else {
+    p.ht[slot] = r.tmax; p.hprim[slot] = hit; p.hu[slot] = hu; p.hv[slot] = hv;
+  }
+  }  // grid-stride loop over rays
+}
+
+
+// ------------------------------------------------------------------------------------------------------------
+// Persistent-thread variant: the kernel is VALU-issue bound with ~26 % of the lanes doing useful work when a wave
+// owns 64 fixed rays (a wave lasts as long as its longest ray). Here a wave keeps pulling rays: it reserves
+// kGrain rays at a time from a global cursor (one atomic per kGrain rays) and refills idle lanes from that private
+// range, so lanes stay busy until the queue is empty. Each lane is a small state machine that advances one step
+// per loop iteration: NODE (one pair-node step), TRI (one triangle of the current leaf), IDLE.
+// Per ray the sequence of box tests, triangle tests, acceptances and t_max updates is unchanged.
+// ------------------------------------------------------------------------------------------------------------
+constexpr int kPtBlock = 256;
+constexpr int kPtStack = 12;
+constexpr uint32_t kGrain = 256;
+
+template <bool ANY>
+__global__ void __launch_bounds__(kPtBlock) k_trace_pt_f32(TravScene ts, Pools<float> p, const uint32_t* queue, const uint32_t* count,
+                                                            uint32_t n_fixed, uint32_t* work, uint8_t* occluded, uint32_t n_lo, uint32_t n_hi) {
+  {
+    const uint32_t nn = count ? *count : n_fixed;
+    if (nn < n_lo || nn >= n_hi) return;
+  }
+  __shared__ uint32_t stk_id[kPtStack * kPtBlock];
+  __shared__ float stk_t[kPtStack * kPtBlock];
+  const uint32_t tid = threadIdx.x, lane = tid & 63u;
+  const uint32_t gtid = blockIdx.x * blockDim.x + tid;   // overflow-stack column of this lane
+  const uint32_t n = count ? *count : n_fixed;
+  enum { ST_IDLE = 0, ST_NODE = 1, ST_TRI = 2 };
+  int state = ST_IDLE;
+  LaneRay r;
+  r.ox = r.oy = r.oz = r.dx = r.dy = r.dz = r.ix = r.iy = r.iz = r.tmax = 0.0f; r.neg = 0; r.skip_plane = 0xffffffffu;
+  uint32_t slot = 0, qidx = 0, cur = 0, sp = 0, lf = 0, ln = 0;
+  int hit = -1;
+  float hu = 0.0f, hv = 0.0f;
+  bool found = false;
+  uint32_t lo = 0, hi = 0;      // wave-private range of reserved rays
+  bool exhausted = false;       // wave-uniform
+  // reservation grain: large enough to amortise the atomic, small enough that a short queue still spreads over
+  // every resident wave (a wave that reserves 256 rays of a 100k-ray queue would serialise four ray chains)
+  const uint32_t n_waves = gridDim.x * (kPtBlock / 64);
+  uint32_t grain = (n / (2u * n_waves) + 63u) & ~63u;
+  grain = grain < 64u ? 64u : (grain > kGrain ? kGrain : grain);
+
+  auto push = [&](uint32_t ref, uint32_t nprims, float tmin) {
+    const uint32_t id = nprims ? (0x80000000u | (nprims << 19) | ref) : ref;
+    if (sp < (uint32_t)kPtStack) { stk_id[sp * kPtBlock + tid] = id; stk_t[sp * kPtBlock + tid] = tmin; }
+    else { uint32_t* o = ts.overflow + ((size_t)(sp - kPtStack) * ts.overflow_stride + gtid) * 2; o[0] = id; o[1] = __float_as_uint(tmin); }
+    sp++;
+  };
+  auto finish = [&]() {
+    if (ANY) {
+      if (occluded) occluded[qidx] = found ? 1 : 0;
+      else if (!found) { p.lr[slot] += p.ldr[slot]; p.lg[slot] += p.ldg[slot]; p.lb[slot] += p.ldb[slot]; }
+    } else {
+      p.ht[slot] = r.tmax; p.hprim[slot] = hit; p.hu[slot] = hu; p.hv[slot] = hv;
+    }
+    state = ST_IDLE;
+  };
+  auto pop = [&]() {   // re-checks the one comparison that depends on the current t_max
+    while (sp > 0) {
+      sp--;
+      uint32_t id; float tmin;
+      if (sp < (uint32_t)kPtStack) { id = stk_id[sp * kPtBlock + tid]; tmin = stk_t[sp * kPtBlock + tid]; }
+      else { const uint32_t* o = ts.overflow + ((size_t)(sp - kPtStack) * ts.overflow_stride + gtid) * 2; id = o[0]; tmin = __uint_as_float(o[1]); }
+      if (!(tmin < r.tmax)) continue;
+      if (id & 0x80000000u) { lf = id & 0x7ffffu; ln = (id >> 19) & 0xfffu; state = ST_TRI; }
+      else { cur = id; state = ST_NODE; }
+      return;
+    }
+    finish();
+  };
+
+  while (true) {
+    // ---- refill idle lanes ---------------------------------------------------------------------------------------
+    const uint64_t idle = __ballot(state == ST_IDLE);
+    const uint32_t n_idle = (uint32_t)__popcll(idle);
+    if (!exhausted && (n_idle >= 16u)) {
+      if (lo == hi) {
+        uint32_t base = 0;
+        if (lane == 0) base = atomicAdd(work, grain);
+        base = __shfl(base, 0);
+        lo = base; hi = base + grain < n ? base + grain : n;
+        if (base >= n) { exhausted = true; lo = hi = 0; }
+      }
+      if (!exhausted) {
+        const uint32_t take = (hi - lo) < n_idle ? (hi - lo) : n_idle;
+        const uint32_t rank = (uint32_t)__popcll(idle & ((1ull << lane) - 1ull));
+        if (state == ST_IDLE && rank < take) {
+          qidx = lo + rank;
+          slot = queue ? queue[qidx] : qidx;
+          int sk;
+          if (ANY && !occluded) {
+            r.ox = p.sox[slot]; r.oy = p.soy[slot]; r.oz = p.soz[slot]; r.dx = p.sdx[slot]; r.dy = p.sdy[slot]; r.dz = p.sdz[slot];
+            r.tmax = p.stmax[slot]; sk = p.sskip[slot];
+          } else {
+            r.ox = p.ox[slot]; r.oy = p.oy[slot]; r.oz = p.oz[slot]; r.dx = p.dx[slot]; r.dy = p.dy[slot]; r.dz = p.dz[slot];
+            r.tmax = p.tmax[slot]; sk = p.skip[slot];
+          }
+          r.skip_plane = sk >= 0 ? __float_as_uint(ts.tris[(size_t)sk * 12 + 11]) : 0xffffffffu;
+          r.ix = 1.0f / r.dx; r.iy = 1.0f / r.dy; r.iz = 1.0f / r.dz;
+          r.neg = (r.ix < 0.0f ? 1u : 0u) | (r.iy < 0.0f ? 2u : 0u) | (r.iz < 0.0f ? 4u : 0u);
+          sp = 0; hit = -1; hu = 0.0f; hv = 0.0f; found = false;
+          float tmin;
+          if (ts.n_nodes != 0 && box_slabs_f32(ts.root_box[0], ts.root_box[1], ts.root_box[2], ts.root_box[3], ts.root_box[4], ts.root_box[5], r, &tmin) && tmin < r.tmax) {
+            if (ts.root_n) { lf = ts.root_ref; ln = ts.root_n; state = ST_TRI; }
+            else { cur = ts.root_ref; state = ST_NODE; }
+          } else finish();
+        }
+        lo += take;
+      }
+    }
+    if (__ballot(state != ST_IDLE) == 0ull) { if (exhausted) break; else continue; }
+
+    // ---- one step, for the lanes in the majority state only: the other path is not executed at all this iteration
+    // (its lanes wait), so every iteration runs one code path with at least half of the busy lanes active.
+    const uint32_t n_node = (uint32_t)__popcll(__ballot(state == ST_NODE)), n_tri = (uint32_t)__popcll(__ballot(state == ST_TRI));
+    const bool do_node = n_node >= n_tri;
+    if (do_node && state == ST_NODE) {
+      const float* np = reinterpret_cast<const float*>(ts.pairs + cur);
+      const F4 a = ld4(np), b = ld4(np + 4), c = ld4(np + 8), d = ld4(np + 12);
+      const uint32_t ref0 = __float_as_uint(d.x), ref1 = __float_as_uint(d.y), meta = __float_as_uint(d.z);
+      const uint32_t n0 = (meta >> 2) & 0xfffu, n1 = (meta >> 14) & 0xfffu;
+      float t0, t1;
+      const bool h0 = box_slabs_f32(a.x, a.y, a.z, a.w, b.x, b.y, r, &t0) & (t0 < r.tmax);
+      const bool h1 = box_slabs_f32(b.z, b.w, c.x, c.y, c.z, c.w, r, &t1) & (t1 < r.tmax);
+      const bool second_first = (r.neg >> (meta & 3u)) & 1u;
+      const bool hn = second_first ? h1 : h0, hf = second_first ? h0 : h1;
+      const uint32_t refn = second_first ? ref1 : ref0, reff = second_first ? ref0 : ref1;
+      const uint32_t nn = second_first ? n1 : n0, nf = second_first ? n0 : n1;
+      const float tf = second_first ? t0 : t1;
+      if (hf) push(reff, nf, tf);
+      if (hn) {
+        if (nn) { lf = refn; ln = nn; state = ST_TRI; }
+        else cur = refn;
+      } else pop();
+    } else if (!do_node && state == ST_TRI) {
+      float t, u, v;
+      const bool h = tri_test_f32<ANY>(ts.tris + (size_t)lf * 12, r, &t, &u, &v);
+      if (h) {
+        if (ANY) found = true;
+        else { r.tmax = t; hit = (int)lf; hu = u; hv = v; }
+      }
+      lf++; ln--;
+      if (ANY && found) finish();
+      else if (ln == 0) pop();
+    }
+  }
+}
+
+}  // namespace rrtd

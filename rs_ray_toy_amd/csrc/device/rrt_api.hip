@@ -79,6 +79,12 @@ int rrt_render_rect(rrt_handle* h, const int32_t rect[4], void* film_xyzw, int f
   return guarded([&]() { h->impl->render_rect(rect, film_xyzw, film_mem, stats); });
 }
 
+int rrt_render_bands(rrt_handle* h, int rank, int world, void* film_xyzw, int film_mem, rrt_render_stats* stats) {
+  if (!h || !film_xyzw) { rrt::set_last_error("rrt_render_bands: null argument"); return RRT_EINVAL; }
+  if (film_mem != RRT_MEM_HOST && film_mem != RRT_MEM_DEVICE) { rrt::set_last_error("rrt_render_bands: bad film_mem"); return RRT_EINVAL; }
+  return guarded([&]() { h->impl->render_bands(rank, world, film_xyzw, film_mem, stats); });
+}
+
 int rrt_set_option(rrt_handle* h, const char* key, double value) {
   if (!h || !key) { rrt::set_last_error("rrt_set_option: null argument"); return RRT_EINVAL; }
   return guarded([&]() { h->impl->set_option(key, value); });

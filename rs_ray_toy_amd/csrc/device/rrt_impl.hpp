@@ -10,7 +10,10 @@
 #include <unordered_map>
 #include <vector>
 
+#include <type_traits>
+
 #include "dkernels.hpp"
+#include "dtraverse_f32.hpp"
 #include "rrt.h"
 
 namespace rrtd {
@@ -34,6 +37,7 @@ struct HandleBase {
   virtual void trace_any(const rrt_rays* rays, size_t n, uint8_t* occluded) = 0;
   virtual void camera_samples(const int32_t rect[4], uint64_t s0, uint64_t s1, double* dims5, double* ray_od6, double* weight) = 0;
   virtual void render_rect(const int32_t rect[4], void* film, int film_mem, rrt_render_stats* stats) = 0;
+  virtual void render_bands(int rank, int world, void* film, int film_mem, rrt_render_stats* stats) = 0;
   virtual void set_option(const std::string& key, double v) = 0;
 };
 
@@ -126,6 +130,9 @@ class Handle : public HandleBase {
   void set_option(const std::string& key, double v) override {
     if (key == "max_paths") { if (v < 64) throw std::invalid_argument("max_paths must be >= 64"); max_paths_ = (size_t)v; }
     else if (key == "count_traversal") count_traversal_ = v != 0;
+    else if (key == "persistent_traversal") { persistent_ = v != 0; if (v >= 1) trav_mode_ = (int)v; }
+    else if (key == "pt_split_closest") pt_split_closest_ = (uint32_t)v;
+    else if (key == "pt_split_any") pt_split_any_ = (uint32_t)v;
     else throw std::invalid_argument("unknown option " + key);
   }
 
@@ -138,6 +145,7 @@ class Handle : public HandleBase {
     const bool want_counts = out->nodes_visited && out->prims_tested;
     DevBuf<uint32_t> cn, cp;
     if (want_counts) { cn.alloc(n); cp.alloc(n); }
+    hipLaunchKernelGGL(k_rotate, dim3(1), dim3(1), 0, st_, counters_.p, 3);
     launch_closest(nullptr, nullptr, (uint32_t)n, want_counts, want_counts ? cn.p : nullptr, want_counts ? cp.p : nullptr, nullptr);
     auto kind = out->mem == RRT_MEM_DEVICE ? hipMemcpyDeviceToDevice : hipMemcpyDeviceToHost;
     HIP_CHECK(hipMemcpyAsync(out->t, pool_.ht, n * sizeof(R), kind, st_));
@@ -159,7 +167,9 @@ class Handle : public HandleBase {
     uint8_t* dst = occluded;
     if (rays->mem != RRT_MEM_DEVICE) { occ.alloc(n); dst = occ.p; }
     const uint32_t grid = (uint32_t)((n + kBlock - 1) / kBlock);
-    if (deep_) hipLaunchKernelGGL((k_any_public<R, true>), dim3(grid), dim3(kBlock), 0, st_, scene_, pool_, (uint32_t)n, dst, deep_stack_.p, (uint32_t)cap_);
+    hipLaunchKernelGGL(k_rotate, dim3(1), dim3(1), 0, st_, counters_.p, 3);
+    if (use_persistent()) launch_persistent(true, nullptr, nullptr, (uint32_t)n, grid, dst);
+    else if (deep_) hipLaunchKernelGGL((k_any_public<R, true>), dim3(grid), dim3(kBlock), 0, st_, scene_, pool_, (uint32_t)n, dst, deep_stack_.p, (uint32_t)cap_);
     else hipLaunchKernelGGL((k_any_public<R, false>), dim3(grid), dim3(kBlock), 0, st_, scene_, pool_, (uint32_t)n, dst, (uint32_t*)nullptr, 0u);
     HIP_CHECK(hipGetLastError());
     if (rays->mem != RRT_MEM_DEVICE) HIP_CHECK(hipMemcpyAsync(occluded, occ.p, n, hipMemcpyDeviceToHost, st_));
@@ -174,9 +184,12 @@ class Handle : public HandleBase {
     ensure_pools(n);
     DevBuf<double> dd, dr, dw;
     dd.alloc(5 * n); dr.alloc(6 * n); dw.alloc(n);
-    PassDesc pd{rect[0], rect[1], rect[2] - rect[0], 0u, (uint32_t)npix, (uint32_t)s0, (uint32_t)ns};
+    PassDesc pd{rect[0], rect[1], rect[2] - rect[0], 0u, (uint32_t)npix, (uint32_t)s0, (uint32_t)ns, 1u << 30, 1u, 0u};
     hipLaunchKernelGGL(k_rotate, dim3(1), dim3(1), 0, st_, counters_.p, 2);
-    hipLaunchKernelGGL((k_raygen<R>), dim3((uint32_t)((n + kBlock - 1) / kBlock)), dim3(kBlock), 0, st_, scene_, pool_, pd, dd.p, dr.p, dw.p);
+    const uint32_t g = (uint32_t)((n + kBlock - 1) / kBlock);
+    hipLaunchKernelGGL((k_raygen<R>), dim3(g), dim3(kBlock), 0, st_, scene_, pool_, pd, dd.p);
+    hipLaunchKernelGGL((k_raygen_aux<R>), dim3(g), dim3(kBlock), 0, st_, scene_, pool_);
+    hipLaunchKernelGGL((k_camera_dump<R>), dim3(g), dim3(kBlock), 0, st_, pool_, pd, dr.p, dw.p);
     HIP_CHECK(hipGetLastError());
     HIP_CHECK(hipMemcpyAsync(dims5, dd.p, 5 * n * sizeof(double), hipMemcpyDeviceToHost, st_));
     HIP_CHECK(hipMemcpyAsync(ray_od6, dr.p, 6 * n * sizeof(double), hipMemcpyDeviceToHost, st_));
@@ -186,6 +199,15 @@ class Handle : public HandleBase {
 
   // ---- the frame: SamplerIntegrator::si_render (integrator/mod.rs:48-139) over a pixel rect -------------------
   void render_rect(const int32_t rect[4], void* film_user, int film_mem, rrt_render_stats* stats) override {
+    render_impl(rect, 1u << 30, 1, 0, film_user, film_mem, stats);
+  }
+  // rows of the interleaved 16-row bands b with b % world == rank (partition.py), as ONE pixel set
+  void render_bands(int rank, int world, void* film_user, int film_mem, rrt_render_stats* stats) override {
+    if (world < 1 || rank < 0 || rank >= world) throw std::invalid_argument("render_bands: bad rank/world");
+    const int32_t full[4] = {0, 0, desc_.film.xres, desc_.film.yres};
+    render_impl(full, 16, (uint32_t)world, (uint32_t)rank, film_user, film_mem, stats);
+  }
+  void render_impl(const int32_t rect[4], uint32_t band_h, uint32_t n_ranks, uint32_t rank, void* film_user, int film_mem, rrt_render_stats* stats) {
     HIP_CHECK(hipSetDevice(dev_));
     check_renderable();
     const rrt_film& f = desc_.film;
@@ -197,7 +219,13 @@ class Handle : public HandleBase {
       throw PanicError("directlighting.rs:91 unbounded recursion on a miss with an empty light list (Q20)");
     const uint64_t nsamp = desc_.sampler.samples_per_pixel;
     const size_t W = (size_t)f.xres, H = (size_t)f.yres;
-    const size_t rw = (size_t)(rect[2] - rect[0]), rh = (size_t)(rect[3] - rect[1]), rpix = rw * rh;
+    size_t rh_all = (size_t)(rect[3] - rect[1]);
+    if (n_ranks > 1) {  // number of rows of this rank's bands
+      size_t rows = 0;
+      for (size_t y = 0; y < rh_all; y++) if ((y / band_h) % n_ranks == rank) rows++;
+      rh_all = rows;
+    }
+    const size_t rw = (size_t)(rect[2] - rect[0]), rh = rh_all, rpix = rw * rh;
     const uint64_t s_total = nsamp > 1 ? nsamp - 1 : 0;  // samples 1 .. nsamp-1 (Q1)
 
     // internal full-frame film (zeroed), merged into the caller's buffer at the end
@@ -228,16 +256,19 @@ class Handle : public HandleBase {
     const int integ = desc_.integrator.type;
     const int max_depth = desc_.integrator.max_depth;
 
+    if (rpix == 0) { if (stats) memset(stats, 0, sizeof(*stats)); return; }
     for (size_t g0 = 0; g0 < rpix && s_total > 0; g0 += group) {
       const size_t npix = std::min(group, rpix - g0);
       for (uint64_t sb = 0; sb < s_total; sb += s_chunk) {
         const uint64_t ns = std::min<uint64_t>(s_chunk, s_total - sb);
-        PassDesc pd{rect[0], rect[1], (int32_t)rw, (uint32_t)g0, (uint32_t)npix, (uint32_t)(1 + sb), (uint32_t)ns};
+        PassDesc pd{rect[0], rect[1], (int32_t)rw, (uint32_t)g0, (uint32_t)npix, (uint32_t)(1 + sb), (uint32_t)ns, band_h, n_ranks, rank};
         const size_t nslots = npix * (size_t)ns;
         const uint32_t grid = (uint32_t)((nslots + kBlock - 1) / kBlock);
         hipLaunchKernelGGL(k_rotate, dim3(1), dim3(1), 0, st_, counters_.p, 2);
         size_t e = tick(0);
-        hipLaunchKernelGGL((k_raygen<R>), dim3(grid), dim3(kBlock), 0, st_, scene_, pool_, pd, (double*)nullptr, (double*)nullptr, (double*)nullptr);
+        hipLaunchKernelGGL((k_raygen<R>), dim3(grid), dim3(kBlock), 0, st_, scene_, pool_, pd, (double*)nullptr);
+        hipLaunchKernelGGL((k_raygen_aux<R>), dim3(grid), dim3(kBlock), 0, st_, scene_, pool_);
+        hipLaunchKernelGGL(k_rotate, dim3(1), dim3(1), 0, st_, counters_.p, 4);   // q_next was only a staging queue
         tock(e);
         hipLaunchKernelGGL(k_accumulate_camera, dim3(1), dim3(1), 0, st_, counters_.p, totals_.p);
         if (integ == RRT_INT_PATH) {
@@ -343,8 +374,16 @@ class Handle : public HandleBase {
   SceneDev<R> scene_{};
   Pools<R> pool_{};
   size_t cap_ = 0;
-  size_t max_paths_ = (size_t)1 << 22;
-  bool deep_ = false, count_traversal_ = false;
+  size_t max_paths_ = (size_t)1 << 24;
+  bool deep_ = false, count_traversal_ = false, persistent_ = true;
+  bool pairs_ok_ = false;
+  uint32_t trav_grid_ = 0, pt_grid_ = 0;
+  int trav_mode_ = 3;   // 1 = LDS-treelet grid-stride kernel, 2 = persistent-thread kernel, 3 = by queue size
+  uint32_t pt_split_closest_ = 600000u, pt_split_any_ = 2500000u;
+  DevBuf<uint32_t> pt_overflow_;
+  TravScene trav_{};
+  DevBuf<PairNode> pairs_;
+  DevBuf<uint32_t> overflow_;
   DevBuf<Node<R>> nodes_;
   DevBuf<Tri<R>> tris_;
   DevBuf<TriShade<R>> shades_;
@@ -507,7 +546,7 @@ class Handle : public HandleBase {
     std::vector<uint16_t> perms;
     if (d->sampler.type == RRT_SAMPLER_HALTON && d->sampler.perms) perms.assign(d->sampler.perms, d->sampler.perms + d->sampler.n_perms);
 
-    nodes_.upload(nodes, st_); tris_.upload(tris, st_); shades_.upload(shades, st_); materials_.upload(mats, st_);
+    nodes_.upload(nodes, st_); tris_.upload(tris, st_); build_pairs(nodes, tris.size()); shades_.upload(shades, st_); materials_.upload(mats, st_);
     lights_.upload(lights, st_); light_cdf_.upload(cdf_r, st_); lens_.upload(lens, st_); hdims_.upload(hd, st_); perms_.upload(perms, st_);
     HIP_CHECK(hipStreamSynchronize(st_));  // host vectors go out of scope below
 
@@ -558,6 +597,7 @@ class Handle : public HandleBase {
     p.hprim = (int32_t*)nu(); p.skip = (int32_t*)nu(); p.sskip = (int32_t*)nu(); p.pixel = nu(); p.hindex = nu(); p.dim_bounce = nu(); p.q_active = nu(); p.q_next = nu(); p.q_shadow = nu();
     p.counters = counters_.p;
     if (deep_) deep_stack_.alloc((size_t)scene_.stack_depth * cap_);
+    if (pairs_ok_ && scene_.stack_depth > (uint32_t)kStackLds) overflow_.alloc((size_t)(scene_.stack_depth - kStackLds) * cap_ * 2);
   }
 
   void load_rays(const rrt_rays* rays, size_t n) {
@@ -572,6 +612,7 @@ class Handle : public HandleBase {
   void launch_closest(const uint32_t* queue, const uint32_t* count, uint32_t n_fixed, bool counting, uint32_t* cn, uint32_t* cp,
                       unsigned long long* totals, uint32_t grid_override = 0) {
     const uint32_t grid = grid_override ? grid_override : (uint32_t)((n_fixed + kBlock - 1) / kBlock);
+    if (!counting && use_persistent()) { launch_persistent(false, queue, count, n_fixed, grid, nullptr); return; }
     uint32_t* ds = deep_ ? deep_stack_.p : nullptr;
     const uint32_t stride = deep_ ? (uint32_t)cap_ : 0u;
     if (deep_) {
@@ -583,7 +624,118 @@ class Handle : public HandleBase {
     }
     HIP_CHECK(hipGetLastError());
   }
+  // fp32 production traversal (dtraverse_f32.hpp): 64 B pair nodes, LDS stack with global overflow
+  bool use_persistent() const { return std::is_same<R, float>::value && persistent_ && pairs_ok_; }
+  void launch_persistent(bool any, const uint32_t* queue, const uint32_t* count, uint32_t n_fixed, uint32_t grid, uint8_t* occluded) {
+    if constexpr (std::is_same<R, float>::value) {
+      const uint32_t grid_in = grid;
+      trav_.overflow = overflow_.p;
+      trav_.overflow_stride = (uint32_t)cap_;
+      if (trav_grid_ == 0) {
+        int per_cu = 0, cus = 0;
+        HIP_CHECK(hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, dev_));
+        HIP_CHECK(hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu, k_trace_pairs_f32<false>, kTravBlock, 0));
+        trav_grid_ = (uint32_t)(std::max(1, per_cu) * std::max(1, cus));
+      }
+      // persistent workgroups: grid-stride over the queue (slots / kBlock thread blocks were requested by the caller)
+      const uint32_t need = (uint32_t)(((size_t)grid * kBlock + kTravBlock - 1) / kTravBlock);
+      grid = std::max(1u, std::min(need, trav_grid_));
+      // Two kernels, two queue-size regimes (decided on the device from the queue counter): large queues go to the
+      // persistent-thread kernel (lane refill keeps the VALUs busy), small ones to the grid-stride kernel (its fixed
+      // cost — the latency chain of the longest ray — is lower). trav_mode_: 1 = grid-stride only, 2 = persistent
+      // only, 3 = both by regime.
+      const uint32_t split = any ? pt_split_any_ : pt_split_closest_;
+      const uint32_t lo_pt = trav_mode_ == 2 ? 0u : (trav_mode_ == 1 ? 0xffffffffu : split);
+      const uint32_t hi_gs = trav_mode_ == 1 ? 0xffffffffu : (trav_mode_ == 2 ? 0u : split);
+      if (trav_mode_ != 1) {
+        if (pt_grid_ == 0) {
+          int per_cu = 0, cus = 0;
+          HIP_CHECK(hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, dev_));
+          HIP_CHECK(hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu, k_trace_pt_f32<false>, kPtBlock, 0));
+          pt_grid_ = (uint32_t)(std::max(1, per_cu) * std::max(1, cus));
+          if (pairs_ok_ && scene_.stack_depth > (uint32_t)kPtStack) pt_overflow_.alloc((size_t)(scene_.stack_depth - kPtStack) * (size_t)pt_grid_ * kPtBlock * 2);
+        }
+        TravScene t2 = trav_;
+        t2.overflow = pt_overflow_.p;
+        t2.overflow_stride = pt_grid_ * kPtBlock;
+        const uint32_t g2 = std::max(1u, std::min(grid_in, pt_grid_));
+        uint32_t* work = &counters_.p[any ? C_WORK_SHADOW : C_WORK_CLOSEST];
+        if (any) hipLaunchKernelGGL((k_trace_pt_f32<true>), dim3(g2), dim3(kPtBlock), 0, st_, t2, pool_, queue, count, n_fixed, work, occluded, lo_pt, 0xffffffffu);
+        else hipLaunchKernelGGL((k_trace_pt_f32<false>), dim3(g2), dim3(kPtBlock), 0, st_, t2, pool_, queue, count, n_fixed, work, occluded, lo_pt, 0xffffffffu);
+      }
+      if (trav_mode_ != 2) {
+        if (any) hipLaunchKernelGGL((k_trace_pairs_f32<true>), dim3(grid), dim3(kTravBlock), 0, st_, trav_, pool_, queue, count, n_fixed, occluded, 0u, hi_gs);
+        else hipLaunchKernelGGL((k_trace_pairs_f32<false>), dim3(grid), dim3(kTravBlock), 0, st_, trav_, pool_, queue, count, n_fixed, occluded, 0u, hi_gs);
+      }
+      HIP_CHECK(hipGetLastError());
+    }
+  }
+  // re-pack the linear BVH into pair nodes (see dtraverse_f32.hpp)
+  void build_pairs(const std::vector<Node<R>>& nodes, size_t n_tris) {
+    if constexpr (std::is_same<R, float>::value) {
+      pairs_ok_ = false;
+      if (nodes.empty() || n_tris >= (1u << 19)) return;
+      std::vector<uint32_t> compact(nodes.size(), 0xffffffffu);
+      uint32_t n_int = 0;
+      for (size_t i = 0; i < nodes.size(); i++) {
+        const uint32_t np = nodes[i].meta >> 2;
+        if (np == 0) compact[i] = n_int++;
+        else if (np >= 4096) return;
+      }
+      std::vector<PairNode> pairs(n_int);
+      for (size_t i = 0; i < nodes.size(); i++) {
+        if ((nodes[i].meta >> 2) != 0) continue;
+        PairNode& pn = pairs[compact[i]];
+        const size_t c0 = i + 1, c1 = nodes[i].offset;
+        const uint32_t n0 = nodes[c0].meta >> 2, n1 = nodes[c1].meta >> 2;
+        for (int k = 0; k < 3; k++) { pn.b0min[k] = nodes[c0].bmin[k]; pn.b0max[k] = nodes[c0].bmax[k]; pn.b1min[k] = nodes[c1].bmin[k]; pn.b1max[k] = nodes[c1].bmax[k]; }
+        pn.ref0 = n0 ? nodes[c0].offset : compact[c0];
+        pn.ref1 = n1 ? nodes[c1].offset : compact[c1];
+        pn.meta = (nodes[i].meta & 3u) | (n0 << 2) | (n1 << 14);
+        pn.pad = 0;
+      }
+      // renumber: the BFS top of the tree first (staged in LDS by the kernels), the rest in pre-order
+      if (n_int > 0 && (nodes[0].meta >> 2) == 0) {
+        std::vector<uint32_t> order; order.reserve(n_int);
+        std::vector<uint8_t> taken(n_int, 0);
+        std::vector<uint32_t> frontier{0};
+        while (!frontier.empty() && order.size() < (size_t)kTreeletNodes) {
+          std::vector<uint32_t> next;
+          for (uint32_t k : frontier) {
+            if (order.size() >= (size_t)kTreeletNodes) break;
+            order.push_back(k); taken[k] = 1;
+            const PairNode& pn = pairs[k];
+            if (((pn.meta >> 2) & 0xfffu) == 0) next.push_back(pn.ref0);
+            if (((pn.meta >> 14) & 0xfffu) == 0) next.push_back(pn.ref1);
+          }
+          frontier.swap(next);
+        }
+        trav_.n_treelet = (uint32_t)order.size();
+        for (uint32_t k = 0; k < n_int; k++) if (!taken[k]) order.push_back(k);
+        std::vector<uint32_t> newidx(n_int);
+        for (uint32_t i = 0; i < n_int; i++) newidx[order[i]] = i;
+        std::vector<PairNode> re(n_int);
+        for (uint32_t i = 0; i < n_int; i++) {
+          PairNode pn = pairs[order[i]];
+          if (((pn.meta >> 2) & 0xfffu) == 0) pn.ref0 = newidx[pn.ref0];
+          if (((pn.meta >> 14) & 0xfffu) == 0) pn.ref1 = newidx[pn.ref1];
+          re[i] = pn;
+        }
+        pairs.swap(re);
+      } else trav_.n_treelet = 0;
+      pairs_.upload(pairs, st_);
+      HIP_CHECK(hipStreamSynchronize(st_));
+      trav_.pairs = pairs_.p;
+      trav_.tris = reinterpret_cast<const float*>(tris_.p);
+      for (int k = 0; k < 3; k++) { trav_.root_box[k] = nodes[0].bmin[k]; trav_.root_box[3 + k] = nodes[0].bmax[k]; }
+      trav_.root_n = nodes[0].meta >> 2;
+      trav_.root_ref = trav_.root_n ? nodes[0].offset : 0u;
+      trav_.n_nodes = (uint32_t)nodes.size();
+      pairs_ok_ = true;
+    }
+  }
   void launch_shadow(uint32_t grid) {
+    if (!count_traversal_ && use_persistent()) { launch_persistent(true, pool_.q_shadow, &counters_.p[C_SHADOW], 0, grid, nullptr); return; }
     uint32_t* ds = deep_ ? deep_stack_.p : nullptr;
     const uint32_t stride = deep_ ? (uint32_t)cap_ : 0u;
     unsigned long long* tot = count_traversal_ ? totals_.p + 5 : nullptr;

@@ -189,6 +189,24 @@ def test_render_rect_and_passes_are_consistent(workdir):
     np.testing.assert_allclose(small, full, rtol=1e-12, atol=1e-15)
 
 
+def test_render_bands_partition_sums_to_the_frame(workdir):
+    """rrt_render_bands: the ranks' interleaved 16-row bands are disjoint and sum to the full frame (world 1, 3)."""
+    cfg, root = scenes.cfg2(workdir, xres=48, yres=72, nsamp=5, max_depth=3)
+    sc = Scene.loads(cfg, root)
+    for prec in (RRT_F64, RRT_F32):
+        r = Renderer(sc, 0, prec)
+        full = r.render()
+        one = r.render_bands(0, 1)
+        parts = [r.render_bands(k, 3) for k in range(3)]
+        r.close()
+        assert np.array_equal(one, full)
+        cover = sum((p[..., 3] > 0).astype(int) for p in parts)
+        assert (cover == 1).all()                                  # every pixel rendered by exactly one rank
+        rows = np.nonzero(parts[1][:, 0, 3] > 0)[0]
+        assert list(rows[:16]) == list(range(16, 32)) and list(rows[16:]) == list(range(64, 72))
+        assert np.array_equal(sum(parts), full)
+
+
 @pytest.mark.parametrize("integrator", ["Debug", "DirectLighting_all", "DirectLighting_one", "AO"])
 def test_other_integrators(integrator, workdir):
     cfg, root = scenes.cfg2(workdir, xres=64, yres=64, nsamp=5)
