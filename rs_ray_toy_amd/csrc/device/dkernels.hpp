@@ -270,7 +270,7 @@ __global__ void __launch_bounds__(kBlock) k_raygen(SceneDev<R> s, Pools<R> p, Pa
     pass_pixel(pd, pd.pix_begin + pl, &px, &py);
     const uint32_t sample_num = pd.s_begin + sl;
     const uint32_t index = halton_pixel_offset(s, px, py) + sample_num * s.stride;
-    const double d0 = halton_dim(s, index, 0), d1 = halton_dim(s, index, 1), d2 = halton_dim(s, index, 2), d3 = halton_dim(s, index, 3);
+    const double d0 = halton_dim(s, index, 0), d1 = halton_dim(s, index, 1), d2 = halton_cam_dim(s, index, 0), d3 = halton_cam_dim(s, index, 1);
     // dimension 4 (time) is drawn and unused by a static scene
     const R pfx = (R)px + to_real<R>(d0), pfy = (R)py + to_real<R>(d1);
     const R lx = to_real<R>(d2) + R(0.5), ly = to_real<R>(d3) + R(0.5);  // Q5

@@ -168,6 +168,24 @@ RRT_DEV double halton_dim(const SceneDev<R>& s, uint32_t index, uint32_t dim) {
   const HaltonDim hd = s.hdims[dim];
   return scrambled_radical_inverse_dev(index, hd, s.perms + hd.perm_offset, s.fast_div);
 }
+// dims 2 / 3 (lens sample) on the fast path: same digits, same permutation, same f64 value as
+// scrambled_radical_inverse_dev — the product inv_base^k comes from a table built with the identical multiplications
+template <typename R>
+RRT_DEV double halton_cam_dim(const SceneDev<R>& s, uint32_t index, int which) {
+  const HaltonDim hd = s.hdims[2 + which];
+  if (!s.fast_div) return scrambled_radical_inverse_dev(index, hd, s.perms + hd.perm_offset, 0u);
+  const uint32_t packed = s.cam_perm[which];
+  uint64_t reversed = 0;
+  uint32_t a = index, k = 0;
+  while (a > 0) {
+    const uint32_t next = (uint32_t)(((uint64_t)a * hd.magic) >> 40);
+    const uint32_t digit = a - next * hd.base;
+    reversed = reversed * hd.base + ((packed >> (3u * digit)) & 7u);
+    a = next;
+    k++;
+  }
+  return fmin(s.cam_invpow[which][k] * ((double)reversed + s.cam_tail[which]), 0.99999999999999989);
+}
 template <typename R> RRT_DEV R to_real(double u) { return (R)u; }
 template <> RRT_DEV float to_real<float>(double u) { return fminf((float)u, Const<float>::one_minus_eps); }  // keep u < 1 after narrowing
 

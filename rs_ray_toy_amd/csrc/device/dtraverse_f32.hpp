@@ -118,7 +118,8 @@ __global__ void __launch_bounds__(kTravBlock) k_trace_pairs_f32(TravScene ts, Po
   for (uint32_t i = tid; i < ts.n_treelet * 4u; i += kTravBlock) treelet[i] = reinterpret_cast<const float4*>(ts.pairs)[i];
   __syncthreads();
   const uint32_t n = count ? *count : n_fixed;
-  for (uint32_t gid = blockIdx.x * kTravBlock + tid; gid < n; gid += gridDim.x * kTravBlock) {
+  const uint32_t col = blockIdx.x * kTravBlock + tid;   // overflow-stack column of this resident thread
+  for (uint32_t gid = col; gid < n; gid += gridDim.x * kTravBlock) {
   const uint32_t slot = queue ? queue[gid] : gid;
   LaneRay r;
   int sk;
@@ -141,7 +142,7 @@ __global__ void __launch_bounds__(kTravBlock) k_trace_pairs_f32(TravScene ts, Po
   auto push = [&](uint32_t ref, uint32_t nprims, float tmin) {   // id word: ref | leaf flag; leaf count in the low bits of a second use
     const uint32_t id = nprims ? (0x80000000u | (nprims << 19) | ref) : ref;   // ref < 2^19 checked on the host when n_prims is packed
     if (sp < (uint32_t)kStackLds) { stk_id[sp * kTravBlock + tid] = id; stk_t[sp * kTravBlock + tid] = tmin; }
-    else { uint32_t* o = ts.overflow + ((size_t)(sp - kStackLds) * ts.overflow_stride + gid) * 2; o[0] = id; o[1] = __float_as_uint(tmin); }
+    else { uint32_t* o = ts.overflow + ((size_t)(sp - kStackLds) * ts.overflow_stride + col) * 2; o[0] = id; o[1] = __float_as_uint(tmin); }
     sp++;
   };
   auto leaf = [&](uint32_t first, uint32_t cnt) {   // every triangle, in order; each accepted hit overwrites (Q10)
@@ -166,7 +167,7 @@ __global__ void __launch_bounds__(kTravBlock) k_trace_pairs_f32(TravScene ts, Po
       sp--;
       uint32_t id; float tmin;
       if (sp < (uint32_t)kStackLds) { id = stk_id[sp * kTravBlock + tid]; tmin = stk_t[sp * kTravBlock + tid]; }
-      else { const uint32_t* o = ts.overflow + ((size_t)(sp - kStackLds) * ts.overflow_stride + gid) * 2; id = o[0]; tmin = __uint_as_float(o[1]); }
+      else { const uint32_t* o = ts.overflow + ((size_t)(sp - kStackLds) * ts.overflow_stride + col) * 2; id = o[0]; tmin = __uint_as_float(o[1]); }
       if (!(tmin < r.tmax)) continue;
       if (id & 0x80000000u) { lf = id & 0x7ffffu; ln = (id >> 19) & 0xfffu; state = ST_LEAF; }
       else { cur = id; state = ST_NODE; }
@@ -365,6 +366,205 @@ __global__ void __launch_bounds__(kPtBlock) k_trace_pt_f32(TravScene ts, Pools<f
       if (ANY && found) finish();
       else if (ln == 0) pop();
     }
+  }
+}
+
+}  // namespace rrtd
+
+// ------------------------------------------------------------------------------------------------------------
+// Persistent-thread camera ray generation (fp32 product path).
+// generate_ray_differential (camera.rs:582-628) traces the main ray through 13 lens interfaces and then 2-4
+// auxiliary rays; 70 % of the main rays die at some interface (29 % at the second one, 16 % at the third, ...), so
+// with one sample per lane a wave runs all 13 steps at ~50 % lane utilisation, and the auxiliary traces at ~30 %.
+// Here every lane is a state machine over (trace, interface): a lane whose sample is decided (dead or alive) pulls
+// the next sample of its wave's reserved range at once, so all lanes execute useful interface steps. The arithmetic
+// per interface is that of trace_from_film / generate_ray in dmath.hpp (same operation order: identical results).
+// ------------------------------------------------------------------------------------------------------------
+namespace rrtd {
+
+constexpr int kRgBlock = 256;
+
+struct RgLane {
+  V3<float> o, d;      // ray in lens space
+  float element_z;
+  int i;               // next interface to process (counts down), -1 = through
+  int phase;           // 0 main, 1 x+0.05, 2 x-0.05, 3 y+0.05, 4 y-0.05
+};
+
+// start one trace: generate_ray up to the call of trace_lenses_from_film (camera.rs:534-556) + flip_z
+RRT_DEV void rg_begin(const SceneDev<float>& s, float pfx, float pfy, float lx, float ly, RgLane* L, float* cos4_area) {
+  const float sx = pfx / (float)s.xres, sy = pfy / (float)s.yres;
+  const float p2x = s.extent[0] * (1.0f - sx) + s.extent[2] * sx, p2y = s.extent[1] * (1.0f - sy) + s.extent[3] * sy;
+  const V3<float> p_film(-p2x, p2y, 0.0f);
+  const float r_film = sqrtf(p_film.x * p_film.x + p_film.y * p_film.y);
+  const float* pb = (r_film / (s.diagonal / 2.0f) >= 1.0f) ? s.pupil63 : s.pupil0;
+  const float plx = pb[0] * (1.0f - lx) + pb[2] * lx, ply = pb[1] * (1.0f - ly) + pb[3] * ly;
+  const float sin_t = r_film != 0.0f ? p_film.y / r_film : 0.0f, cos_t = r_film != 0.0f ? p_film.x / r_film : 1.0f;
+  const float area = (pb[2] - pb[0]) * (pb[3] - pb[1]);
+  const V3<float> p_rear(cos_t * plx - sin_t * ply, sin_t * plx + cos_t * ply, s.lens[s.n_lens - 1].thickness);
+  RayT<float> rf;
+  rf.o = p_film;
+  rf.d = vnormalize(p_rear - p_film);
+  const float cos_theta = vnormalize(rf.d).z;
+  const float cos4 = (cos_theta * cos_theta) * (cos_theta * cos_theta);
+  if (s.simple_weighting) *cos4_area = cos4 * area / ((s.pupil0[2] - s.pupil0[0]) * (s.pupil0[3] - s.pupil0[1]));
+  else { const float rz = s.lens[s.n_lens - 1].thickness; *cos4_area = (s.shutter_close - s.shutter_open) * (cos4 * area) / rz * rz; }
+  const RayT<float> r = flip_z(rf);
+  L->o = r.o; L->d = r.d; L->element_z = 0.0f; L->i = s.n_lens - 1;
+}
+
+// one interface of trace_lenses_from_film (camera.rs:163-211); false = the ray is blocked
+RRT_DEV bool rg_step(const float4* lens_s, RgLane* L) {
+  const int i = L->i;
+  const float4 el = lens_s[i];   // curvature_radius, thickness, eta, aperture_radius
+  L->element_z -= el.y;
+  float t = 0.0f;
+  V3<float> n;
+  const bool is_stop = el.x == 0.0f;
+  RayT<float> r; r.o = L->o; r.d = L->d;
+  if (is_stop) {
+    if (r.d.z >= 0.0f) return false;
+    t = (L->element_z - r.o.z) / r.d.z;
+  } else {
+    if (!intersect_spherical(el.x, L->element_z + el.x, r, &t, &n)) return false;
+  }
+  if (!(t >= 0.0f)) return false;
+  const V3<float> p_hit = r.o + r.d * t;
+  const float r2 = p_hit.x * p_hit.x + p_hit.y * p_hit.y;
+  if (r2 >= el.w * el.w) return false;
+  L->o = p_hit;
+  if (!is_stop) {
+    V3<float> w;
+    const float eta_prev = (i > 0) ? lens_s[i - 1].z : 0.0f;
+    const float eta_t = (i > 0 && eta_prev != 0.0f) ? eta_prev : 1.0f;
+    if (!refract(vnormalize(-r.d), n, el.z / eta_t, &w)) return false;
+    L->d = w;
+  }
+  L->i = i - 1;
+  return true;
+}
+
+// `dims_out` (optional): the five sampler dimensions per slot, [pixel][sample] order (rrt_camera_samples)
+static __global__ void __launch_bounds__(kRgBlock) k_raygen_pt_f32(SceneDev<float> s, Pools<float> p, PassDesc pd, uint32_t* work, double* dims_out) {
+  __shared__ float4 lens_s[32];
+  const uint32_t tid = threadIdx.x, lane = tid & 63u;
+  if (tid < (uint32_t)s.n_lens) { const LensElem<float> e = s.lens[tid]; lens_s[tid] = make_float4(e.curvature_radius, e.thickness, e.eta, e.aperture_radius); }
+  __syncthreads();
+  const uint32_t total = pd.npix * pd.ns;
+  bool busy = false, exhausted = false;
+  uint32_t slot = 0, lo = 0, hi = 0;
+  float pfx = 0, pfy = 0, lx = 0, ly = 0, w_main = 0, scratch_w = 0;
+  RgLane L; L.i = -1; L.phase = 0; L.element_z = 0;
+  const uint32_t n_waves = gridDim.x * (kRgBlock / 64);
+  uint32_t grain = (total / (4u * n_waves) + 63u) & ~63u;
+  grain = grain < 64u ? 64u : (grain > 1024u ? 1024u : grain);
+
+  while (true) {
+    // ---- refill -------------------------------------------------------------------------------------------------
+    const uint64_t idle = __ballot(!busy);
+    const uint32_t n_idle = (uint32_t)__popcll(idle);
+    if (!exhausted && n_idle >= 16u) {
+      if (lo == hi) {
+        uint32_t base = 0;
+        if (lane == 0) base = atomicAdd(work, grain);
+        base = __shfl(base, 0);
+        lo = base; hi = base + grain < total ? base + grain : total;
+        if (base >= total) { exhausted = true; lo = hi = 0; }
+      }
+      if (!exhausted) {
+        const uint32_t take = (hi - lo) < n_idle ? (hi - lo) : n_idle;
+        const uint32_t rank = (uint32_t)__popcll(idle & ((1ull << lane) - 1ull));
+        if (!busy && rank < take) {
+          slot = lo + rank;
+          const uint32_t pl = slot % pd.npix, sl = slot / pd.npix;
+          uint32_t px, py;
+          pass_pixel(pd, pd.pix_begin + pl, &px, &py);
+          const uint32_t index = halton_pixel_offset(s, px, py) + (pd.s_begin + sl) * s.stride;
+          const double d0 = halton_dim(s, index, 0), d1 = halton_dim(s, index, 1), d2 = halton_cam_dim(s, index, 0), d3 = halton_cam_dim(s, index, 1);
+          pfx = (float)px + to_real<float>(d0); pfy = (float)py + to_real<float>(d1);
+          lx = to_real<float>(d2) + 0.5f; ly = to_real<float>(d3) + 0.5f;   // Q5
+          p.pixel[slot] = py * (uint32_t)s.xres + px;
+          p.hindex[slot] = index;
+          p.dim_bounce[slot] = 5u;
+          p.pfx[slot] = pfx; p.pfy[slot] = pfy;
+          p.lr[slot] = 0.0f; p.lg[slot] = 0.0f; p.lb[slot] = 0.0f;
+          p.br[slot] = 1.0f; p.bg[slot] = 1.0f; p.bb[slot] = 1.0f;
+          p.weight[slot] = 0.0f;
+          if (dims_out) { double* dd = dims_out + 5 * (size_t)(pl * pd.ns + sl); dd[0] = d0; dd[1] = d1; dd[2] = d2; dd[3] = d3; dd[4] = halton_dim(s, index, 4); }
+          L.phase = 0;
+          rg_begin(s, pfx, pfy, lx, ly, &L, &w_main);
+          busy = true;
+        }
+        lo += take;
+      }
+    }
+    if (__ballot(busy) == 0ull) { if (exhausted) break; else continue; }
+
+    // ---- one lens interface per busy lane -------------------------------------------------------------------------
+    if (busy) {
+      const bool ok = rg_step(lens_s, &L);
+      if (!ok) {
+        // main blocked: weight 0. x+ blocked: try x-. y+ blocked: try y-. x- or y- blocked: weight 0 (camera.rs:589-624)
+        if (L.phase == 1) { L.phase = 2; rg_begin(s, pfx - 0.05f, pfy, lx, ly, &L, &scratch_w); }
+        else if (L.phase == 3) { L.phase = 4; rg_begin(s, pfx, pfy - 0.05f, lx, ly, &L, &scratch_w); }
+        else busy = false;
+      } else if (L.i < 0) {
+        if (L.phase == 0) {
+          if (w_main == 0.0f) busy = false;   // `if wt == 0.0 { return 0.0 }`
+          else {
+            // ray out of the lens: flip_z, camera_to_world (double normalise), ray.d.normalize() (camera.rs:558-565)
+            RayT<float> rl; rl.o = L.o; rl.d = L.d;
+            const RayT<float> rc = flip_z(rl);
+            const V3<float> wo = aff_pt(s.cam_m, rc.o);
+            const V3<float> wd = vnormalize(vnormalize(vnormalize(aff_vec(s.cam_m, rc.d))));
+            p.ox[slot] = wo.x; p.oy[slot] = wo.y; p.oz[slot] = wo.z;
+            p.dx[slot] = wd.x; p.dy[slot] = wd.y; p.dz[slot] = wd.z;
+            p.tmax[slot] = Const<float>::inf;
+            p.skip[slot] = -1;
+            L.phase = 1; rg_begin(s, pfx + 0.05f, pfy, lx, ly, &L, &scratch_w);
+          }
+        } else if (L.phase <= 2) {
+          if (scratch_w == 0.0f) { if (L.phase == 1) { L.phase = 2; rg_begin(s, pfx - 0.05f, pfy, lx, ly, &L, &scratch_w); } else busy = false; }
+          else { L.phase = 3; rg_begin(s, pfx, pfy + 0.05f, lx, ly, &L, &scratch_w); }
+        } else {
+          if (scratch_w == 0.0f) { if (L.phase == 3) { L.phase = 4; rg_begin(s, pfx, pfy - 0.05f, lx, ly, &L, &scratch_w); } else busy = false; }
+          else { p.weight[slot] = w_main; busy = false; }   // alive: weight of the main ray
+        }
+      }
+    }
+  }
+}
+
+// alive samples (weight > 0) -> q_active; counts the reference's "rays generated". Each wave scans kCompactRun
+// consecutive 64-slot groups, reserves its output range with ONE atomic and then writes, so a 268 M-slot frame
+// issues 65 k atomics on the queue counter instead of 4 M (which serialise on one L2 atomic unit).
+constexpr uint32_t kCompactRun = 64;
+static __global__ void __launch_bounds__(kBlock) k_compact_alive(SceneDev<float> s, Pools<float> p, uint32_t total) {
+  const uint32_t lane = threadIdx.x & 63u;
+  const uint32_t wave = (blockIdx.x * blockDim.x + threadIdx.x) >> 6;
+  const uint64_t base_slot = (uint64_t)wave * 64u * kCompactRun;
+  if (base_slot >= total) return;
+  uint32_t n_alive = 0;
+  for (uint32_t k = 0; k < kCompactRun; k++) {
+    const uint64_t slot = base_slot + (uint64_t)k * 64u + lane;
+    const bool alive = slot < total && p.weight[slot] > 0.0f;
+    n_alive += (uint32_t)__popcll(__ballot(alive));
+  }
+  if (n_alive == 0) return;
+  const bool enqueue_all = s.integrator != 3;   // AOIntegrator::li returns 0 before drawing (ao.rs:62-64)
+  uint32_t out = 0;
+  if (lane == 0) {
+    atomicAdd(&p.counters[C_CAMERA_RAYS], n_alive);
+    if (enqueue_all) out = atomicAdd(&p.counters[C_ACTIVE], n_alive);
+  }
+  if (!enqueue_all) return;
+  out = __shfl(out, 0);
+  for (uint32_t k = 0; k < kCompactRun; k++) {
+    const uint64_t slot = base_slot + (uint64_t)k * 64u + lane;
+    const bool alive = slot < total && p.weight[slot] > 0.0f;
+    const uint64_t m = __ballot(alive);
+    if (alive) p.q_active[out + (uint32_t)__popcll(m & ((1ull << lane) - 1ull))] = (uint32_t)slot;
+    out += (uint32_t)__popcll(m);
   }
 }
 

@@ -93,6 +93,11 @@ struct SceneDev {
   uint32_t nsamp, sample_at_center;
   uint32_t base_exp0, base_exp1, base_scale0, base_scale1, stride, mult_inv0, mult_inv1;
   uint32_t fast_div;           // all sample indices < 2^26
+  // camera lens dimensions 2 and 3 (bases 5 and 7): digit permutation packed 3 bits per digit, and the
+  // reference's running product inv_base^k (lowdiscrepancy.rs:204-227) tabulated by the same f64 multiplications
+  uint32_t cam_perm[2];
+  double cam_invpow[2][16];
+  double cam_tail[2];          // inv_base * perm[0] / (1 - inv_base)
   // integrator
   int32_t integrator, max_depth, light_strategy;
   R rr_threshold;

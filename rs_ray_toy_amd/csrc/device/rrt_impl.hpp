@@ -118,6 +118,12 @@ class Handle : public HandleBase {
     HIP_CHECK(hipStreamCreate(&st_));
     upload_scene(d);
     HIP_CHECK(hipStreamSynchronize(st_));
+    // Large pools matter: a launch lasts at least as long as the latency chain of its longest ray, so few big
+    // launches beat many small ones (whole 1024^2 x 256 spp frame in one pass: 268 M slots x 172 B = 46 GB).
+    size_t free_b = 0, total_b = 0;
+    HIP_CHECK(hipMemGetInfo(&free_b, &total_b));
+    const size_t per_slot = 33 * sizeof(R) + 9 * sizeof(uint32_t);
+    max_paths_ = std::max<size_t>(1u << 16, std::min(max_paths_, (free_b / 2) / per_slot));
   }
   ~Handle() override {
     (void)hipSetDevice(dev_);
@@ -131,6 +137,7 @@ class Handle : public HandleBase {
     if (key == "max_paths") { if (v < 64) throw std::invalid_argument("max_paths must be >= 64"); max_paths_ = (size_t)v; }
     else if (key == "count_traversal") count_traversal_ = v != 0;
     else if (key == "persistent_traversal") { persistent_ = v != 0; if (v >= 1) trav_mode_ = (int)v; }
+    else if (key == "raygen_pt") raygen_pt_ = v != 0;
     else if (key == "pt_split_closest") pt_split_closest_ = (uint32_t)v;
     else if (key == "pt_split_any") pt_split_any_ = (uint32_t)v;
     else throw std::invalid_argument("unknown option " + key);
@@ -187,8 +194,7 @@ class Handle : public HandleBase {
     PassDesc pd{rect[0], rect[1], rect[2] - rect[0], 0u, (uint32_t)npix, (uint32_t)s0, (uint32_t)ns, 1u << 30, 1u, 0u};
     hipLaunchKernelGGL(k_rotate, dim3(1), dim3(1), 0, st_, counters_.p, 2);
     const uint32_t g = (uint32_t)((n + kBlock - 1) / kBlock);
-    hipLaunchKernelGGL((k_raygen<R>), dim3(g), dim3(kBlock), 0, st_, scene_, pool_, pd, dd.p);
-    hipLaunchKernelGGL((k_raygen_aux<R>), dim3(g), dim3(kBlock), 0, st_, scene_, pool_);
+    launch_raygen(pd, g, dd.p);
     hipLaunchKernelGGL((k_camera_dump<R>), dim3(g), dim3(kBlock), 0, st_, pool_, pd, dr.p, dw.p);
     HIP_CHECK(hipGetLastError());
     HIP_CHECK(hipMemcpyAsync(dims5, dd.p, 5 * n * sizeof(double), hipMemcpyDeviceToHost, st_));
@@ -266,9 +272,7 @@ class Handle : public HandleBase {
         const uint32_t grid = (uint32_t)((nslots + kBlock - 1) / kBlock);
         hipLaunchKernelGGL(k_rotate, dim3(1), dim3(1), 0, st_, counters_.p, 2);
         size_t e = tick(0);
-        hipLaunchKernelGGL((k_raygen<R>), dim3(grid), dim3(kBlock), 0, st_, scene_, pool_, pd, (double*)nullptr);
-        hipLaunchKernelGGL((k_raygen_aux<R>), dim3(grid), dim3(kBlock), 0, st_, scene_, pool_);
-        hipLaunchKernelGGL(k_rotate, dim3(1), dim3(1), 0, st_, counters_.p, 4);   // q_next was only a staging queue
+        launch_raygen(pd, grid, nullptr);
         tock(e);
         hipLaunchKernelGGL(k_accumulate_camera, dim3(1), dim3(1), 0, st_, counters_.p, totals_.p);
         if (integ == RRT_INT_PATH) {
@@ -374,10 +378,11 @@ class Handle : public HandleBase {
   SceneDev<R> scene_{};
   Pools<R> pool_{};
   size_t cap_ = 0;
-  size_t max_paths_ = (size_t)1 << 24;
+  size_t max_paths_ = (size_t)1 << 28;   // clamped to half of the free HBM at creation (sized for 288 GB parts)
   bool deep_ = false, count_traversal_ = false, persistent_ = true;
   bool pairs_ok_ = false;
-  uint32_t trav_grid_ = 0, pt_grid_ = 0;
+  uint32_t trav_grid_ = 0, pt_grid_ = 0, rg_grid_ = 0;
+  bool raygen_pt_ = true;
   int trav_mode_ = 3;   // 1 = LDS-treelet grid-stride kernel, 2 = persistent-thread kernel, 3 = by queue size
   uint32_t pt_split_closest_ = 600000u, pt_split_any_ = 2500000u;
   DevBuf<uint32_t> pt_overflow_;
@@ -570,6 +575,17 @@ class Handle : public HandleBase {
     s.base_scale0 = (uint32_t)d->sampler.base_scales[0]; s.base_scale1 = (uint32_t)d->sampler.base_scales[1];
     s.stride = (uint32_t)d->sampler.sample_stride; s.mult_inv0 = (uint32_t)d->sampler.mult_inverse[0]; s.mult_inv1 = (uint32_t)d->sampler.mult_inverse[1];
     s.fast_div = (d->sampler.sample_stride * (d->sampler.samples_per_pixel + 1) < (1ull << 26)) ? 1u : 0u;
+    for (int w = 0; w < 2; w++) {   // lens dims 2, 3: bases hd[2].base = 5, hd[3].base = 7
+      const uint32_t base = hd[2 + w].base;
+      uint32_t packed = 0;
+      const uint16_t* pm = perms.empty() ? nullptr : perms.data() + hd[2 + w].perm_offset;
+      for (uint32_t dgt = 0; dgt < base && pm; dgt++) packed |= ((uint32_t)pm[dgt] & 7u) << (3u * dgt);
+      s.cam_perm[w] = packed;
+      const double inv_base = 1.0 / (double)base;
+      double v = 1.0;
+      for (int k = 0; k < 16; k++) { s.cam_invpow[w][k] = v; v *= inv_base; }
+      s.cam_tail[w] = pm ? inv_base * (double)pm[0] / (1.0 - inv_base) : 0.0;
+    }
     s.integrator = d->integrator.type; s.max_depth = d->integrator.max_depth; s.light_strategy = d->integrator.light_strategy;
     s.rr_threshold = (R)d->integrator.rr_threshold;
     counters_.alloc(C_COUNT);
@@ -597,7 +613,7 @@ class Handle : public HandleBase {
     p.hprim = (int32_t*)nu(); p.skip = (int32_t*)nu(); p.sskip = (int32_t*)nu(); p.pixel = nu(); p.hindex = nu(); p.dim_bounce = nu(); p.q_active = nu(); p.q_next = nu(); p.q_shadow = nu();
     p.counters = counters_.p;
     if (deep_) deep_stack_.alloc((size_t)scene_.stack_depth * cap_);
-    if (pairs_ok_ && scene_.stack_depth > (uint32_t)kStackLds) overflow_.alloc((size_t)(scene_.stack_depth - kStackLds) * cap_ * 2);
+
   }
 
   void load_rays(const rrt_rays* rays, size_t n) {
@@ -624,19 +640,44 @@ class Handle : public HandleBase {
     }
     HIP_CHECK(hipGetLastError());
   }
+  // camera ray generation: persistent-thread kernel in fp32, two-stage (main trace, compaction, auxiliary traces) in f64
+  void launch_raygen(const PassDesc& pd, uint32_t grid, double* dims_out) {
+    if constexpr (std::is_same<R, float>::value) {
+      if (raygen_pt_ && scene_.n_lens <= 32) {
+        if (rg_grid_ == 0) {
+          int per_cu = 0, cus = 0;
+          HIP_CHECK(hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, dev_));
+          HIP_CHECK(hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu, k_raygen_pt_f32, kRgBlock, 0));
+          rg_grid_ = (uint32_t)(std::max(1, per_cu) * std::max(1, cus));
+        }
+        const uint32_t total = pd.npix * pd.ns;
+        const uint32_t g = std::max(1u, std::min((total + kRgBlock - 1) / kRgBlock, rg_grid_));
+        hipLaunchKernelGGL(k_raygen_pt_f32, dim3(g), dim3(kRgBlock), 0, st_, scene_, pool_, pd, &counters_.p[C_WORK_AUX], dims_out);
+        const uint32_t n_cw = (total + 64u * kCompactRun - 1) / (64u * kCompactRun);   // waves
+        hipLaunchKernelGGL(k_compact_alive, dim3((n_cw * 64u + kBlock - 1) / kBlock), dim3(kBlock), 0, st_, scene_, pool_, total);
+        HIP_CHECK(hipGetLastError());
+        return;
+      }
+    }
+    hipLaunchKernelGGL((k_raygen<R>), dim3(grid), dim3(kBlock), 0, st_, scene_, pool_, pd, dims_out);
+    hipLaunchKernelGGL((k_raygen_aux<R>), dim3(grid), dim3(kBlock), 0, st_, scene_, pool_);
+    hipLaunchKernelGGL(k_rotate, dim3(1), dim3(1), 0, st_, counters_.p, 4);   // q_next was only a staging queue
+    HIP_CHECK(hipGetLastError());
+  }
   // fp32 production traversal (dtraverse_f32.hpp): 64 B pair nodes, LDS stack with global overflow
   bool use_persistent() const { return std::is_same<R, float>::value && persistent_ && pairs_ok_; }
   void launch_persistent(bool any, const uint32_t* queue, const uint32_t* count, uint32_t n_fixed, uint32_t grid, uint8_t* occluded) {
     if constexpr (std::is_same<R, float>::value) {
       const uint32_t grid_in = grid;
-      trav_.overflow = overflow_.p;
-      trav_.overflow_stride = (uint32_t)cap_;
       if (trav_grid_ == 0) {
         int per_cu = 0, cus = 0;
         HIP_CHECK(hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, dev_));
         HIP_CHECK(hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu, k_trace_pairs_f32<false>, kTravBlock, 0));
         trav_grid_ = (uint32_t)(std::max(1, per_cu) * std::max(1, cus));
+        if (scene_.stack_depth > (uint32_t)kStackLds) overflow_.alloc((size_t)(scene_.stack_depth - kStackLds) * (size_t)trav_grid_ * kTravBlock * 2);
       }
+      trav_.overflow = overflow_.p;
+      trav_.overflow_stride = trav_grid_ * kTravBlock;   // one column per resident thread of the persistent grid
       // persistent workgroups: grid-stride over the queue (slots / kBlock thread blocks were requested by the caller)
       const uint32_t need = (uint32_t)(((size_t)grid * kBlock + kTravBlock - 1) / kTravBlock);
       grid = std::max(1u, std::min(need, trav_grid_));

@@ -121,9 +121,18 @@ def _film_err(film, ref):
     return np.abs(film[..., :3].astype(np.float64) - ref[..., :3]).max() / scale, scale
 
 
+def _cfg3_tilted(wd):
+    """cfg3 with the enclosure and the cube instanced under generic rotations: the literal axis-aligned box has flat
+    wall triangles whose leaf boxes are coplanar with them, i.e. exact box/face ties (see the module docstring)."""
+    cfg, root = scenes.cfg3(wd, xres=64, yres=64, nsamp=5, max_depth=5)
+    cfg["Aggregate"]["primitives"][0]["instances"][0]["rotation_axis"] = [1.0, 2.0, 3.0]
+    cfg["Aggregate"]["primitives"][1]["instances"] = [{"world_pos": [0.0, 0.0, 0.0], "rotation_axis": [3.0, 1.0, 2.0], "rotation_angle": 7}]
+    return cfg, root
+
+
 RENDER_CASES = {
     "cfg2_path": lambda wd: scenes.cfg2(wd, xres=96, yres=96, nsamp=9, max_depth=4),
-    "cfg3_path": lambda wd: scenes.cfg3(wd, xres=64, yres=64, nsamp=5, max_depth=5),
+    "cfg3_path": lambda wd: _cfg3_tilted(wd),
     "cfg4_path": lambda wd: scenes.cfg4(wd, xres=64, yres=64, nsamp=5, max_depth=8, n=48),
     "cfg5_path": lambda wd: scenes.cfg5(wd, xres=64, yres=64, nsamp=9, max_depth=16, n=48),
 }
