@@ -162,12 +162,15 @@ def main():
         # per-rank kernel time: ranks run concurrently, take the slowest rank's sum
         ms_closest = mx_tot["ms_closest"]
         achieved = (bytes_closest / world) / (ms_closest * 1e-3) / 1e9 if ms_closest > 0 else 0.0
+        # `traffic`: HBM bytes per launch from the committed PMC passes of this same workload (tools/profile_round.sh;
+        # separate --pmc FETCH_SIZE / WRITE_SIZE runs, x1024, reads x2 per the gfx950 note). Far BELOW the
+        # algorithmic bytes: the 11 MB BVH + triangles live in L2 / Infinity Cache, only ray/hit streams reach HBM.
         traffic = None
-        pmc = os.path.join(ROOT, "profiles", "r1_pmc_closest.json")
-        if os.path.exists(pmc):
+        pmc = os.path.join(ROOT, "profiles", "r1_pmc_traffic.json")
+        if os.path.exists(pmc) and args.res == 1024 and args.spp == 256 and args.depth == 8 and world == 1:
             with open(pmc) as f:
-                traffic = json.load(f).get("hbm_bytes_per_launch")
-        roofline = {"kernel": "k_closest<float>", "bound": "hbm", "achieved": round(achieved, 2), "peak": HBM_PEAK_GBS, "unit": "GB/s",
+                traffic = round(json.load(f)["closest"]["hbm_bytes"] / n_launch, 1)
+        roofline = {"kernel": "k_trace_pt_f32<false> + k_trace_pairs_f32<false> (closest-hit BVH traversal, one pair per bounce)", "bound": "hbm", "achieved": round(achieved, 2), "peak": HBM_PEAK_GBS, "unit": "GB/s",
                     "frac": round(achieved / HBM_PEAK_GBS, 4), "traffic": traffic,
                     "algorithmic_bytes_per_launch": round(bytes_closest / n_launch, 1),
                     "avg_launch_ms": round(ms_closest * world / n_launch, 4), "launches": int(n_launch),
