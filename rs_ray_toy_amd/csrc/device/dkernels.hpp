@@ -115,6 +115,79 @@ struct GlobStack {
 template <typename R> RRT_DEV int self_prim(int prim) { return sizeof(R) == 4 ? prim : -1; }
 template <typename R> RRT_DEV uint32_t skip_plane_of(const SceneDev<R>& s, int skip) { return skip >= 0 ? s.tris[skip].plane : 0xffffffffu; }
 
+// Sphere::intersect (sphere.rs:124-259) / Sphere::intersect_p (:51-108) behind GeometricPrimitive /
+// TransformedPrimitive (primitives.rs:51-68,115-139), replayed transform by transform.
+//   * the quadratic is solved with the object-space ray, the first p_hit uses the ray *handed to the sphere* (Q16);
+//   * intersect_p tests the clipping planes against p_hit = 0, phi = 0 first (:75-83);
+//   * neither compares t with ray.t_max (Q10).
+// There is no epsilon in sphere.rs: a ray spawned on a sphere re-tests it with c = |o|^2 - r^2 ~ 1 ulp of either
+// sign and re-hits its own sphere at t ~ 0 whenever the stored hit point landed inside, i.e. for about half of the
+// spawned rays. The reference's pixels on spheres are that rounding noise. The f64 mode replays it bit for bit; the
+// fp32 mode deliberately keeps the same test (no self exclusion, unlike triangles), so it shows the same noise in
+// distribution (mean radiance within a few % of the oracle) though not pixel by pixel.
+template <typename R>
+struct SphereSI { V3<R> p, n, wo, sn, sdpdu; };
+
+template <typename R, bool ANY>
+RRT_DEV bool sphere_prim_hit(const SphereDev<R>& S, V3<R> wo_, V3<R> wd_, R* t_out, SphereSI<R>* si) {
+  V3<R> ro = wo_, rd = wd_;
+  if (S.has_inst) { ro = aff_pt(S.imi, wo_); rd = vnormalize(vnormalize(aff_vec(S.imi, wd_))); }   // xf_ray + Ray::new
+  const V3<R> oo = aff_pt(S.mi, ro), od = vnormalize(vnormalize(aff_vec(S.mi, rd)));
+  const R a = od.x * od.x + od.y * od.y + od.z * od.z;
+  const R b = R(2) * (od.x * oo.x + od.y * oo.y + od.z * oo.z);
+  const R c = oo.x * oo.x + oo.y * oo.y + oo.z * oo.z - S.radius * S.radius;
+  R t0, t1;
+  if (!quadratic(a, b, c, &t0, &t1)) return false;
+  const R kMax = R(1999999999.0);   // MAX_DIST misc.rs
+  if (t0 > kMax || t1 <= R(0)) return false;
+  R th = t0;
+  if (t0 <= R(0)) { th = t1; if (th > kMax) return false; }
+  V3<R> ph = ANY ? V3<R>() : ro + rd * th;
+  R phi = R(0);
+  if (!ANY) {
+    if (ph.x == R(0) && ph.y == R(0)) ph.x = R(1e-5) * S.radius;
+    phi = atan2(ph.y, ph.x);
+    if (phi < R(0)) phi += R(2) * R(RRT_PI);
+  }
+  if ((S.z_min > -S.radius && ph.z < S.z_min) || (S.z_max < S.radius && ph.z > S.z_max) || (phi > S.phi_max)) {
+    if (th == t1) return false;
+    if (t1 > kMax) return false;
+    th = t1;
+    ph = oo + od * th;
+    ph = ph * (S.radius / len(ph));
+    if (ph.x == R(0) && ph.y == R(0)) ph.x = R(1e-5) * S.radius;
+    phi = atan2(ph.y, ph.x);
+    if (phi < R(0)) phi += R(2) * R(RRT_PI);
+    if ((S.z_min > -S.radius && ph.z < S.z_min) || (S.z_max < S.radius && ph.z > S.z_max) || (phi > S.phi_max)) return false;
+  }
+  if (ANY) return true;
+  *t_out = th;
+  if (si) {
+    const R theta = acos(clampr(ph.z / S.radius, R(-1), R(1)));
+    const R z_radius = sqrt(ph.x * ph.x + ph.y * ph.y);
+    const R inv_zr = R(1) / z_radius;
+    const R cphi = ph.x * inv_zr, sphi = ph.y * inv_zr;
+    const V3<R> dpdu(-S.phi_max * ph.y, S.phi_max * ph.x, R(0));
+    const V3<R> dpdv = V3<R>(ph.z * cphi, ph.z * sphi, -S.radius * R(sin(theta))) * (S.theta_max - S.theta_min);
+    // SurfaceInteraction::new (interaction.rs:131-181) then obj_to_world.t(&ist) (transform.rs:628-655)
+    V3<R> n = vnormalize(cross(dpdu, dpdv));
+    si->p = aff_pt(S.m, ph);
+    si->wo = aff_vec(S.m, -od);
+    si->n = aff_nrm(S.mi, n);
+    si->sn = faceforward(nnormalize(aff_nrm(S.mi, n)), si->n);
+    si->sdpdu = aff_vec(S.m, dpdu);
+    if (S.has_inst && !S.inst_identity) {   // TransformedPrimitive::intersect primitives.rs:131-136
+      si->p = aff_pt(S.im, si->p);
+      si->wo = aff_vec(S.im, si->wo);
+      const V3<R> n2 = aff_nrm(S.imi, si->n);
+      si->sn = faceforward(nnormalize(aff_nrm(S.imi, si->sn)), n2);
+      si->n = n2;
+      si->sdpdu = aff_vec(S.im, si->sdpdu);
+    }
+  }
+  return true;
+}
+
 template <typename R, typename Stack>
 RRT_DEV int traverse_closest(const SceneDev<R>& s, RayCtx<R>& r, Stack& st, int skip, R* hu, R* hv, uint32_t* nn, uint32_t* np) {
   int hit = -1;
@@ -131,6 +204,10 @@ RRT_DEV int traverse_closest(const SceneDev<R>& s, RayCtx<R>& r, Stack& st, int 
           cp++;
           R t, u, v;
           const Tri<R> tr = s.tris[nd.offset + i];
+          if (tr.plane == kSphereMark) {
+            if (sphere_prim_hit<R, false>(s.spheres[tr.shade], r.o, r.d, &t, (SphereSI<R>*)nullptr)) { r.tmax = t; hit = (int)(nd.offset + i); *hu = R(0); *hv = R(0); }
+            continue;
+          }
           if (tr.plane == skip_plane) continue;
           if (tri_closest(tr, r, &t, &u, &v)) { r.tmax = t; hit = (int)(nd.offset + i); *hu = u; *hv = v; }
         }
@@ -163,6 +240,11 @@ RRT_DEV bool traverse_any(const SceneDev<R>& s, const RayCtx<R>& r, Stack& st, i
         for (uint32_t i = 0; i < nprims; i++) {
           cp++;
           const Tri<R> tr = s.tris[nd.offset + i];
+          if (tr.plane == kSphereMark) {
+            R t;
+            if (sphere_prim_hit<R, true>(s.spheres[tr.shade], r.o, r.d, &t, (SphereSI<R>*)nullptr)) { found = true; break; }
+            continue;
+          }
           if (tr.plane == skip_plane) continue;
           if (tri_any(tr, r)) { found = true; break; }
         }
@@ -358,6 +440,15 @@ template <typename R>
 RRT_DEV Surf<R> build_surface(const SceneDev<R>& s, int prim, V3<R> o, V3<R> d, R t, R u, R v) {
   Surf<R> si;
   const Tri<R> tr = s.tris[prim];
+  if (tr.plane == kSphereMark) {   // redo the accepted test with the interaction outputs switched on
+    SphereSI<R> ss;
+    R th;
+    si.ok = sphere_prim_hit<R, false>(s.spheres[tr.shade], o, d, &th, &ss);
+    si.p = ss.p; si.n = ss.n; si.wo = ss.wo; si.sn = ss.sn; si.sdpdu = ss.sdpdu;
+    si.material = tr.material;
+    if (!(dot(si.n, si.sn) >= R(0))) si.ok = false;   // primitives.rs:66
+    return si;
+  }
   V3<R> p0(tr.p0), p1(tr.p1), p2(tr.p2);
   R uv[3][2] = {{R(0), R(0)}, {R(1), R(0)}, {R(1), R(1)}};  // get_uvs :113-128
   uint32_t has_n = 0;

@@ -27,6 +27,21 @@ struct alignas(16) Tri {
   uint32_t plane;      // id shared by exactly coplanar triangles (host, see plane_ids()); used by self_prim()
 };
 
+// A sphere primitive of the aggregate occupies one Tri slot (so node.offset still indexes one array in traversal
+// order): plane == kSphereMark, shade = index into SceneDev::spheres, material as usual.
+constexpr uint32_t kSphereMark = 0xfffffffeu;
+
+// Sphere (shape/sphere.rs:14-49) + the TransformedPrimitive around it (primitives.rs:100-139). Spheres are not
+// flattened: the reference's own sequence of ray transforms is replayed, including its quirks (Q15, Q16).
+template <typename R>
+struct SphereDev {
+  R m[12], mi[12];       // the sphere's obj_to_world / world_to_obj (rows 0..2)
+  R im[12], imi[12];     // instance primitive_to_world / its inverse
+  R radius, z_min, z_max, theta_min, theta_max, phi_max;
+  uint32_t has_inst;     // 0: GeometricPrimitive used directly; 1: wrapped in a TransformedPrimitive
+  uint32_t inst_identity;  // TransformedPrimitive::intersect skips the interaction transform for the identity
+};
+
 // Optional per-triangle shading attributes (meshes with vn / vt), world space.
 template <typename R>
 struct TriShade {
@@ -70,6 +85,7 @@ struct SceneDev {
   const Node<R>* nodes;
   const Tri<R>* tris;
   const TriShade<R>* shades;
+  const SphereDev<R>* spheres;
   const Material<R>* materials;
   const Light<R>* lights;
   const R* light_cdf;          // Distribution1D([1; n]).cdf, n_lights + 1 entries

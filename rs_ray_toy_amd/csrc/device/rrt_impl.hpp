@@ -392,6 +392,7 @@ class Handle : public HandleBase {
   DevBuf<Node<R>> nodes_;
   DevBuf<Tri<R>> tris_;
   DevBuf<TriShade<R>> shades_;
+  DevBuf<SphereDev<R>> spheres_;
   DevBuf<Material<R>> materials_;
   DevBuf<Light<R>> lights_;
   DevBuf<R> light_cdf_;
@@ -444,12 +445,34 @@ class Handle : public HandleBase {
     // triangles in traversal order, flattened to world space (TransformedPrimitive, primitives.rs:115-139)
     std::vector<Tri<R>> tris(d->n_prim_order);
     std::vector<TriShade<R>> shades;
+    std::vector<SphereDev<R>> spheres;
     std::vector<double> world(9 * d->n_prim_order);
     for (size_t i = 0; i < d->n_prim_order; i++) {
       const uint32_t pi = d->prim_order[i];
       const rrt_prim& pr = d->prims[pi];
-      if (pr.type != RRT_PRIM_TRIANGLE)
-        throw UnsupportedError("sphere primitives in the aggregate are CPU-oracle only this round (BASELINE config 1); sphere *light shapes* are supported");
+      if (pr.type != RRT_PRIM_TRIANGLE) {   // sphere: one marked Tri slot + a SphereDev record (not flattened)
+        const rrt_sphere& sp = d->spheres[pr.shape];
+        SphereDev<R> sd{};
+        affine_rows(d->xforms[sp.xform].m, sd.m, "sphere obj_to_world");
+        affine_rows(d->xforms[sp.xform].m_inv, sd.mi, "sphere world_to_obj");
+        const double ident[16] = {1, 0, 0, 0, 0, 1, 0, 0, 0, 0, 1, 0, 0, 0, 0, 1};
+        const double* im = pr.instance >= 0 ? d->xforms[pr.instance].m : ident;
+        const double* imi = pr.instance >= 0 ? d->xforms[pr.instance].m_inv : ident;
+        affine_rows(im, sd.im, "sphere instance transform");
+        affine_rows(imi, sd.imi, "sphere instance transform");
+        sd.has_inst = pr.instance >= 0 ? 1u : 0u;
+        sd.inst_identity = 1u;   // Transform::is_identity transform.rs:229-246 (value compare)
+        for (int k = 0; k < 16; k++) if (im[k] != ident[k]) sd.inst_identity = 0u;
+        sd.radius = (R)sp.radius; sd.z_min = (R)sp.z_min; sd.z_max = (R)sp.z_max;
+        sd.theta_min = (R)sp.theta_min; sd.theta_max = (R)sp.theta_max; sd.phi_max = (R)sp.phi_max;
+        Tri<R>& o = tris[i];
+        memset(&o, 0, sizeof(o));
+        o.material = pr.material;
+        o.shade = (uint32_t)spheres.size();
+        o.plane = kSphereMark;
+        spheres.push_back(sd);
+        continue;
+      }
       const rrt_tri& t = d->tris[pr.shape];
       const double* m = nullptr;
       const double* mi = nullptr;
@@ -488,7 +511,7 @@ class Handle : public HandleBase {
     }
     {
       std::vector<uint32_t> ids = plane_ids(world, d->n_prim_order, d->world_bound);
-      for (size_t i = 0; i < d->n_prim_order; i++) tris[i].plane = ids[i];
+      for (size_t i = 0; i < d->n_prim_order; i++) if (tris[i].plane != kSphereMark) tris[i].plane = ids[i];
     }
     std::vector<Material<R>> mats(d->n_materials);
     for (size_t i = 0; i < d->n_materials; i++) {
@@ -551,12 +574,14 @@ class Handle : public HandleBase {
     std::vector<uint16_t> perms;
     if (d->sampler.type == RRT_SAMPLER_HALTON && d->sampler.perms) perms.assign(d->sampler.perms, d->sampler.perms + d->sampler.n_perms);
 
-    nodes_.upload(nodes, st_); tris_.upload(tris, st_); build_pairs(nodes, tris.size()); shades_.upload(shades, st_); materials_.upload(mats, st_);
+    nodes_.upload(nodes, st_); tris_.upload(tris, st_); build_pairs(nodes, tris.size()); shades_.upload(shades, st_); spheres_.upload(spheres, st_);
+    materials_.upload(mats, st_);
+    if (!spheres.empty()) pairs_ok_ = false;   // the fp32 pair-node kernels are triangle-only: sphere scenes use the generic kernels
     lights_.upload(lights, st_); light_cdf_.upload(cdf_r, st_); lens_.upload(lens, st_); hdims_.upload(hd, st_); perms_.upload(perms, st_);
     HIP_CHECK(hipStreamSynchronize(st_));  // host vectors go out of scope below
 
     SceneDev<R>& s = scene_;
-    s.nodes = nodes_.p; s.tris = tris_.p; s.shades = shades_.p; s.materials = materials_.p; s.lights = lights_.p; s.light_cdf = light_cdf_.p;
+    s.nodes = nodes_.p; s.tris = tris_.p; s.shades = shades_.p; s.spheres = spheres_.p; s.materials = materials_.p; s.lights = lights_.p; s.light_cdf = light_cdf_.p;
     s.n_nodes = (uint32_t)d->n_bvh_nodes; s.n_tris = (uint32_t)d->n_prim_order; s.n_lights = (uint32_t)nl;
     s.light_pick_pdf = (nl && func_int > 0.0) ? (R)(1.0 / (func_int * (double)nl)) : (R)0;
     s.stack_depth = d->bvh_depth + 1;

@@ -143,7 +143,7 @@ def write_heightfield(workdir, n=224, extent=20.0, center=(35.0, 0.0, 0.0), amp=
 
 
 def cfg1(workdir, xres=256, yres=256, nsamp=2):
-    """24 spheres r=0.75 via `instances` (Q16), 3 point lights, DirectLighting. CPU oracle only."""
+    """24 spheres r=0.75 via `instances` (Q16), 3 point lights, DirectLighting (BASELINE config 1)."""
     cfg = _base(xres, yres, nsamp, {"integrator_type": "DirectLighting", "light_strategy": "all", "max_depth": 5})
     cfg["lights"] = SCENE_JSON_LIGHTS
     inst = []
