@@ -444,16 +444,42 @@ RRT_DEV bool rg_step(const float4* lens_s, RgLane* L) {
   return true;
 }
 
-// `dims_out` (optional): the five sampler dimensions per slot, [pixel][sample] order (rrt_camera_samples)
-static __global__ void __launch_bounds__(kRgBlock) k_raygen_pt_f32(SceneDev<float> s, Pools<float> p, PassDesc pd, uint32_t* work, double* dims_out) {
+// Stage 1, dense (one thread per slot, every lane busy): get_camerasample (samplers/mod.rs:28-34) = Halton index and
+// the four film / lens dimensions, plus the initial path state. All stores are coalesced in slot order, which is why
+// the state of dead samples is written too: 14 streamed words per slot cost less than scattered stores for the 31 %
+// that survive. `dims_out` (optional): the five sampler dimensions per slot, [pixel][sample] order (rrt_camera_samples)
+static __global__ void __launch_bounds__(kBlock) k_sample_f32(SceneDev<float> s, Pools<float> p, PassDesc pd, double* dims_out) {
+  const uint32_t slot = blockIdx.x * blockDim.x + threadIdx.x;
+  if (slot >= pd.npix * pd.ns) return;
+  const uint32_t pl = slot % pd.npix, sl = slot / pd.npix;
+  uint32_t px, py;
+  pass_pixel(pd, pd.pix_begin + pl, &px, &py);
+  const uint32_t index = halton_pixel_offset(s, px, py) + (pd.s_begin + sl) * s.stride;
+  const double d0 = halton_dim(s, index, 0), d1 = halton_dim(s, index, 1), d2 = halton_cam_dim(s, index, 0), d3 = halton_cam_dim(s, index, 1);
+  p.pfx[slot] = (float)px + to_real<float>(d0); p.pfy[slot] = (float)py + to_real<float>(d1);
+  p.sox[slot] = to_real<float>(d2) + 0.5f; p.soy[slot] = to_real<float>(d3) + 0.5f;   // p_lens (Q5), parked in the shadow-ray arrays
+  p.pixel[slot] = py * (uint32_t)s.xres + px;
+  p.hindex[slot] = index;
+  p.dim_bounce[slot] = 5u;
+  p.lr[slot] = 0.0f; p.lg[slot] = 0.0f; p.lb[slot] = 0.0f;
+  p.br[slot] = 1.0f; p.bg[slot] = 1.0f; p.bb[slot] = 1.0f;
+  p.weight[slot] = 0.0f;
+  if (dims_out) { double* dd = dims_out + 5 * (size_t)(pl * pd.ns + sl); dd[0] = d0; dd[1] = d1; dd[2] = d2; dd[3] = d3; dd[4] = halton_dim(s, index, 4); }
+}
+
+// Stage 2, persistent threads: the lens traces. A lane holds one sample and walks (trace, interface); a decided lane
+// (blocked or through all five traces' logic) takes the next sample of its wave's reserved range. Exactly one
+// rg_begin site and one rg_step site per loop iteration, so lanes in different traces still execute together.
+// Only survivors write: the camera ray and the weight (dead samples keep the 0 from stage 1).
+static __global__ void __launch_bounds__(kRgBlock) k_raygen_pt_f32(SceneDev<float> s, Pools<float> p, PassDesc pd, uint32_t* work) {
   __shared__ float4 lens_s[32];
   const uint32_t tid = threadIdx.x, lane = tid & 63u;
   if (tid < (uint32_t)s.n_lens) { const LensElem<float> e = s.lens[tid]; lens_s[tid] = make_float4(e.curvature_radius, e.thickness, e.eta, e.aperture_radius); }
   __syncthreads();
   const uint32_t total = pd.npix * pd.ns;
-  bool busy = false, exhausted = false;
+  bool busy = false, exhausted = false, begin = false;
   uint32_t slot = 0, lo = 0, hi = 0;
-  float pfx = 0, pfy = 0, lx = 0, ly = 0, w_main = 0, scratch_w = 0;
+  float pfx = 0, pfy = 0, lx = 0, ly = 0, w_main = 0, w_cur = 0;
   RgLane L; L.i = -1; L.phase = 0; L.element_z = 0;
   const uint32_t n_waves = gridDim.x * (kRgBlock / 64);
   uint32_t grain = (total / (4u * n_waves) + 63u) & ~63u;
@@ -476,43 +502,32 @@ static __global__ void __launch_bounds__(kRgBlock) k_raygen_pt_f32(SceneDev<floa
         const uint32_t rank = (uint32_t)__popcll(idle & ((1ull << lane) - 1ull));
         if (!busy && rank < take) {
           slot = lo + rank;
-          const uint32_t pl = slot % pd.npix, sl = slot / pd.npix;
-          uint32_t px, py;
-          pass_pixel(pd, pd.pix_begin + pl, &px, &py);
-          const uint32_t index = halton_pixel_offset(s, px, py) + (pd.s_begin + sl) * s.stride;
-          const double d0 = halton_dim(s, index, 0), d1 = halton_dim(s, index, 1), d2 = halton_cam_dim(s, index, 0), d3 = halton_cam_dim(s, index, 1);
-          pfx = (float)px + to_real<float>(d0); pfy = (float)py + to_real<float>(d1);
-          lx = to_real<float>(d2) + 0.5f; ly = to_real<float>(d3) + 0.5f;   // Q5
-          p.pixel[slot] = py * (uint32_t)s.xres + px;
-          p.hindex[slot] = index;
-          p.dim_bounce[slot] = 5u;
-          p.pfx[slot] = pfx; p.pfy[slot] = pfy;
-          p.lr[slot] = 0.0f; p.lg[slot] = 0.0f; p.lb[slot] = 0.0f;
-          p.br[slot] = 1.0f; p.bg[slot] = 1.0f; p.bb[slot] = 1.0f;
-          p.weight[slot] = 0.0f;
-          if (dims_out) { double* dd = dims_out + 5 * (size_t)(pl * pd.ns + sl); dd[0] = d0; dd[1] = d1; dd[2] = d2; dd[3] = d3; dd[4] = halton_dim(s, index, 4); }
+          pfx = p.pfx[slot]; pfy = p.pfy[slot]; lx = p.sox[slot]; ly = p.soy[slot];
           L.phase = 0;
-          rg_begin(s, pfx, pfy, lx, ly, &L, &w_main);
-          busy = true;
+          busy = true; begin = true;
         }
         lo += take;
       }
     }
     if (__ballot(busy) == 0ull) { if (exhausted) break; else continue; }
 
+    // ---- start of a trace (main, x+, x-, y+, y-: camera.rs:589-624) -------------------------------------------------
+    if (begin) {
+      const float ox = L.phase == 1 ? 0.05f : (L.phase == 2 ? -0.05f : 0.0f);
+      const float oy = L.phase == 3 ? 0.05f : (L.phase == 4 ? -0.05f : 0.0f);
+      rg_begin(s, pfx + ox, pfy + oy, lx, ly, &L, &w_cur);
+      if (L.phase == 0) w_main = w_cur;
+      begin = false;
+    }
     // ---- one lens interface per busy lane -------------------------------------------------------------------------
     if (busy) {
       const bool ok = rg_step(lens_s, &L);
-      if (!ok) {
-        // main blocked: weight 0. x+ blocked: try x-. y+ blocked: try y-. x- or y- blocked: weight 0 (camera.rs:589-624)
-        if (L.phase == 1) { L.phase = 2; rg_begin(s, pfx - 0.05f, pfy, lx, ly, &L, &scratch_w); }
-        else if (L.phase == 3) { L.phase = 4; rg_begin(s, pfx, pfy - 0.05f, lx, ly, &L, &scratch_w); }
-        else busy = false;
-      } else if (L.i < 0) {
+      const bool through = ok && L.i < 0;
+      const bool pass = through && w_cur != 0.0f;           // this trace returned a non-zero weight
+      if (!ok || through) {
         if (L.phase == 0) {
-          if (w_main == 0.0f) busy = false;   // `if wt == 0.0 { return 0.0 }`
-          else {
-            // ray out of the lens: flip_z, camera_to_world (double normalise), ray.d.normalize() (camera.rs:558-565)
+          if (!pass) busy = false;                            // `if wt == 0.0 { return 0.0 }`
+          else {   // ray out of the lens = flip_z, camera_to_world (double normalise), ray.d.normalize() (camera.rs:558-565)
             RayT<float> rl; rl.o = L.o; rl.d = L.d;
             const RayT<float> rc = flip_z(rl);
             const V3<float> wo = aff_pt(s.cam_m, rc.o);
@@ -521,14 +536,14 @@ static __global__ void __launch_bounds__(kRgBlock) k_raygen_pt_f32(SceneDev<floa
             p.dx[slot] = wd.x; p.dy[slot] = wd.y; p.dz[slot] = wd.z;
             p.tmax[slot] = Const<float>::inf;
             p.skip[slot] = -1;
-            L.phase = 1; rg_begin(s, pfx + 0.05f, pfy, lx, ly, &L, &scratch_w);
+            L.phase = 1; begin = true;
           }
-        } else if (L.phase <= 2) {
-          if (scratch_w == 0.0f) { if (L.phase == 1) { L.phase = 2; rg_begin(s, pfx - 0.05f, pfy, lx, ly, &L, &scratch_w); } else busy = false; }
-          else { L.phase = 3; rg_begin(s, pfx, pfy + 0.05f, lx, ly, &L, &scratch_w); }
-        } else {
-          if (scratch_w == 0.0f) { if (L.phase == 3) { L.phase = 4; rg_begin(s, pfx, pfy - 0.05f, lx, ly, &L, &scratch_w); } else busy = false; }
-          else { p.weight[slot] = w_main; busy = false; }   // alive: weight of the main ray
+        } else if (L.phase == 1) { L.phase = pass ? 3 : 2; begin = true; }
+        else if (L.phase == 2) { if (pass) { L.phase = 3; begin = true; } else busy = false; }
+        else if (L.phase == 3 && !pass) { L.phase = 4; begin = true; }
+        else {
+          if (pass) p.weight[slot] = w_main;   // alive: weight of the main ray (dead samples keep stage 1's 0)
+          busy = false;
         }
       }
     }

@@ -677,7 +677,8 @@ class Handle : public HandleBase {
         }
         const uint32_t total = pd.npix * pd.ns;
         const uint32_t g = std::max(1u, std::min((total + kRgBlock - 1) / kRgBlock, rg_grid_));
-        hipLaunchKernelGGL(k_raygen_pt_f32, dim3(g), dim3(kRgBlock), 0, st_, scene_, pool_, pd, &counters_.p[C_WORK_AUX], dims_out);
+        hipLaunchKernelGGL(k_sample_f32, dim3((total + kBlock - 1) / kBlock), dim3(kBlock), 0, st_, scene_, pool_, pd, dims_out);
+        hipLaunchKernelGGL(k_raygen_pt_f32, dim3(g), dim3(kRgBlock), 0, st_, scene_, pool_, pd, &counters_.p[C_WORK_AUX]);
         const uint32_t n_cw = (total + 64u * kCompactRun - 1) / (64u * kCompactRun);   // waves
         hipLaunchKernelGGL(k_compact_alive, dim3((n_cw * 64u + kBlock - 1) / kBlock), dim3(kBlock), 0, st_, scene_, pool_, total);
         HIP_CHECK(hipGetLastError());
