@@ -1,13 +1,17 @@
 // Wavefront kernels (gfx950, wave64): camera ray generation, BVH traversal (closest / any), shading
 // (next-event estimation + BSDF sampling + Russian roulette), film accumulation. One thread = one path
-// slot; live paths are carried between kernels as index queues compacted with wave ballots (wave_push).
+// slot; live paths are carried between kernels as index queues compacted with wave ballots and one atomic per block (block_push).
 #pragma once
 #include "dmath.hpp"
 
 namespace rrtd {
 
 constexpr int kBlock = 256;
-enum { C_ACTIVE = 0, C_NEXT = 1, C_SHADOW = 2, C_CAMERA_RAYS = 3, C_ERROR = 4, C_WORK_CLOSEST = 5, C_WORK_SHADOW = 6, C_WORK_AUX = 7, C_COUNT = 16 };
+// device counters, one 128-byte line each (atomics on different queues must not share an L2 line)
+enum { C_ACTIVE = 0, C_NEXT = 32, C_SHADOW = 64, C_CAMERA_RAYS = 96, C_ERROR = 128, C_WORK_CLOSEST = 160, C_WORK_SHADOW = 192, C_WORK_AUX = 224, C_COUNT = 256 };
+// shading kernels push to their queues once per block: big blocks where the registers allow (fp32: 118 VGPRs)
+template <typename R> struct ShadeBlock { static constexpr int n = 256; };
+template <> struct ShadeBlock<float> { static constexpr int n = 1024; };
 enum { ERR_SHADING_NORMAL = 1, ERR_STACK = 2, ERR_BETA = 4 };
 
 // ------------------------------------------------------------------------------------------------------------
@@ -20,6 +24,18 @@ struct RayCtx {
   int neg[3];
   R tmax;
 };
+
+// ---- pool records (dtypes.hpp Pools): 4-word loads / stores and raw-bit integers ------------------------------------
+RRT_DEV float bits_to_real(uint32_t u, float) { return __uint_as_float(u); }
+RRT_DEV double bits_to_real(uint32_t u, double) { return __longlong_as_double((long long)u); }
+RRT_DEV uint32_t real_to_bits(float v) { return __float_as_uint(v); }
+RRT_DEV uint32_t real_to_bits(double v) { return (uint32_t)__double_as_longlong(v); }
+template <typename R> RRT_DEV typename Vec4T<R>::type mk4(R x, R y, R z, R w) { typename Vec4T<R>::type v; v.x = x; v.y = y; v.z = z; v.w = w; return v; }
+template <typename R> RRT_DEV typename Vec4T<R>::type mk4u(R x, R y, R z, uint32_t w) { return mk4<R>(x, y, z, bits_to_real(w, R(0))); }
+template <typename R> RRT_DEV void store_ray(typename Vec4T<R>::type* ro, typename Vec4T<R>::type* rd, uint32_t i, V3<R> o, V3<R> d, R tmax, int skip) {
+  ro[i] = mk4<R>(o.x, o.y, o.z, tmax);
+  rd[i] = mk4u<R>(d.x, d.y, d.z, (uint32_t)skip);
+}
 
 // Bounds3::intersect_p geometry.rs:1767-1800 with gamma(3) of the arithmetic type
 template <typename R>
@@ -264,8 +280,8 @@ RRT_DEV bool traverse_any(const SceneDev<R>& s, const RayCtx<R>& r, Stack& st, i
   return found;
 }
 
-// Closest-hit kernel. `queue` maps launch index -> slot (nullptr = identity); `count` is read on device so
-// the host never synchronises between bounces. Optional per-ray counters feed the roofline's byte model.
+// Closest-hit kernel over the rays of the active queue (records in queue order: `queue` itself is not read);
+// `count` is read on device so the host never synchronises between bounces. Optional per-ray counters feed the roofline's byte model.
 template <typename R, bool DEEP, bool COUNT>
 __global__ void __launch_bounds__(kBlock) k_closest(SceneDev<R> s, Pools<R> p, const uint32_t* queue, const uint32_t* count, uint32_t n_fixed,
                                                      uint32_t* deep_stack, uint32_t deep_stride, uint32_t* nodes_out, uint32_t* prims_out,
@@ -273,19 +289,28 @@ __global__ void __launch_bounds__(kBlock) k_closest(SceneDev<R> s, Pools<R> p, c
   const uint32_t i = blockIdx.x * blockDim.x + threadIdx.x;
   const uint32_t n = count ? *count : n_fixed;
   if (i >= n) return;
-  const uint32_t slot = queue ? queue[i] : i;
-  RayCtx<R> r = make_ctx(V3<R>(p.ox[slot], p.oy[slot], p.oz[slot]), V3<R>(p.dx[slot], p.dy[slot], p.dz[slot]), p.tmax[slot]);
+  const typename Vec4T<R>::type ro = p.ray_o[i], rd = p.ray_d[i];
+  RayCtx<R> r = make_ctx(V3<R>(ro.x, ro.y, ro.z), V3<R>(rd.x, rd.y, rd.z), ro.w);
   R hu = 0, hv = 0;
   uint32_t nn = 0, np = 0;
   int hit;
-  const int skip = p.skip[slot];
+  const int skip = (int)real_to_bits(rd.w);
   if (DEEP) { GlobStack st{deep_stack + i, deep_stride}; hit = traverse_closest(s, r, st, skip, &hu, &hv, &nn, &np); }
   else { PrivStack st; hit = traverse_closest(s, r, st, skip, &hu, &hv, &nn, &np); }
-  p.ht[slot] = r.tmax; p.hprim[slot] = hit; p.hu[slot] = hu; p.hv[slot] = hv;
+  p.hit[i] = mk4<R>(r.tmax, bits_to_real((uint32_t)hit, R(0)), hu, hv);
   if (COUNT) {
-    if (nodes_out) { nodes_out[slot] = nn; prims_out[slot] = np; }
+    if (nodes_out) { nodes_out[i] = nn; prims_out[i] = np; }
     if (totals) { atomicAdd(&totals[0], (unsigned long long)nn); atomicAdd(&totals[1], (unsigned long long)np); }
   }
+}
+
+// unoccluded shadow ray: L += Ld (a path owns at most one shadow ray per launch, so the update needs no atomic)
+template <typename R> RRT_DEV void add_pending(const Pools<R>& p, uint32_t i) {
+  const typename Vec4T<R>::type ld = p.sld[i];
+  const uint32_t slot = real_to_bits(ld.w);
+  typename Vec4T<R>::type L = p.L[slot];
+  L.x += ld.x; L.y += ld.y; L.z += ld.z;
+  p.L[slot] = L;
 }
 
 // Any-hit kernel over the shadow queue: VisibilityTester::unoccluded (lights/mod.rs:60-66); unoccluded paths
@@ -295,15 +320,33 @@ __global__ void __launch_bounds__(kBlock) k_shadow(SceneDev<R> s, Pools<R> p, co
                                                     uint32_t* deep_stack, uint32_t deep_stride, unsigned long long* totals) {
   const uint32_t i = blockIdx.x * blockDim.x + threadIdx.x;
   if (i >= *count) return;
-  const uint32_t slot = queue[i];
-  RayCtx<R> r = make_ctx(V3<R>(p.sox[slot], p.soy[slot], p.soz[slot]), V3<R>(p.sdx[slot], p.sdy[slot], p.sdz[slot]), p.stmax[slot]);
+  const typename Vec4T<R>::type ro = p.sray_o[i], rd = p.sray_d[i];
+  RayCtx<R> r = make_ctx(V3<R>(ro.x, ro.y, ro.z), V3<R>(rd.x, rd.y, rd.z), ro.w);
   uint32_t nn = 0, np = 0;
   bool occ;
-  const int skip = p.sskip[slot];
+  const int skip = (int)real_to_bits(rd.w);
   if (DEEP) { GlobStack st{deep_stack + i, deep_stride}; occ = traverse_any(s, r, st, skip, &nn, &np); }
   else { PrivStack st; occ = traverse_any(s, r, st, skip, &nn, &np); }
-  if (!occ) { p.lr[slot] += p.ldr[slot]; p.lg[slot] += p.ldg[slot]; p.lb[slot] += p.ldb[slot]; }
+  if (!occ) add_pending(p, i);
   if (COUNT && totals) { atomicAdd(&totals[0], (unsigned long long)nn); atomicAdd(&totals[1], (unsigned long long)np); }
+}
+
+// Public batches (rrt_rays / rrt_hits are SoA arrays): pack into / unpack from the pool's records.
+template <typename R>
+__global__ void __launch_bounds__(kBlock) k_pack_rays(Pools<R> p, const R* ox, const R* oy, const R* oz, const R* dx, const R* dy, const R* dz, const R* tmax,
+                                                       const int32_t* skip, uint32_t n) {
+  const uint32_t i = blockIdx.x * blockDim.x + threadIdx.x;
+  if (i >= n) return;
+  store_ray<R>(p.ray_o, p.ray_d, i, V3<R>(ox[i], oy[i], oz[i]), V3<R>(dx[i], dy[i], dz[i]), tmax[i], skip ? skip[i] : -1);
+}
+template <typename R>
+__global__ void __launch_bounds__(kBlock) k_unpack_hits(Pools<R> p, R* t, int32_t* prim, R* u, R* v, uint32_t n) {
+  const uint32_t i = blockIdx.x * blockDim.x + threadIdx.x;
+  if (i >= n) return;
+  const typename Vec4T<R>::type h = p.hit[i];
+  t[i] = h.x; prim[i] = (int32_t)real_to_bits(h.y);
+  if (u) u[i] = h.z;
+  if (v) v[i] = h.w;
 }
 
 // Public any-hit on caller rays (rrt_trace_any): rays live in the closest-ray arrays of the pool.
@@ -311,10 +354,11 @@ template <typename R, bool DEEP>
 __global__ void __launch_bounds__(kBlock) k_any_public(SceneDev<R> s, Pools<R> p, uint32_t n, uint8_t* occluded, uint32_t* deep_stack, uint32_t deep_stride) {
   const uint32_t i = blockIdx.x * blockDim.x + threadIdx.x;
   if (i >= n) return;
-  RayCtx<R> r = make_ctx(V3<R>(p.ox[i], p.oy[i], p.oz[i]), V3<R>(p.dx[i], p.dy[i], p.dz[i]), p.tmax[i]);
+  const typename Vec4T<R>::type ro = p.ray_o[i], rd = p.ray_d[i];
+  RayCtx<R> r = make_ctx(V3<R>(ro.x, ro.y, ro.z), V3<R>(rd.x, rd.y, rd.z), ro.w);
   uint32_t nn, np;
   bool occ;
-  const int skip = p.skip[i];
+  const int skip = (int)real_to_bits(rd.w);
   if (DEEP) { GlobStack st{deep_stack + i, deep_stride}; occ = traverse_any(s, r, st, skip, &nn, &np); }
   else { PrivStack st; occ = traverse_any(s, r, st, skip, &nn, &np); }
   occluded[i] = occ ? 1 : 0;
@@ -340,7 +384,8 @@ RRT_DEV void pass_pixel(const PassDesc& pd, uint32_t lin, uint32_t* px, uint32_t
 
 // Stage 1 (every slot): Halton index + dims 0..3, film point, lens sample, and the *main* lens trace
 // (generate_ray, camera.rs:534-580). About 70 % of the samples die here (lens samples are drawn in [0.5,1.5)^2,
-// Q5); the survivors are compacted into q_next so that stage 2 runs with full lanes.
+// Q5); the survivors are compacted into q_next so that stage 2 runs with full lanes. The main ray waits in the
+// next-ray arrays *by slot* until stage 2 knows whether the sample lives.
 template <typename R>
 __global__ void __launch_bounds__(kBlock) k_raygen(SceneDev<R> s, Pools<R> p, PassDesc pd, double* dbg_dims) {
   const uint32_t slot = blockIdx.x * blockDim.x + threadIdx.x;
@@ -359,41 +404,37 @@ __global__ void __launch_bounds__(kBlock) k_raygen(SceneDev<R> s, Pools<R> p, Pa
     RayT<R> ray;
     const R w = generate_ray(s, pfx, pfy, lx, ly, &ray);
     alive = w != R(0);
-    p.pixel[slot] = py * (uint32_t)s.xres + px;
     p.hindex[slot] = index;
-    p.dim_bounce[slot] = 5u;
     p.weight[slot] = alive ? w : R(0);
     p.pfx[slot] = pfx; p.pfy[slot] = pfy;
-    p.lr[slot] = R(0); p.lg[slot] = R(0); p.lb[slot] = R(0);
-    p.br[slot] = R(1); p.bg[slot] = R(1); p.bb[slot] = R(1);
     if (alive) {
-      p.ox[slot] = ray.o.x; p.oy[slot] = ray.o.y; p.oz[slot] = ray.o.z;
-      p.dx[slot] = ray.d.x; p.dy[slot] = ray.d.y; p.dz[slot] = ray.d.z;
-      p.tmax[slot] = Const<R>::inf;
-      p.skip[slot] = -1;
-      p.sox[slot] = lx; p.soy[slot] = ly;   // lens sample parked in the (idle) shadow-ray arrays for stage 2
+      store_ray<R>(p.nray_o, p.nray_d, slot, ray.o, ray.d, Const<R>::inf, -1);
+      p.lensx[slot] = lx; p.lensy[slot] = ly;
     }
     if (dbg_dims) {
       double* dd = dbg_dims + 5 * (size_t)(pl * pd.ns + sl);   // [pixel][sample]
       dd[0] = d0; dd[1] = d1; dd[2] = d2; dd[3] = d3; dd[4] = halton_dim(s, index, 4);
     }
   }
-  const uint32_t q = wave_push(&p.counters[C_NEXT], alive);
-  if (alive) p.q_next[q] = slot;
+  __shared__ uint32_t push_lds[kBlock / 64 + 1];
+  const uint32_t q = block_push(&p.counters[C_NEXT], alive, push_lds);
+  if (alive) p.q_next[q] = QEnt{slot, 0u};
 }
 
 // Stage 2 (survivors): the auxiliary rays of generate_ray_differential (camera.rs:582-628) at p_film +- 0.05 px in
 // x then y. Only whether they make it through the lens is observable (the differentials feed texture filtering,
-// and only constant textures are in scope): a sample whose x or y pair both fail gets weight 0.
+// and only constant textures are in scope): a sample whose x or y pair both fail gets weight 0. Living samples
+// enter q_active with their ray at the same position. `enqueue` = 0 for AOIntegrator, whose li returns 0 before
+// drawing anything (ao.rs:62-64).
 template <typename R>
-__global__ void __launch_bounds__(kBlock) k_raygen_aux(SceneDev<R> s, Pools<R> p) {
+__global__ void __launch_bounds__(kBlock) k_raygen_aux(SceneDev<R> s, Pools<R> p, int enqueue) {
   const uint32_t i = blockIdx.x * blockDim.x + threadIdx.x;
   const uint32_t n = p.counters[C_NEXT];
   bool alive = false;
   uint32_t slot = 0;
   if (i < n) {
-    slot = p.q_next[i];
-    const R pfx = p.pfx[slot], pfy = p.pfy[slot], lx = p.sox[slot], ly = p.soy[slot];
+    slot = p.q_next[i].slot;
+    const R pfx = p.pfx[slot], pfy = p.pfy[slot], lx = p.lensx[slot], ly = p.lensy[slot];
     RayT<R> aux;
     R wtx = generate_ray(s, pfx + R(0.05), pfy, lx, ly, &aux);
     if (wtx == R(0)) wtx = generate_ray(s, pfx + R(-0.05), pfy, lx, ly, &aux);
@@ -405,24 +446,35 @@ __global__ void __launch_bounds__(kBlock) k_raygen_aux(SceneDev<R> s, Pools<R> p
     alive = wtx != R(0) && wty != R(0) && p.weight[slot] > R(0);   // `if ray_weight > 0.0` integrator/mod.rs:100
     if (!(wtx != R(0) && wty != R(0))) p.weight[slot] = R(0);
   }
-  const bool enqueue = alive && s.integrator != 3;  // AOIntegrator::li returns 0 before drawing (ao.rs:62-64)
-  const uint32_t q = wave_push(&p.counters[C_ACTIVE], enqueue);
-  if (enqueue) p.q_active[q] = slot;
-  (void)wave_push(&p.counters[C_CAMERA_RAYS], alive);
+  __shared__ uint32_t push_lds[kBlock / 64 + 1];
+  const bool enq = alive && enqueue;
+  const uint32_t q = block_push(&p.counters[C_ACTIVE], enq, push_lds);
+  if (enq) {
+    p.q_active[q] = QEnt{slot, 5u};   // five camera dimensions consumed, bounce 0
+    p.path[q] = mk4u<R>(R(1), R(1), R(1), p.hindex[slot]);
+    p.ray_o[q] = p.nray_o[slot]; p.ray_d[q] = p.nray_d[slot];
+  }
+  if (alive) p.L[slot] = mk4<R>(R(0), R(0), R(0), R(0));
+  (void)block_push(&p.counters[C_CAMERA_RAYS], alive, push_lds);
 }
 
-// debug / unit-test surface of rrt_camera_samples: rays + weights of a pass, [pixel][sample] order
+// debug / unit-test surface of rrt_camera_samples: rays + weights of a pass, [pixel][sample] order (dbg_ray zeroed
+// by the host: dead samples report a zero ray)
 template <typename R>
 __global__ void __launch_bounds__(kBlock) k_camera_dump(Pools<R> p, PassDesc pd, double* dbg_ray, double* dbg_w) {
-  const uint32_t slot = blockIdx.x * blockDim.x + threadIdx.x;
-  if (slot >= pd.npix * pd.ns) return;
-  const uint32_t pl = slot % pd.npix, sl = slot / pd.npix;
-  const double w = (double)p.weight[slot];
-  const bool alive = w > 0.0;
-  double* rr = dbg_ray + 6 * (size_t)(pl * pd.ns + sl);
-  rr[0] = alive ? (double)p.ox[slot] : 0.0; rr[1] = alive ? (double)p.oy[slot] : 0.0; rr[2] = alive ? (double)p.oz[slot] : 0.0;
-  rr[3] = alive ? (double)p.dx[slot] : 0.0; rr[4] = alive ? (double)p.dy[slot] : 0.0; rr[5] = alive ? (double)p.dz[slot] : 0.0;
-  dbg_w[pl * pd.ns + sl] = w;
+  const uint32_t t = blockIdx.x * blockDim.x + threadIdx.x;
+  if (t < pd.npix * pd.ns) {
+    const uint32_t pl = t % pd.npix, sl = t / pd.npix;
+    dbg_w[pl * pd.ns + sl] = (double)p.weight[t];
+  }
+  if (t < p.counters[C_ACTIVE]) {
+    const uint32_t slot = p.q_active[t].slot;
+    const uint32_t pl = slot % pd.npix, sl = slot / pd.npix;
+    const typename Vec4T<R>::type ro = p.ray_o[t], rd = p.ray_d[t];
+    double* rr = dbg_ray + 6 * (size_t)(pl * pd.ns + sl);
+    rr[0] = (double)ro.x; rr[1] = (double)ro.y; rr[2] = (double)ro.z;
+    rr[3] = (double)rd.x; rr[4] = (double)rd.y; rr[5] = (double)rd.z;
+  }
 }
 
 // ------------------------------------------------------------------------------------------------------------
@@ -625,37 +677,39 @@ RRT_DEV uint32_t sample_light_discrete(const SceneDev<R>& s, R u) {
   return off;
 }
 
-template <typename R>
-RRT_DEV void store_shadow(Pools<R>& p, uint32_t slot, V3<R> so, V3<R> sd, Rgb<R> ld, int prim) {
-  p.sskip[slot] = self_prim<R>(prim);
-  p.sox[slot] = so.x; p.soy[slot] = so.y; p.soz[slot] = so.z;
-  p.sdx[slot] = sd.x; p.sdy[slot] = sd.y; p.sdz[slot] = sd.z;
-  p.stmax[slot] = R(1) - R(0.0001);
-  p.ldr[slot] = ld.r; p.ldg[slot] = ld.g; p.ldb[slot] = ld.b;
-}
-
 // PathIntegrator::li loop body (path.rs:74-223) for one bounce of every active path.
 template <typename R>
-__global__ void __launch_bounds__(kBlock) k_shade_path(SceneDev<R> s, Pools<R> p) {
+__global__ void __launch_bounds__(ShadeBlock<R>::n) k_shade_path(SceneDev<R> s, Pools<R> p) {
+  __shared__ uint32_t push_lds[ShadeBlock<R>::n / 64 + 1];
   const uint32_t i = blockIdx.x * blockDim.x + threadIdx.x;
   const uint32_t n = p.counters[C_ACTIVE];
+  if (blockIdx.x * blockDim.x >= n) return;   // whole block past the queue end (the grid is sized for the worst case)
+  using V4 = typename Vec4T<R>::type;
   bool want_shadow = false, want_next = false;
   uint32_t slot = 0;
+  int prim = -1;
+  V3<R> sh_o, sh_d, nx_o, nx_d;   // shadow ray / next ray + path state, stored at their queue positions at the end
+  Rgb<R> sh_ld, nx_beta;
+  uint32_t index = 0, nx_db = 0;
   if (i < n) {
-    slot = p.q_active[i];
-    const int prim = p.hprim[slot];
-    uint32_t db = p.dim_bounce[slot];
+    const QEnt qe = p.q_active[i];
+    slot = qe.slot;
+    const V4 h = p.hit[i];
+    prim = (int)real_to_bits(h.y);
+    const uint32_t db = qe.db;
     uint32_t dim = db & 0xffffu, bounces = db >> 16;
     // `if !found_intersection || bounces >= max_depth { break }` (:91); emitted light is 0 (Q18)
     if (prim >= 0 && (int)bounces < s.max_depth) {
-      V3<R> o(p.ox[slot], p.oy[slot], p.oz[slot]), d(p.dx[slot], p.dy[slot], p.dz[slot]);
-      Surf<R> si = build_surface(s, prim, o, d, p.ht[slot], p.hu[slot], p.hv[slot]);
+      const V4 ro = p.ray_o[i], rd = p.ray_d[i];
+      V3<R> o(ro.x, ro.y, ro.z), d(rd.x, rd.y, rd.z);
+      Surf<R> si = build_surface(s, prim, o, d, h.x, h.z, h.w);
       if (!si.ok) { atomicOr(&p.counters[C_ERROR], (uint32_t)ERR_SHADING_NORMAL); }
       else {
         Bsdf<R> bsdf;
         build_bsdf(s, si, &bsdf);
-        const uint32_t index = p.hindex[slot];
-        Rgb<R> beta(p.br[slot], p.bg[slot], p.bb[slot]);
+        const V4 st_b = p.path[i];
+        index = real_to_bits(st_b.w);
+        Rgb<R> beta(st_b.x, st_b.y, st_b.z);
         // uniform_sample_one_light integrator/mod.rs:359-401 with the uniform Distribution1D (path.rs:47-49)
         if (bsdf.num_components(BXDF_ALL & ~BXDF_SPECULAR) > 0 && s.n_lights > 0) {
           R u_pick = to_real<R>(halton_dim(s, index, dim));
@@ -665,8 +719,8 @@ __global__ void __launch_bounds__(kBlock) k_shade_path(SceneDev<R> s, Pools<R> p
           V3<R> so, sd;
           Rgb<R> ld;
           if (s.light_pick_pdf != R(0) && estimate_direct_light(si, bsdf, s.lights[ln], ul0, ul1, &so, &sd, &ld)) {
-            ld = beta * (ld / s.light_pick_pdf);
-            store_shadow(p, slot, so, sd, ld, prim);
+            sh_ld = beta * (ld / s.light_pick_pdf);
+            sh_o = so; sh_d = sd;
             want_shadow = true;
           }
         }
@@ -694,48 +748,65 @@ __global__ void __launch_bounds__(kBlock) k_shade_path(SceneDev<R> s, Pools<R> p
           // the next loop iteration would trace and then break on `bounces >= max_depth` without using the
           // hit (emission is 0): that dead closest-hit query is not issued.
           if (cont && (int)bounces < s.max_depth) {
-            p.ox[slot] = si.p.x; p.oy[slot] = si.p.y; p.oz[slot] = si.p.z;
-            p.dx[slot] = nd.x; p.dy[slot] = nd.y; p.dz[slot] = nd.z;
-            p.tmax[slot] = Const<R>::inf;
-            p.skip[slot] = self_prim<R>(prim);
-            p.br[slot] = beta.r; p.bg[slot] = beta.g; p.bb[slot] = beta.b;
-            p.dim_bounce[slot] = (dim & 0xffffu) | (bounces << 16);
+            nx_o = si.p; nx_d = nd;
+            nx_beta = beta;
+            nx_db = (dim & 0xffffu) | (bounces << 16);
             want_next = true;
           }
         }
       }
     }
   }
-  const uint32_t qs = wave_push(&p.counters[C_SHADOW], want_shadow);
-  if (want_shadow) p.q_shadow[qs] = slot;
-  const uint32_t qn = wave_push(&p.counters[C_NEXT], want_next);
-  if (want_next) p.q_next[qn] = slot;
+  const uint32_t qs = block_push(&p.counters[C_SHADOW], want_shadow, push_lds);
+  if (want_shadow) {
+    store_ray<R>(p.sray_o, p.sray_d, qs, sh_o, sh_d, R(1) - R(0.0001), self_prim<R>(prim));
+    p.sld[qs] = mk4u<R>(sh_ld.r, sh_ld.g, sh_ld.b, slot);
+  }
+  const uint32_t qn = block_push(&p.counters[C_NEXT], want_next, push_lds);
+  if (want_next) {
+    p.q_next[qn] = QEnt{slot, nx_db};
+    p.npath[qn] = mk4u<R>(nx_beta.r, nx_beta.g, nx_beta.b, index);
+    store_ray<R>(p.nray_o, p.nray_d, qn, nx_o, nx_d, Const<R>::inf, self_prim<R>(prim));
+  }
 }
 
 // DirectLighting / Debug integrators (directlighting.rs:72-132, intersect_debug.rs:56-89) as a wavefront chain:
 // one NEE launch per light (strategy all) or one (strategy one), then the specular continuation.
 // mode: light_j >= 0 -> uniform_sample_all_lights' j-th term; light_j == -1 -> uniform_sample_one_light(None).
 template <typename R>
-__global__ void __launch_bounds__(kBlock) k_shade_nee(SceneDev<R> s, Pools<R> p, int light_j, int first) {
+__global__ void __launch_bounds__(ShadeBlock<R>::n) k_shade_nee(SceneDev<R> s, Pools<R> p, int light_j, int first) {
+  __shared__ uint32_t push_lds[ShadeBlock<R>::n / 64 + 1];
+  using V4 = typename Vec4T<R>::type;
   const uint32_t i = blockIdx.x * blockDim.x + threadIdx.x;
   const uint32_t n = p.counters[C_ACTIVE];
+  if (blockIdx.x * blockDim.x >= n) return;   // whole block past the queue end (the grid is sized for the worst case)
   bool want_shadow = false;
   uint32_t slot = 0;
+  int prim = -1;
+  V3<R> sh_o, sh_d;
+  Rgb<R> sh_ld;
   if (i < n) {
-    slot = p.q_active[i];
-    const int prim = p.hprim[slot];
+    const QEnt qe = p.q_active[i];
+    slot = qe.slot;
+    const V4 h = p.hit[i];
+    prim = (int)real_to_bits(h.y);
     if (prim >= 0) {
-      V3<R> o(p.ox[slot], p.oy[slot], p.oz[slot]), d(p.dx[slot], p.dy[slot], p.dz[slot]);
-      Surf<R> si = build_surface(s, prim, o, d, p.ht[slot], p.hu[slot], p.hv[slot]);
+      const V4 ro = p.ray_o[i], rd = p.ray_d[i];
+      V3<R> o(ro.x, ro.y, ro.z), d(rd.x, rd.y, rd.z);
+      Surf<R> si = build_surface(s, prim, o, d, h.x, h.z, h.w);
       if (!si.ok) atomicOr(&p.counters[C_ERROR], (uint32_t)ERR_SHADING_NORMAL);
       else {
         Bsdf<R> bsdf;
         build_bsdf(s, si, &bsdf);
-        uint32_t db = p.dim_bounce[slot], dim = db & 0xffffu;
-        const uint32_t index = p.hindex[slot];
-        Rgb<R> beta(p.br[slot], p.bg[slot], p.bb[slot]);
+        const uint32_t db = qe.db;
+        uint32_t dim = db & 0xffffu;
+        const V4 st_b = p.path[i];
+        const uint32_t index = real_to_bits(st_b.w);
+        Rgb<R> beta(st_b.x, st_b.y, st_b.z);
         if (first && s.integrator == 2) {  // Debug: l = Spectrum(0.1) on a hit (intersect_debug.rs:66-70)
-          p.lr[slot] += beta.r * R(0.1); p.lg[slot] += beta.g * R(0.1); p.lb[slot] += beta.b * R(0.1);
+          V4 l = p.L[slot];
+          l.x += beta.r * R(0.1); l.y += beta.g * R(0.1); l.z += beta.b * R(0.1);
+          p.L[slot] = l;
         }
         uint32_t ln;
         R pick_pdf = R(1);
@@ -753,43 +824,61 @@ __global__ void __launch_bounds__(kBlock) k_shade_nee(SceneDev<R> s, Pools<R> p,
         V3<R> so, sd;
         Rgb<R> ld;
         if (estimate_direct_light(si, bsdf, s.lights[ln], ul0, ul1, &so, &sd, &ld)) {
-          ld = beta * (ld / pick_pdf);
-          store_shadow(p, slot, so, sd, ld, prim);
+          sh_ld = beta * (ld / pick_pdf);
+          sh_o = so; sh_d = sd;
           want_shadow = true;
         }
-        p.dim_bounce[slot] = (dim & 0xffffu) | (db & 0xffff0000u);
+        p.q_active[i].db = (dim & 0xffffu) | (db & 0xffff0000u);
       }
     }
   }
-  const uint32_t qs = wave_push(&p.counters[C_SHADOW], want_shadow);
-  if (want_shadow) p.q_shadow[qs] = slot;
+  const uint32_t qs = block_push(&p.counters[C_SHADOW], want_shadow, push_lds);
+  if (want_shadow) {
+    store_ray<R>(p.sray_o, p.sray_d, qs, sh_o, sh_d, R(1) - R(0.0001), self_prim<R>(prim));
+    p.sld[qs] = mk4u<R>(sh_ld.r, sh_ld.g, sh_ld.b, slot);
+  }
 }
 
 // specular_reflect (integrator/mod.rs:150-198) as the chain's continuation; specular_transmit (:199-301) finds
 // no transmissive lobe among the in-scope materials and its 2D draw lands after the recursion returns.
 // `depth` of the reference starts at 1; the high half of dim_bounce stores depth - 1.
 template <typename R>
-__global__ void __launch_bounds__(kBlock) k_shade_specular(SceneDev<R> s, Pools<R> p, int grey_only) {
+__global__ void __launch_bounds__(ShadeBlock<R>::n) k_shade_specular(SceneDev<R> s, Pools<R> p, int grey_only) {
+  __shared__ uint32_t push_lds[ShadeBlock<R>::n / 64 + 1];
+  using V4 = typename Vec4T<R>::type;
   const uint32_t i = blockIdx.x * blockDim.x + threadIdx.x;
   const uint32_t n = p.counters[C_ACTIVE];
+  if (blockIdx.x * blockDim.x >= n) return;   // whole block past the queue end (the grid is sized for the worst case)
   bool want_next = false;
   uint32_t slot = 0;
+  int prim = -1;
+  V3<R> nx_o, nx_d;
+  Rgb<R> nx_beta;
+  uint32_t index = 0, nx_db = 0;
   if (i < n) {
-    slot = p.q_active[i];
-    const int prim = p.hprim[slot];
+    const QEnt qe = p.q_active[i];
+    slot = qe.slot;
+    const V4 h = p.hit[i];
+    prim = (int)real_to_bits(h.y);
     if (prim >= 0) {
-      uint32_t db = p.dim_bounce[slot], dim = db & 0xffffu, depth = (db >> 16) + 1;
+      const V4 st_b = p.path[i];
+      const uint32_t db = qe.db;
+      uint32_t dim = db & 0xffffu;
+      const uint32_t depth = (db >> 16) + 1;
+      Rgb<R> beta(st_b.x, st_b.y, st_b.z);
+      index = real_to_bits(st_b.w);
       if (grey_only) {  // Debug with no lights still adds the 0.1 grey
-        Rgb<R> beta(p.br[slot], p.bg[slot], p.bb[slot]);
-        p.lr[slot] += beta.r * R(0.1); p.lg[slot] += beta.g * R(0.1); p.lb[slot] += beta.b * R(0.1);
+        V4 l = p.L[slot];
+        l.x += beta.r * R(0.1); l.y += beta.g * R(0.1); l.z += beta.b * R(0.1);
+        p.L[slot] = l;
       }
       if ((int)(depth + 1) < s.max_depth) {
-        V3<R> o(p.ox[slot], p.oy[slot], p.oz[slot]), d(p.dx[slot], p.dy[slot], p.dz[slot]);
-        Surf<R> si = build_surface(s, prim, o, d, p.ht[slot], p.hu[slot], p.hv[slot]);
+        const V4 ro = p.ray_o[i], rd = p.ray_d[i];
+        V3<R> o(ro.x, ro.y, ro.z), d(rd.x, rd.y, rd.z);
+        Surf<R> si = build_surface(s, prim, o, d, h.x, h.z, h.w);
         if (si.ok) {
           Bsdf<R> bsdf;
           build_bsdf(s, si, &bsdf);
-          const uint32_t index = p.hindex[slot];
           R u0 = to_real<R>(halton_dim(s, index, dim)), u1 = to_real<R>(halton_dim(s, index, dim + 1));
           dim += 2;
           V3<R> wi;
@@ -797,23 +886,21 @@ __global__ void __launch_bounds__(kBlock) k_shade_specular(SceneDev<R> s, Pools<
           uint32_t st = 0;
           Rgb<R> f = bsdf.sample_f(si.wo, &wi, u0, u1, &pdf, BXDF_SPECULAR | BXDF_REFLECTION, &st);
           if (pdf > R(0) && !f.is_black() && absdot(wi, si.sn) != R(0)) {
-            Rgb<R> beta(p.br[slot], p.bg[slot], p.bb[slot]);
-            beta = beta * (f * absdot(wi, si.sn) / pdf);
-            V3<R> nd = vnormalize(wi);
-            p.ox[slot] = si.p.x; p.oy[slot] = si.p.y; p.oz[slot] = si.p.z;
-            p.dx[slot] = nd.x; p.dy[slot] = nd.y; p.dz[slot] = nd.z;
-            p.tmax[slot] = Const<R>::inf;
-            p.skip[slot] = self_prim<R>(prim);
-            p.br[slot] = beta.r; p.bg[slot] = beta.g; p.bb[slot] = beta.b;
-            p.dim_bounce[slot] = (dim & 0xffffu) | (depth << 16);
+            nx_beta = beta * (f * absdot(wi, si.sn) / pdf);
+            nx_o = si.p; nx_d = vnormalize(wi);
+            nx_db = (dim & 0xffffu) | (depth << 16);
             want_next = true;
           }
         }
       }
     }
   }
-  const uint32_t qn = wave_push(&p.counters[C_NEXT], want_next);
-  if (want_next) p.q_next[qn] = slot;
+  const uint32_t qn = block_push(&p.counters[C_NEXT], want_next, push_lds);
+  if (want_next) {
+    p.q_next[qn] = QEnt{slot, nx_db};
+    p.npath[qn] = mk4u<R>(nx_beta.r, nx_beta.g, nx_beta.b, index);
+    store_ray<R>(p.nray_o, p.nray_d, qn, nx_o, nx_d, Const<R>::inf, self_prim<R>(prim));
+  }
 }
 
 // queue rotation between bounces: active <- next, next <- 0, shadow <- 0 (single thread)
@@ -842,17 +929,19 @@ __global__ void __launch_bounds__(kBlock) k_film_box(SceneDev<R> s, Pools<R> p, 
   const uint32_t pl = blockIdx.x * blockDim.x + threadIdx.x;
   if (pl >= pd.npix) return;
   R cr = R(0), cg = R(0), cb = R(0), wsum = R(0);
-  uint32_t pix = 0;
+  uint32_t px_, py_;
+  pass_pixel(pd, pd.pix_begin + pl, &px_, &py_);
+  const uint32_t pix = py_ * (uint32_t)s.xres + px_;
   for (uint32_t sl = 0; sl < pd.ns; sl++) {
     const uint32_t slot = sl * pd.npix + pl;
-    pix = p.pixel[slot];
-    Rgb<R> L(p.lr[slot], p.lg[slot], p.lb[slot]);
+    const R w = p.weight[slot];
+    Rgb<R> L;
+    if (w > R(0)) { const typename Vec4T<R>::type l = p.L[slot]; L = Rgb<R>(l.x, l.y, l.z); }   // dead samples: L = 0, w = 0 (Q2)
     // integrator/mod.rs:105-122
     if (L.has_nan()) L = Rgb<R>();
     else if (L.y() < R(-1e-5)) L = Rgb<R>();
     else if (isinf(L.y())) L = Rgb<R>();
     if (L.y() > s.max_sample_luminance) L = L * (s.max_sample_luminance / L.y());
-    const R w = p.weight[slot];
     cr += (L.r * w) * R(1); cg += (L.g * w) * R(1); cb += (L.b * w) * R(1);  // box filter table weight 1
     wsum += R(1);
   }

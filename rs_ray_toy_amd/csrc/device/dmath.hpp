@@ -123,6 +123,25 @@ RRT_DEV uint32_t wave_push(uint32_t* counter, bool pred) {
   return base + prefix;
 }
 
+// Block-wide queue push: one atomic per BLOCK. All atomics on a queue counter serialise on one L2 line (~7-12 ns
+// each on MI355X): with a per-wave atomic the first-bounce shading kernel (1.3 M waves, two queues) spent its
+// whole 18 ms there. `lds` = (waves per block + 1) words. Must be reached by every thread of the block.
+RRT_DEV uint32_t block_push(uint32_t* counter, bool pred, uint32_t* lds) {
+  const uint64_t mask = __ballot(pred);
+  const uint32_t lane = __lane_id(), w = threadIdx.x >> 6, nw = (blockDim.x + 63u) >> 6;
+  if (lane == 0) lds[w] = (uint32_t)__popcll(mask);
+  __syncthreads();
+  if (threadIdx.x == 0) {
+    uint32_t tot = 0;
+    for (uint32_t k = 0; k < nw; k++) { const uint32_t c = lds[k]; lds[k] = tot; tot += c; }
+    lds[nw] = tot ? atomicAdd(counter, tot) : 0u;
+  }
+  __syncthreads();
+  const uint32_t base = lds[nw] + lds[w];
+  __syncthreads();   // lds is reused by the next push
+  return base + (uint32_t)__popcll(mask & ((1ull << lane) - 1ull));
+}
+
 // ---- Halton (samplers/halton.rs, lowdiscrepancy.rs); values are produced in f64 in both modes ---------
 RRT_DEV uint32_t div_base(uint32_t a, const HaltonDim& hd, uint32_t fast) {
   if (fast) return (uint32_t)(((uint64_t)a * hd.magic) >> 40);

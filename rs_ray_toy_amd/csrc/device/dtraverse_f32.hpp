@@ -120,15 +120,11 @@ __global__ void __launch_bounds__(kTravBlock) k_trace_pairs_f32(TravScene ts, Po
   const uint32_t n = count ? *count : n_fixed;
   const uint32_t col = blockIdx.x * kTravBlock + tid;   // overflow-stack column of this resident thread
   for (uint32_t gid = col; gid < n; gid += gridDim.x * kTravBlock) {
-  const uint32_t slot = queue ? queue[gid] : gid;
   LaneRay r;
   int sk;
-  if (ANY && !occluded) {
-    r.ox = p.sox[slot]; r.oy = p.soy[slot]; r.oz = p.soz[slot]; r.dx = p.sdx[slot]; r.dy = p.sdy[slot]; r.dz = p.sdz[slot];
-    r.tmax = p.stmax[slot]; sk = p.sskip[slot];
-  } else {
-    r.ox = p.ox[slot]; r.oy = p.oy[slot]; r.oz = p.oz[slot]; r.dx = p.dx[slot]; r.dy = p.dy[slot]; r.dz = p.dz[slot];
-    r.tmax = p.tmax[slot]; sk = p.skip[slot];
+  {
+    const float4 ro = (ANY && !occluded) ? p.sray_o[gid] : p.ray_o[gid], rd = (ANY && !occluded) ? p.sray_d[gid] : p.ray_d[gid];
+    r.ox = ro.x; r.oy = ro.y; r.oz = ro.z; r.tmax = ro.w; r.dx = rd.x; r.dy = rd.y; r.dz = rd.z; sk = (int)__float_as_uint(rd.w);
   }
   r.skip_plane = sk >= 0 ? __float_as_uint(ts.tris[(size_t)sk * 12 + 11]) : 0xffffffffu;
   r.ix = 1.0f / r.dx; r.iy = 1.0f / r.dy; r.iz = 1.0f / r.dz;
@@ -215,9 +211,9 @@ __global__ void __launch_bounds__(kTravBlock) k_trace_pairs_f32(TravScene ts, Po
   }
   if (ANY) {
     if (occluded) occluded[gid] = found ? 1 : 0;
-    else if (!found) { p.lr[slot] += p.ldr[slot]; p.lg[slot] += p.ldg[slot]; p.lb[slot] += p.ldb[slot]; }
+    else if (!found) add_pending(p, gid);
   } else {
-    p.ht[slot] = r.tmax; p.hprim[slot] = hit; p.hu[slot] = hu; p.hv[slot] = hv;
+    p.hit[gid] = make_float4(r.tmax, __uint_as_float((uint32_t)hit), hu, hv);
   }
   }  // grid-stride loop over rays
 }
@@ -251,7 +247,7 @@ __global__ void __launch_bounds__(kPtBlock) k_trace_pt_f32(TravScene ts, Pools<f
   int state = ST_IDLE;
   LaneRay r;
   r.ox = r.oy = r.oz = r.dx = r.dy = r.dz = r.ix = r.iy = r.iz = r.tmax = 0.0f; r.neg = 0; r.skip_plane = 0xffffffffu;
-  uint32_t slot = 0, qidx = 0, cur = 0, sp = 0, lf = 0, ln = 0;
+  uint32_t qidx = 0, cur = 0, sp = 0, lf = 0, ln = 0;
   int hit = -1;
   float hu = 0.0f, hv = 0.0f;
   bool found = false;
@@ -272,9 +268,9 @@ __global__ void __launch_bounds__(kPtBlock) k_trace_pt_f32(TravScene ts, Pools<f
   auto finish = [&]() {
     if (ANY) {
       if (occluded) occluded[qidx] = found ? 1 : 0;
-      else if (!found) { p.lr[slot] += p.ldr[slot]; p.lg[slot] += p.ldg[slot]; p.lb[slot] += p.ldb[slot]; }
+      else if (!found) add_pending(p, qidx);
     } else {
-      p.ht[slot] = r.tmax; p.hprim[slot] = hit; p.hu[slot] = hu; p.hv[slot] = hv;
+      p.hit[qidx] = make_float4(r.tmax, __uint_as_float((uint32_t)hit), hu, hv);
     }
     state = ST_IDLE;
   };
@@ -309,14 +305,10 @@ __global__ void __launch_bounds__(kPtBlock) k_trace_pt_f32(TravScene ts, Pools<f
         const uint32_t rank = (uint32_t)__popcll(idle & ((1ull << lane) - 1ull));
         if (state == ST_IDLE && rank < take) {
           qidx = lo + rank;
-          slot = queue ? queue[qidx] : qidx;
           int sk;
-          if (ANY && !occluded) {
-            r.ox = p.sox[slot]; r.oy = p.soy[slot]; r.oz = p.soz[slot]; r.dx = p.sdx[slot]; r.dy = p.sdy[slot]; r.dz = p.sdz[slot];
-            r.tmax = p.stmax[slot]; sk = p.sskip[slot];
-          } else {
-            r.ox = p.ox[slot]; r.oy = p.oy[slot]; r.oz = p.oz[slot]; r.dx = p.dx[slot]; r.dy = p.dy[slot]; r.dz = p.dz[slot];
-            r.tmax = p.tmax[slot]; sk = p.skip[slot];
+          {
+            const float4 ro = (ANY && !occluded) ? p.sray_o[qidx] : p.ray_o[qidx], rd = (ANY && !occluded) ? p.sray_d[qidx] : p.ray_d[qidx];
+            r.ox = ro.x; r.oy = ro.y; r.oz = ro.z; r.tmax = ro.w; r.dx = rd.x; r.dy = rd.y; r.dz = rd.z; sk = (int)__float_as_uint(rd.w);
           }
           r.skip_plane = sk >= 0 ? __float_as_uint(ts.tris[(size_t)sk * 12 + 11]) : 0xffffffffu;
           r.ix = 1.0f / r.dx; r.iy = 1.0f / r.dy; r.iz = 1.0f / r.dz;
@@ -446,8 +438,7 @@ RRT_DEV bool rg_step(const float4* lens_s, RgLane* L) {
 
 // Stage 1, dense (one thread per slot, every lane busy): get_camerasample (samplers/mod.rs:28-34) = Halton index and
 // the four film / lens dimensions, plus the initial path state. All stores are coalesced in slot order, which is why
-// the state of dead samples is written too: 14 streamed words per slot cost less than scattered stores for the 31 %
-// that survive. `dims_out` (optional): the five sampler dimensions per slot, [pixel][sample] order (rrt_camera_samples)
+// the sample of every slot is written: 6 streamed words per slot. `dims_out` (optional): the five sampler dimensions per slot, [pixel][sample] order (rrt_camera_samples)
 static __global__ void __launch_bounds__(kBlock) k_sample_f32(SceneDev<float> s, Pools<float> p, PassDesc pd, double* dims_out) {
   const uint32_t slot = blockIdx.x * blockDim.x + threadIdx.x;
   if (slot >= pd.npix * pd.ns) return;
@@ -457,12 +448,8 @@ static __global__ void __launch_bounds__(kBlock) k_sample_f32(SceneDev<float> s,
   const uint32_t index = halton_pixel_offset(s, px, py) + (pd.s_begin + sl) * s.stride;
   const double d0 = halton_dim(s, index, 0), d1 = halton_dim(s, index, 1), d2 = halton_cam_dim(s, index, 0), d3 = halton_cam_dim(s, index, 1);
   p.pfx[slot] = (float)px + to_real<float>(d0); p.pfy[slot] = (float)py + to_real<float>(d1);
-  p.sox[slot] = to_real<float>(d2) + 0.5f; p.soy[slot] = to_real<float>(d3) + 0.5f;   // p_lens (Q5), parked in the shadow-ray arrays
-  p.pixel[slot] = py * (uint32_t)s.xres + px;
+  p.lensx[slot] = to_real<float>(d2) + 0.5f; p.lensy[slot] = to_real<float>(d3) + 0.5f;   // p_lens (Q5)
   p.hindex[slot] = index;
-  p.dim_bounce[slot] = 5u;
-  p.lr[slot] = 0.0f; p.lg[slot] = 0.0f; p.lb[slot] = 0.0f;
-  p.br[slot] = 1.0f; p.bg[slot] = 1.0f; p.bb[slot] = 1.0f;
   p.weight[slot] = 0.0f;
   if (dims_out) { double* dd = dims_out + 5 * (size_t)(pl * pd.ns + sl); dd[0] = d0; dd[1] = d1; dd[2] = d2; dd[3] = d3; dd[4] = halton_dim(s, index, 4); }
 }
@@ -502,7 +489,7 @@ static __global__ void __launch_bounds__(kRgBlock) k_raygen_pt_f32(SceneDev<floa
         const uint32_t rank = (uint32_t)__popcll(idle & ((1ull << lane) - 1ull));
         if (!busy && rank < take) {
           slot = lo + rank;
-          pfx = p.pfx[slot]; pfy = p.pfy[slot]; lx = p.sox[slot]; ly = p.soy[slot];
+          pfx = p.pfx[slot]; pfy = p.pfy[slot]; lx = p.lensx[slot]; ly = p.lensy[slot];
           L.phase = 0;
           busy = true; begin = true;
         }
@@ -532,10 +519,7 @@ static __global__ void __launch_bounds__(kRgBlock) k_raygen_pt_f32(SceneDev<floa
             const RayT<float> rc = flip_z(rl);
             const V3<float> wo = aff_pt(s.cam_m, rc.o);
             const V3<float> wd = vnormalize(vnormalize(vnormalize(aff_vec(s.cam_m, rc.d))));
-            p.ox[slot] = wo.x; p.oy[slot] = wo.y; p.oz[slot] = wo.z;
-            p.dx[slot] = wd.x; p.dy[slot] = wd.y; p.dz[slot] = wd.z;
-            p.tmax[slot] = Const<float>::inf;
-            p.skip[slot] = -1;
+            store_ray<float>(p.nray_o, p.nray_d, slot, wo, wd, Const<float>::inf, -1);   // by slot, until k_compact_alive
             L.phase = 1; begin = true;
           }
         } else if (L.phase == 1) { L.phase = pass ? 3 : 2; begin = true; }
@@ -550,11 +534,13 @@ static __global__ void __launch_bounds__(kRgBlock) k_raygen_pt_f32(SceneDev<floa
   }
 }
 
-// alive samples (weight > 0) -> q_active; counts the reference's "rays generated". Each wave scans kCompactRun
-// consecutive 64-slot groups, reserves its output range with ONE atomic and then writes, so a 268 M-slot frame
-// issues 65 k atomics on the queue counter instead of 4 M (which serialise on one L2 atomic unit).
+// Stage 3: alive samples (weight > 0) -> q_active in slot order, with their rays moved to the same queue positions;
+// counts the reference's "rays generated". Each wave scans kCompactRun consecutive 64-slot groups, reserves its output
+// range with ONE atomic and then writes, so a 268 M-slot frame issues 65 k atomics on the queue counter instead of
+// 4 M (which serialise on one L2 atomic unit). Slot order keeps the per-slot state gathers of the first bounces
+// nearly coalesced (and makes the queue order deterministic).
 constexpr uint32_t kCompactRun = 64;
-static __global__ void __launch_bounds__(kBlock) k_compact_alive(SceneDev<float> s, Pools<float> p, uint32_t total) {
+static __global__ void __launch_bounds__(kBlock) k_compact_alive(Pools<float> p, uint32_t total, int enqueue) {
   const uint32_t lane = threadIdx.x & 63u;
   const uint32_t wave = (blockIdx.x * blockDim.x + threadIdx.x) >> 6;
   const uint64_t base_slot = (uint64_t)wave * 64u * kCompactRun;
@@ -566,19 +552,24 @@ static __global__ void __launch_bounds__(kBlock) k_compact_alive(SceneDev<float>
     n_alive += (uint32_t)__popcll(__ballot(alive));
   }
   if (n_alive == 0) return;
-  const bool enqueue_all = s.integrator != 3;   // AOIntegrator::li returns 0 before drawing (ao.rs:62-64)
   uint32_t out = 0;
   if (lane == 0) {
     atomicAdd(&p.counters[C_CAMERA_RAYS], n_alive);
-    if (enqueue_all) out = atomicAdd(&p.counters[C_ACTIVE], n_alive);
+    if (enqueue) out = atomicAdd(&p.counters[C_ACTIVE], n_alive);
   }
-  if (!enqueue_all) return;
+  if (!enqueue) return;
   out = __shfl(out, 0);
   for (uint32_t k = 0; k < kCompactRun; k++) {
     const uint64_t slot = base_slot + (uint64_t)k * 64u + lane;
     const bool alive = slot < total && p.weight[slot] > 0.0f;
     const uint64_t m = __ballot(alive);
-    if (alive) p.q_active[out + (uint32_t)__popcll(m & ((1ull << lane) - 1ull))] = (uint32_t)slot;
+    if (alive) {
+      const uint32_t q = out + (uint32_t)__popcll(m & ((1ull << lane) - 1ull));
+      p.q_active[q] = QEnt{(uint32_t)slot, 5u};   // five camera dimensions consumed, bounce 0
+      p.path[q] = make_float4(1.0f, 1.0f, 1.0f, __uint_as_float(p.hindex[slot]));
+      p.ray_o[q] = p.nray_o[slot]; p.ray_d[q] = p.nray_d[slot];
+      p.L[slot] = make_float4(0.0f, 0.0f, 0.0f, 0.0f);
+    }
     out += (uint32_t)__popcll(m);
   }
 }

@@ -119,29 +119,40 @@ struct SceneDev {
   R rr_threshold;
 };
 
-// Wavefront pools (SoA over path slots). One slot = one camera sample of the current pass.
+// Wavefront pools. One slot = one camera sample of the current pass.
+//
+// Rays, hits and shadow rays are 16-byte-per-word records stored in QUEUE ORDER (index = position in the queue the
+// kernel iterates), not by slot, and so is the path state that changes per bounce (beta, sampler dimension, bounce
+// count): every bounce's traversal and shading kernels stream them with coalesced 128-bit loads / stores; the only
+// per-slot gather left is the radiance update of an unoccluded shadow ray. (The first version kept rays / hits as 4-byte
+// SoA arrays indexed by slot through the queue: 8 + 4 scattered dword accesses per ray, each its own 32/64-B
+// request - the PMC write traffic of the closest-hit kernel was 7x its algorithmic bytes.)
+// Integers ride in the 4th component as raw bits (never touched by arithmetic).
+template <typename R> struct Vec4T;
+template <> struct Vec4T<float> { using type = float4; };
+template <> struct Vec4T<double> { using type = double4; };
+
+struct QEnt { uint32_t slot, db; };
+
 template <typename R>
 struct Pools {
-  // rays for the closest-hit kernel (also the public rrt_rays layout)
-  R *ox, *oy, *oz, *dx, *dy, *dz, *tmax;
-  int32_t* skip;         // triangle (traversal order) a spawned ray starts on, -1 = none (see self_prim())
-  // hits
-  R *ht, *hu, *hv;
-  int32_t* hprim;
-  // shadow rays + pending contribution
-  R *sox, *soy, *soz, *sdx, *sdy, *sdz, *stmax;
-  R *ldr, *ldg, *ldb;
-  int32_t* sskip;
-  // path state
-  uint32_t* pixel;       // pixel index inside the frame (y * xres + x)
-  uint32_t* hindex;      // Halton global sample index
-  uint32_t* dim_bounce;  // dimension counter (low 16) | bounces (high 16)
-  R *br, *bg, *bb;       // beta
-  R *lr, *lg, *lb;       // L
-  R* weight;             // camera ray weight
+  using V4 = typename Vec4T<R>::type;
+  // rays of q_active (also the public rrt_rays batch): {o.x, o.y, o.z, t_max}, {d.x, d.y, d.z, skip}
+  // skip = triangle (traversal order) a spawned ray starts on, -1 = none (see self_prim())
+  V4 *ray_o, *ray_d;
+  V4 *nray_o, *nray_d;   // rays being spawned for q_next (the host swaps the pairs together with the queues)
+  V4* hit;               // {t, prim, u, v} for the ray at the same queue position
+  V4 *sray_o, *sray_d;   // shadow rays, in shadow-queue order
+  V4* sld;               // {Ld.r, Ld.g, Ld.b, slot}: pending contribution of the shadow ray at the same position
+  // path state that changes every bounce travels with the queue too (cur / next, swapped with the rays)
+  V4 *path, *npath;      // {beta.r, beta.g, beta.b, Halton global sample index}
+  QEnt *q_active, *q_next;   // {slot, dimension counter (low 16) | bounces (high 16)}
+  // per-slot state: only what outlives a path's queue entries
+  V4* L;                 // {L.r, L.g, L.b, -}: radiance; touched by unoccluded shadow rays and the film kernel
+  R* weight;             // camera ray weight (0 = dead sample: its L is never read)
   R *pfx, *pfy;          // p_film
-  // queues
-  uint32_t *q_active, *q_next, *q_shadow;
+  R *lensx, *lensy;      // p_lens (raygen only)
+  uint32_t* hindex;      // Halton index (raygen -> first queue entry)
   uint32_t* counters;    // [0] active, [1] next, [2] shadow, [3] camera rays, [4..] stats
 };
 

@@ -122,7 +122,7 @@ class Handle : public HandleBase {
     // launches beat many small ones (whole 1024^2 x 256 spp frame in one pass: 268 M slots x 172 B = 46 GB).
     size_t free_b = 0, total_b = 0;
     HIP_CHECK(hipMemGetInfo(&free_b, &total_b));
-    const size_t per_slot = 33 * sizeof(R) + 9 * sizeof(uint32_t);
+    const size_t per_slot = (11 * 4 + 5) * sizeof(R) + 5 * sizeof(uint32_t);
     max_paths_ = std::max<size_t>(1u << 16, std::min(max_paths_, (free_b / 2) / per_slot));
   }
   ~Handle() override {
@@ -155,10 +155,19 @@ class Handle : public HandleBase {
     hipLaunchKernelGGL(k_rotate, dim3(1), dim3(1), 0, st_, counters_.p, 3);
     launch_closest(nullptr, nullptr, (uint32_t)n, want_counts, want_counts ? cn.p : nullptr, want_counts ? cp.p : nullptr, nullptr);
     auto kind = out->mem == RRT_MEM_DEVICE ? hipMemcpyDeviceToDevice : hipMemcpyDeviceToHost;
-    HIP_CHECK(hipMemcpyAsync(out->t, pool_.ht, n * sizeof(R), kind, st_));
-    HIP_CHECK(hipMemcpyAsync(out->prim, pool_.hprim, n * sizeof(int32_t), kind, st_));
-    if (out->u) HIP_CHECK(hipMemcpyAsync(out->u, pool_.hu, n * sizeof(R), kind, st_));
-    if (out->v) HIP_CHECK(hipMemcpyAsync(out->v, pool_.hv, n * sizeof(R), kind, st_));
+    const uint32_t ug = (uint32_t)((n + kBlock - 1) / kBlock);
+    if (out->mem == RRT_MEM_DEVICE) {
+      hipLaunchKernelGGL((k_unpack_hits<R>), dim3(ug), dim3(kBlock), 0, st_, pool_, (R*)out->t, (int32_t*)out->prim, (R*)out->u, (R*)out->v, (uint32_t)n);
+    } else {
+      DevBuf<R> hr; DevBuf<int32_t> hp;
+      hr.alloc(3 * n); hp.alloc(n);
+      hipLaunchKernelGGL((k_unpack_hits<R>), dim3(ug), dim3(kBlock), 0, st_, pool_, hr.p, hp.p, hr.p + n, hr.p + 2 * n, (uint32_t)n);
+      HIP_CHECK(hipMemcpyAsync(out->t, hr.p, n * sizeof(R), kind, st_));
+      HIP_CHECK(hipMemcpyAsync(out->prim, hp.p, n * sizeof(int32_t), kind, st_));
+      if (out->u) HIP_CHECK(hipMemcpyAsync(out->u, hr.p + n, n * sizeof(R), kind, st_));
+      if (out->v) HIP_CHECK(hipMemcpyAsync(out->v, hr.p + 2 * n, n * sizeof(R), kind, st_));
+      HIP_CHECK(hipStreamSynchronize(st_));   // staging buffers go out of scope
+    }
     if (want_counts) {
       HIP_CHECK(hipMemcpyAsync(out->nodes_visited, cn.p, n * sizeof(uint32_t), kind, st_));
       HIP_CHECK(hipMemcpyAsync(out->prims_tested, cp.p, n * sizeof(uint32_t), kind, st_));
@@ -194,7 +203,8 @@ class Handle : public HandleBase {
     PassDesc pd{rect[0], rect[1], rect[2] - rect[0], 0u, (uint32_t)npix, (uint32_t)s0, (uint32_t)ns, 1u << 30, 1u, 0u};
     hipLaunchKernelGGL(k_rotate, dim3(1), dim3(1), 0, st_, counters_.p, 2);
     const uint32_t g = (uint32_t)((n + kBlock - 1) / kBlock);
-    launch_raygen(pd, g, dd.p);
+    launch_raygen(pd, g, dd.p, 1);
+    HIP_CHECK(hipMemsetAsync(dr.p, 0, 6 * n * sizeof(double), st_));
     hipLaunchKernelGGL((k_camera_dump<R>), dim3(g), dim3(kBlock), 0, st_, pool_, pd, dr.p, dw.p);
     HIP_CHECK(hipGetLastError());
     HIP_CHECK(hipMemcpyAsync(dims5, dd.p, 5 * n * sizeof(double), hipMemcpyDeviceToHost, st_));
@@ -270,9 +280,10 @@ class Handle : public HandleBase {
         PassDesc pd{rect[0], rect[1], (int32_t)rw, (uint32_t)g0, (uint32_t)npix, (uint32_t)(1 + sb), (uint32_t)ns, band_h, n_ranks, rank};
         const size_t nslots = npix * (size_t)ns;
         const uint32_t grid = (uint32_t)((nslots + kBlock - 1) / kBlock);
+        const uint32_t sgrid = (uint32_t)((nslots + ShadeBlock<R>::n - 1) / ShadeBlock<R>::n);
         hipLaunchKernelGGL(k_rotate, dim3(1), dim3(1), 0, st_, counters_.p, 2);
         size_t e = tick(0);
-        launch_raygen(pd, grid, nullptr);
+        launch_raygen(pd, grid, nullptr, integ != RRT_INT_AO ? 1 : 0);
         tock(e);
         hipLaunchKernelGGL(k_accumulate_camera, dim3(1), dim3(1), 0, st_, counters_.p, totals_.p);
         if (integ == RRT_INT_PATH) {
@@ -280,16 +291,16 @@ class Handle : public HandleBase {
           for (int b = 0; b < max_depth; b++) {
             hipLaunchKernelGGL(k_accumulate_counts, dim3(1), dim3(1), 0, st_, counters_.p, totals_.p);
             e = tick(1);
-            launch_closest(pool_.q_active, &counters_.p[C_ACTIVE], 0, count_traversal_, nullptr, nullptr, count_traversal_ ? totals_.p : nullptr, grid);
+            launch_closest(nullptr, &counters_.p[C_ACTIVE], 0, count_traversal_, nullptr, nullptr, count_traversal_ ? totals_.p : nullptr, grid);
             tock(e); n_closest_launch++;
             e = tick(3);
-            hipLaunchKernelGGL((k_shade_path<R>), dim3(grid), dim3(kBlock), 0, st_, scene_, pool_);
+            hipLaunchKernelGGL((k_shade_path<R>), dim3(sgrid), dim3(ShadeBlock<R>::n), 0, st_, scene_, pool_);
             tock(e);
             hipLaunchKernelGGL(k_accumulate_shadow, dim3(1), dim3(1), 0, st_, counters_.p, totals_.p);
             e = tick(2);
             launch_shadow(grid);
             tock(e); n_any_launch++;
-            std::swap(pool_.q_active, pool_.q_next);
+            swap_queues();
             hipLaunchKernelGGL(k_rotate, dim3(1), dim3(1), 0, st_, counters_.p, 0);
           }
         } else if (integ == RRT_INT_DIRECT || integ == RRT_INT_DEBUG) {
@@ -298,14 +309,14 @@ class Handle : public HandleBase {
           for (int level = 0; level < std::max(1, max_depth - 1); level++) {
             hipLaunchKernelGGL(k_accumulate_counts, dim3(1), dim3(1), 0, st_, counters_.p, totals_.p);
             e = tick(1);
-            launch_closest(pool_.q_active, &counters_.p[C_ACTIVE], 0, count_traversal_, nullptr, nullptr, count_traversal_ ? totals_.p : nullptr, grid);
+            launch_closest(nullptr, &counters_.p[C_ACTIVE], 0, count_traversal_, nullptr, nullptr, count_traversal_ ? totals_.p : nullptr, grid);
             tock(e); n_closest_launch++;
             if (desc_.n_lights > 0) {
               const int nl = all ? (int)desc_.n_lights : 1;
               for (int j = 0; j < nl; j++) {
                 hipLaunchKernelGGL(k_rotate, dim3(1), dim3(1), 0, st_, counters_.p, 1);
                 e = tick(3);
-                hipLaunchKernelGGL((k_shade_nee<R>), dim3(grid), dim3(kBlock), 0, st_, scene_, pool_, all ? j : -1, j == 0 ? 1 : 0);
+                hipLaunchKernelGGL((k_shade_nee<R>), dim3(sgrid), dim3(ShadeBlock<R>::n), 0, st_, scene_, pool_, all ? j : -1, j == 0 ? 1 : 0);
                 tock(e);
                 hipLaunchKernelGGL(k_accumulate_shadow, dim3(1), dim3(1), 0, st_, counters_.p, totals_.p);
                 e = tick(2);
@@ -314,9 +325,9 @@ class Handle : public HandleBase {
               }
             }
             e = tick(3);
-            hipLaunchKernelGGL((k_shade_specular<R>), dim3(grid), dim3(kBlock), 0, st_, scene_, pool_, (desc_.n_lights == 0 && integ == RRT_INT_DEBUG) ? 1 : 0);
+            hipLaunchKernelGGL((k_shade_specular<R>), dim3(sgrid), dim3(ShadeBlock<R>::n), 0, st_, scene_, pool_, (desc_.n_lights == 0 && integ == RRT_INT_DEBUG) ? 1 : 0);
             tock(e);
-            std::swap(pool_.q_active, pool_.q_next);
+            swap_queues();
             hipLaunchKernelGGL(k_rotate, dim3(1), dim3(1), 0, st_, counters_.p, 0);
           }
         }
@@ -399,6 +410,7 @@ class Handle : public HandleBase {
   DevBuf<LensElem<R>> lens_;
   DevBuf<HaltonDim> hdims_;
   DevBuf<uint16_t> perms_;
+  DevBuf<typename Vec4T<R>::type> vpool_;
   DevBuf<R> rpool_;
   DevBuf<uint32_t> upool_, counters_, deep_stack_;
   DevBuf<unsigned long long> totals_;
@@ -621,34 +633,45 @@ class Handle : public HandleBase {
     if (n <= cap_) return;
     HIP_CHECK(hipStreamSynchronize(st_));
     cap_ = n;
-    const size_t NR = 33, NU = 9;
+    using V4 = typename Vec4T<R>::type;
+    const size_t NV = 11, NR = 5, NU = 5;   // 4-word records, reals, u32 per slot
+    vpool_.alloc(NV * cap_);
     rpool_.alloc(NR * cap_);
     upool_.alloc(NU * cap_);
+    Pools<R>& p = pool_;
+    V4* v = vpool_.p;
+    auto nv = [&]() { V4* x = v; v += cap_; return x; };
+    p.ray_o = nv(); p.ray_d = nv(); p.nray_o = nv(); p.nray_d = nv(); p.hit = nv();
+    p.sray_o = nv(); p.sray_d = nv(); p.sld = nv(); p.path = nv(); p.npath = nv(); p.L = nv();
     R* r = rpool_.p;
     auto nr = [&]() { R* x = r; r += cap_; return x; };
-    Pools<R>& p = pool_;
-    p.ox = nr(); p.oy = nr(); p.oz = nr(); p.dx = nr(); p.dy = nr(); p.dz = nr(); p.tmax = nr();
-    p.ht = nr(); p.hu = nr(); p.hv = nr();
-    p.sox = nr(); p.soy = nr(); p.soz = nr(); p.sdx = nr(); p.sdy = nr(); p.sdz = nr(); p.stmax = nr();
-    p.ldr = nr(); p.ldg = nr(); p.ldb = nr();
-    p.br = nr(); p.bg = nr(); p.bb = nr(); p.lr = nr(); p.lg = nr(); p.lb = nr();
-    p.weight = nr(); p.pfx = nr(); p.pfy = nr();
+    p.weight = nr(); p.pfx = nr(); p.pfy = nr(); p.lensx = nr(); p.lensy = nr();
     uint32_t* u = upool_.p;
     auto nu = [&]() { uint32_t* x = u; u += cap_; return x; };
-    p.hprim = (int32_t*)nu(); p.skip = (int32_t*)nu(); p.sskip = (int32_t*)nu(); p.pixel = nu(); p.hindex = nu(); p.dim_bounce = nu(); p.q_active = nu(); p.q_next = nu(); p.q_shadow = nu();
+    p.q_active = (QEnt*)u; u += 2 * cap_; p.q_next = (QEnt*)u; u += 2 * cap_; p.hindex = nu();
     p.counters = counters_.p;
     if (deep_) deep_stack_.alloc((size_t)scene_.stack_depth * cap_);
 
   }
 
   void load_rays(const rrt_rays* rays, size_t n) {
-    auto kind = rays->mem == RRT_MEM_DEVICE ? hipMemcpyDeviceToDevice : hipMemcpyHostToDevice;
+    const uint32_t g = (uint32_t)((n + kBlock - 1) / kBlock);
+    if (rays->mem == RRT_MEM_DEVICE) {
+      hipLaunchKernelGGL((k_pack_rays<R>), dim3(g), dim3(kBlock), 0, st_, pool_, (const R*)rays->ox, (const R*)rays->oy, (const R*)rays->oz,
+                         (const R*)rays->dx, (const R*)rays->dy, (const R*)rays->dz, (const R*)rays->tmax, (const int32_t*)rays->skip_prim, (uint32_t)n);
+      return;
+    }
+    DevBuf<R> sr; DevBuf<int32_t> sk;
+    sr.alloc(7 * n);
     const void* src[7] = {rays->ox, rays->oy, rays->oz, rays->dx, rays->dy, rays->dz, rays->tmax};
-    R* dst[7] = {pool_.ox, pool_.oy, pool_.oz, pool_.dx, pool_.dy, pool_.dz, pool_.tmax};
-    for (int k = 0; k < 7; k++) HIP_CHECK(hipMemcpyAsync(dst[k], src[k], n * sizeof(R), kind, st_));
-    if (rays->skip_prim) HIP_CHECK(hipMemcpyAsync(pool_.skip, rays->skip_prim, n * sizeof(int32_t), kind, st_));
-    else HIP_CHECK(hipMemsetAsync(pool_.skip, 0xff, n * sizeof(int32_t), st_));
+    for (int k = 0; k < 7; k++) HIP_CHECK(hipMemcpyAsync(sr.p + k * n, src[k], n * sizeof(R), hipMemcpyHostToDevice, st_));
+    if (rays->skip_prim) { sk.alloc(n); HIP_CHECK(hipMemcpyAsync(sk.p, rays->skip_prim, n * sizeof(int32_t), hipMemcpyHostToDevice, st_)); }
+    hipLaunchKernelGGL((k_pack_rays<R>), dim3(g), dim3(kBlock), 0, st_, pool_, sr.p, sr.p + n, sr.p + 2 * n, sr.p + 3 * n, sr.p + 4 * n, sr.p + 5 * n, sr.p + 6 * n,
+                       (const int32_t*)sk.p, (uint32_t)n);
+    HIP_CHECK(hipStreamSynchronize(st_));   // staging buffers go out of scope
   }
+  // active <- next for the queue and for the rays stored at its positions
+  void swap_queues() { std::swap(pool_.q_active, pool_.q_next); std::swap(pool_.ray_o, pool_.nray_o); std::swap(pool_.ray_d, pool_.nray_d); std::swap(pool_.path, pool_.npath); }
 
   void launch_closest(const uint32_t* queue, const uint32_t* count, uint32_t n_fixed, bool counting, uint32_t* cn, uint32_t* cp,
                       unsigned long long* totals, uint32_t grid_override = 0) {
@@ -666,7 +689,7 @@ class Handle : public HandleBase {
     HIP_CHECK(hipGetLastError());
   }
   // camera ray generation: persistent-thread kernel in fp32, two-stage (main trace, compaction, auxiliary traces) in f64
-  void launch_raygen(const PassDesc& pd, uint32_t grid, double* dims_out) {
+  void launch_raygen(const PassDesc& pd, uint32_t grid, double* dims_out, int enqueue) {
     if constexpr (std::is_same<R, float>::value) {
       if (raygen_pt_ && scene_.n_lens <= 32) {
         if (rg_grid_ == 0) {
@@ -680,13 +703,13 @@ class Handle : public HandleBase {
         hipLaunchKernelGGL(k_sample_f32, dim3((total + kBlock - 1) / kBlock), dim3(kBlock), 0, st_, scene_, pool_, pd, dims_out);
         hipLaunchKernelGGL(k_raygen_pt_f32, dim3(g), dim3(kRgBlock), 0, st_, scene_, pool_, pd, &counters_.p[C_WORK_AUX]);
         const uint32_t n_cw = (total + 64u * kCompactRun - 1) / (64u * kCompactRun);   // waves
-        hipLaunchKernelGGL(k_compact_alive, dim3((n_cw * 64u + kBlock - 1) / kBlock), dim3(kBlock), 0, st_, scene_, pool_, total);
+        hipLaunchKernelGGL(k_compact_alive, dim3((n_cw * 64u + kBlock - 1) / kBlock), dim3(kBlock), 0, st_, pool_, total, enqueue);
         HIP_CHECK(hipGetLastError());
         return;
       }
     }
     hipLaunchKernelGGL((k_raygen<R>), dim3(grid), dim3(kBlock), 0, st_, scene_, pool_, pd, dims_out);
-    hipLaunchKernelGGL((k_raygen_aux<R>), dim3(grid), dim3(kBlock), 0, st_, scene_, pool_);
+    hipLaunchKernelGGL((k_raygen_aux<R>), dim3(grid), dim3(kBlock), 0, st_, scene_, pool_, enqueue);
     hipLaunchKernelGGL(k_rotate, dim3(1), dim3(1), 0, st_, counters_.p, 4);   // q_next was only a staging queue
     HIP_CHECK(hipGetLastError());
   }
@@ -802,16 +825,16 @@ class Handle : public HandleBase {
     }
   }
   void launch_shadow(uint32_t grid) {
-    if (!count_traversal_ && use_persistent()) { launch_persistent(true, pool_.q_shadow, &counters_.p[C_SHADOW], 0, grid, nullptr); return; }
+    if (!count_traversal_ && use_persistent()) { launch_persistent(true, nullptr, &counters_.p[C_SHADOW], 0, grid, nullptr); return; }
     uint32_t* ds = deep_ ? deep_stack_.p : nullptr;
     const uint32_t stride = deep_ ? (uint32_t)cap_ : 0u;
     unsigned long long* tot = count_traversal_ ? totals_.p + 5 : nullptr;
     if (deep_) {
-      if (count_traversal_) hipLaunchKernelGGL((k_shadow<R, true, true>), dim3(grid), dim3(kBlock), 0, st_, scene_, pool_, pool_.q_shadow, &counters_.p[C_SHADOW], ds, stride, tot);
-      else hipLaunchKernelGGL((k_shadow<R, true, false>), dim3(grid), dim3(kBlock), 0, st_, scene_, pool_, pool_.q_shadow, &counters_.p[C_SHADOW], ds, stride, tot);
+      if (count_traversal_) hipLaunchKernelGGL((k_shadow<R, true, true>), dim3(grid), dim3(kBlock), 0, st_, scene_, pool_, (const uint32_t*)nullptr, &counters_.p[C_SHADOW], ds, stride, tot);
+      else hipLaunchKernelGGL((k_shadow<R, true, false>), dim3(grid), dim3(kBlock), 0, st_, scene_, pool_, (const uint32_t*)nullptr, &counters_.p[C_SHADOW], ds, stride, tot);
     } else {
-      if (count_traversal_) hipLaunchKernelGGL((k_shadow<R, false, true>), dim3(grid), dim3(kBlock), 0, st_, scene_, pool_, pool_.q_shadow, &counters_.p[C_SHADOW], ds, stride, tot);
-      else hipLaunchKernelGGL((k_shadow<R, false, false>), dim3(grid), dim3(kBlock), 0, st_, scene_, pool_, pool_.q_shadow, &counters_.p[C_SHADOW], ds, stride, tot);
+      if (count_traversal_) hipLaunchKernelGGL((k_shadow<R, false, true>), dim3(grid), dim3(kBlock), 0, st_, scene_, pool_, (const uint32_t*)nullptr, &counters_.p[C_SHADOW], ds, stride, tot);
+      else hipLaunchKernelGGL((k_shadow<R, false, false>), dim3(grid), dim3(kBlock), 0, st_, scene_, pool_, (const uint32_t*)nullptr, &counters_.p[C_SHADOW], ds, stride, tot);
     }
     HIP_CHECK(hipGetLastError());
   }
