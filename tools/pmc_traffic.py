@@ -9,7 +9,7 @@ import collections, csv, glob, json, re, sys
 root = sys.argv[1]
 fam = collections.OrderedDict([
     ("closest", r"k_trace_(pt|pairs)_f32<false>"), ("any", r"k_trace_(pt|pairs)_f32<true>"),
-    ("raygen", r"k_raygen|k_compact_alive"), ("shade", r"k_shade"), ("film", r"k_film|k_accumulate")])
+    ("raygen", r"k_raygen|k_compact_alive|k_sample_f32"), ("shade", r"k_shade"), ("film", r"k_film|k_accumulate")])
 tot = {k: collections.defaultdict(float) for k in fam}
 disp = {k: collections.defaultdict(int) for k in fam}
 for f in glob.glob(f"{root}/pass*/**/*counter_collection.csv", recursive=True):
