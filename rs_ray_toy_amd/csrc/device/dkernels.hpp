@@ -953,6 +953,62 @@ __global__ void __launch_bounds__(kBlock) k_film_box(SceneDev<R> s, Pools<R> p, 
   px[3] += wsum; px[3] += wsum; px[3] += wsum;
 }
 
+// Filters wider than one pixel (TriangleFilter / GaussianFilter / wide BoxFilter, film.rs:77-130 with the 16x16
+// table): a sample at p_film touches pixels [ceil(p - 0.5 - r), trunc(p - 0.5 + r)] in x and y. Gather form: one
+// thread owns a film pixel and visits the samples of every pixel of this pass within reach, applying exactly the
+// reference's footprint test and table lookup - deterministic, no atomics, and contributions that cross a rect /
+// band / rank border simply land in that pixel of this handle's film (the multi-GPU reduce is a sum).
+RRT_DEV bool pass_pixel_inverse(const PassDesc& pd, int x, int y, uint32_t* pl) {
+  if (x < pd.rx0 || x >= pd.rx0 + pd.rw || y < pd.ry0) return false;
+  const uint32_t yy = (uint32_t)(y - pd.ry0), band = yy / pd.band_h;
+  if (band % pd.n_ranks != pd.rank) return false;
+  const uint32_t row = (band / pd.n_ranks) * pd.band_h + yy % pd.band_h;
+  const uint64_t lin = (uint64_t)row * (uint32_t)pd.rw + (uint32_t)(x - pd.rx0);
+  if (lin < pd.pix_begin || lin >= (uint64_t)pd.pix_begin + pd.npix) return false;
+  *pl = (uint32_t)(lin - pd.pix_begin);
+  return true;
+}
+template <typename R>
+__global__ void __launch_bounds__(kBlock) k_film_wide(SceneDev<R> s, Pools<R> p, PassDesc pd, R* film, int ex0, int ey0, int ew, int eh, int reach_x, int reach_y, int ymax) {
+  const uint32_t t = blockIdx.x * blockDim.x + threadIdx.x;
+  if (t >= (uint32_t)ew * (uint32_t)eh) return;
+  const int x = ex0 + (int)(t % (uint32_t)ew), y = ey0 + (int)(t / (uint32_t)ew);
+  R cr = R(0), cg = R(0), cb = R(0), wsum = R(0);
+  const R inv_rx = R(1) / s.filter_rx, inv_ry = R(1) / s.filter_ry;
+  for (int sy = y - reach_y; sy <= y + reach_y; sy++) {
+    if (sy < 0 || sy >= ymax) continue;
+    for (int sx = x - reach_x; sx <= x + reach_x; sx++) {
+      uint32_t pl;
+      if (sx < 0 || sx >= s.xres || !pass_pixel_inverse(pd, sx, sy, &pl)) continue;
+      for (uint32_t sl = 0; sl < pd.ns; sl++) {
+        const uint32_t slot = sl * pd.npix + pl;
+        const R dx = p.pfx[slot] - R(0.5), dy = p.pfy[slot] - R(0.5);
+        // p0 = ceil(d - r), p1 = trunc(d + r) + 1 (Point2i::from truncates), clipped to the film by the tile bounds
+        const R p0x = ceil(dx - s.filter_rx), p0y = ceil(dy - s.filter_ry);
+        const R p1x = trunc(dx + s.filter_rx) + R(1), p1y = trunc(dy + s.filter_ry) + R(1);
+        if ((R)x < p0x || (R)x >= p1x || (R)y < p0y || (R)y >= p1y) continue;
+        const R fy = rabs(((R)y - dy) * inv_ry * R(16)), fx = rabs(((R)x - dx) * inv_rx * R(16));
+        const int ify = (int)rmin(floor(fy), R(15)), ifx = (int)rmin(floor(fx), R(15));
+        const R fw = s.filter_table[ify * 16 + ifx];
+        const R w = p.weight[slot];
+        Rgb<R> L;
+        if (w > R(0)) { const typename Vec4T<R>::type l = p.L[slot]; L = Rgb<R>(l.x, l.y, l.z); }
+        if (L.has_nan()) L = Rgb<R>();
+        else if (L.y() < R(-1e-5)) L = Rgb<R>();
+        else if (isinf(L.y())) L = Rgb<R>();
+        if (L.y() > s.max_sample_luminance) L = L * (s.max_sample_luminance / L.y());
+        cr += (L.r * w) * fw; cg += (L.g * w) * fw; cb += (L.b * w) * fw;
+        wsum += fw;
+      }
+    }
+  }
+  R* px = film + 4 * ((size_t)y * (size_t)s.xres + (size_t)x);
+  px[0] += R(0.412453) * cr + R(0.357580) * cg + R(0.180423) * cb;
+  px[1] += R(0.212671) * cr + R(0.715160) * cg + R(0.072169) * cb;
+  px[2] += R(0.019334) * cr + R(0.119193) * cg + R(0.950227) * cb;
+  px[3] += wsum; px[3] += wsum; px[3] += wsum;
+}
+
 template <typename R>
 __global__ void k_film_add(const R* src, R* dst, size_t n) {
   size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x;

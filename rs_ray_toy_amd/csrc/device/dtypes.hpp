@@ -103,6 +103,8 @@ struct SceneDev {
   int32_t xres, yres;
   R diagonal, extent[4];
   R max_sample_luminance;
+  const R* filter_table;       // 16 x 16 (film.rs:163-173, incl. Q4), only read by the wide-filter film kernel
+  R filter_rx, filter_ry;
   // sampler
   const HaltonDim* hdims;
   const uint16_t* perms;

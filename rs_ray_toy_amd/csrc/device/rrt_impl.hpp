@@ -227,8 +227,8 @@ class Handle : public HandleBase {
     HIP_CHECK(hipSetDevice(dev_));
     check_renderable();
     const rrt_film& f = desc_.film;
-    if (f.filter_type != RRT_FILTER_BOX || f.filter_radius[0] > 0.5 || f.filter_radius[1] > 0.5)
-      throw UnsupportedError("device film supports the box filter with radius <= 0.5 this round (wide filters: SURVEY §8f rank 1)");
+    const bool wide_filter = f.filter_type != RRT_FILTER_BOX || f.filter_radius[0] > 0.5 || f.filter_radius[1] > 0.5;
+    if (f.crop[0] != 0 || f.crop[1] != 0 || f.crop[2] != f.xres || f.crop[3] != f.yres) throw UnsupportedError("film crop window");
     if (rect[0] < 0 || rect[1] < 0 || rect[2] > f.xres || rect[3] > f.yres || rect[0] >= rect[2] || rect[1] >= rect[3])
       throw std::invalid_argument("render rect outside the film");
     if (desc_.integrator.type == RRT_INT_DIRECT && desc_.n_lights == 0)
@@ -332,7 +332,16 @@ class Handle : public HandleBase {
           }
         }
         e = tick(4);
-        hipLaunchKernelGGL((k_film_box<R>), dim3((uint32_t)((npix + kBlock - 1) / kBlock)), dim3(kBlock), 0, st_, scene_, pool_, pd, film_.p);
+        if (!wide_filter) hipLaunchKernelGGL((k_film_box<R>), dim3((uint32_t)((npix + kBlock - 1) / kBlock)), dim3(kBlock), 0, st_, scene_, pool_, pd, film_.p);
+        else {
+          // film pixels the samples of this rect can touch: the rect grown by ceil(r + 0.5), clipped to the film
+          const int reach_x = (int)std::ceil(f.filter_radius[0] + 0.5), reach_y = (int)std::ceil(f.filter_radius[1] + 0.5);
+          const int ex0 = std::max(0, rect[0] - reach_x), ey0 = std::max(0, rect[1] - reach_y);
+          const int ex1 = std::min(f.xres, rect[2] + reach_x), ey1 = std::min(f.yres, rect[3] + reach_y);
+          const size_t en = (size_t)(ex1 - ex0) * (size_t)(ey1 - ey0);
+          hipLaunchKernelGGL((k_film_wide<R>), dim3((uint32_t)((en + kBlock - 1) / kBlock)), dim3(kBlock), 0, st_, scene_, pool_, pd, film_.p,
+                             ex0, ey0, ex1 - ex0, ey1 - ey0, reach_x, reach_y, f.yres);
+        }
         tock(e);
         HIP_CHECK(hipGetLastError());
       }
@@ -408,6 +417,7 @@ class Handle : public HandleBase {
   DevBuf<Light<R>> lights_;
   DevBuf<R> light_cdf_;
   DevBuf<LensElem<R>> lens_;
+  DevBuf<R> filter_table_;
   DevBuf<HaltonDim> hdims_;
   DevBuf<uint16_t> perms_;
   DevBuf<typename Vec4T<R>::type> vpool_;
@@ -622,6 +632,14 @@ class Handle : public HandleBase {
       double v = 1.0;
       for (int k = 0; k < 16; k++) { s.cam_invpow[w][k] = v; v *= inv_base; }
       s.cam_tail[w] = pm ? inv_base * (double)pm[0] / (1.0 - inv_base) : 0.0;
+    }
+    {
+      std::vector<R> ft(256);
+      for (int i = 0; i < 256; i++) ft[i] = (R)d->film.filter_table[i];
+      filter_table_.upload(ft, st_);
+      HIP_CHECK(hipStreamSynchronize(st_));
+      s.filter_table = filter_table_.p;
+      s.filter_rx = (R)d->film.filter_radius[0]; s.filter_ry = (R)d->film.filter_radius[1];
     }
     s.integrator = d->integrator.type; s.max_depth = d->integrator.max_depth; s.light_strategy = d->integrator.light_strategy;
     s.rr_threshold = (R)d->integrator.rr_threshold;

@@ -269,6 +269,49 @@ def test_roundtrip_properties_full_size(workdir):
     assert (got["prim"][idx] == ref["prim"]).mean() > 0.999
 
 
+WIDE_FILTERS = {
+    "triangle": {"filter_type": "TriangleFilter", "radius": [2.0, 2.0]},
+    "gaussian": {"filter_type": "GaussianFilter", "radius": [2.0, 2.0], "alpha": 2.0},
+    "gaussian_aniso": {"filter_type": "GaussianFilter", "radius": [1.5, 2.5], "alpha": 1.0},
+    "box_wide": {"filter_type": "BoxFilter", "radius": [1.0, 0.75]},
+}
+
+
+@pytest.mark.parametrize("which", sorted(WIDE_FILTERS))
+def test_wide_filters(which, workdir):
+    """FilmTile::add_sample with filters wider than a pixel (film.rs:77-130, filters/trianglefilter.rs, gaussian.rs): a
+    sample splats into every pixel within the radius through the 16x16 table (incl. Q4: the table only varies with y).
+    f64: same sums up to the order of additions; fp32: the stated tolerance. Rect / band partitions still sum to the frame
+    (splats that cross a border land in the neighbour's pixels: the multi-GPU reduce is a sum)."""
+    cfg, root = scenes.cfg4(workdir, xres=48, yres=40, nsamp=5, max_depth=3, n=24)
+    cfg["Film"]["Filter"] = WIDE_FILTERS[which]
+    sc = Scene.loads(cfg, root, flags=RRT_FIXED_BVH)
+    ref = O.render(sc, flat=True)
+    scale = np.abs(ref[..., :3]).max()
+    assert scale > 0 and ref[..., 3].min() > 0
+    r = Renderer(sc, 0, RRT_F64)
+    film = r.render()
+    np.testing.assert_allclose(film[..., 3], ref[..., 3], rtol=1e-12)          # filter weight sums (x3, Q3)
+    assert np.abs(film[..., :3] - ref[..., :3]).max() / scale < 1e-9
+    parts = np.zeros_like(film)
+    for rect in ((0, 0, 48, 16), (0, 16, 20, 40), (20, 16, 48, 40)):
+        r.render(rect, film=parts)
+    np.testing.assert_allclose(parts, film, rtol=1e-11, atol=1e-13 * scale)
+    bands = np.zeros_like(film)
+    for rank in range(3):
+        bands += r.render_bands(rank, 3)
+    np.testing.assert_allclose(bands, film, rtol=1e-11, atol=1e-13 * scale)
+    r.set_option("max_paths", 700)   # several pixel groups and sample passes
+    small = r.render()
+    np.testing.assert_allclose(small, film, rtol=1e-11, atol=1e-13 * scale)
+    r.close()
+    r = Renderer(sc, 0, RRT_F32)
+    f32 = r.render().astype(np.float64)
+    r.close()
+    assert np.abs(f32[..., :3] - ref[..., :3]).max() / scale < 1e-4
+    np.testing.assert_allclose(f32[..., 3], ref[..., 3], rtol=1e-5)
+
+
 def _sphere_zoo(wd, integrator, xres=48, yres=48, nsamp=5):
     """Sphere primitives next to triangles: plain instanced spheres (cfg1 style), clipped spheres (z_min / z_max /
     phi_max), a sphere with its own to_world (Q16: first p_hit taken from the un-transformed ray), a scaled instance
