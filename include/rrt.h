@@ -32,7 +32,7 @@
 extern "C" {
 #endif
 
-#define RRT_ABI_VERSION 1
+#define RRT_ABI_VERSION 2
 
 /* ---- error codes ------------------------------------------------------- */
 enum {
@@ -60,7 +60,7 @@ enum { RRT_PRIM_TRIANGLE = 0, RRT_PRIM_SPHERE = 1 };
 enum { /* material_type, renderprocess.rs:664-871 */
   RRT_MAT_MATTE = 0, RRT_MAT_PLASTIC = 1, RRT_MAT_METAL = 2, RRT_MAT_MIRROR = 3, RRT_MAT_DEBUG = 4
 };
-enum { RRT_LIGHT_POINT = 0, RRT_LIGHT_DIFFUSE = 1 };            /* renderprocess.rs:991-1017 */
+enum { RRT_LIGHT_POINT = 0, RRT_LIGHT_DIFFUSE = 1, RRT_LIGHT_DISTANT = 2 };  /* renderprocess.rs:991-1031 */
 enum { RRT_SAMPLER_HALTON = 0, RRT_SAMPLER_STRATIFIED = 1 };    /* renderprocess.rs:1306-1325 */
 enum { RRT_FILTER_BOX = 0, RRT_FILTER_TRIANGLE = 1, RRT_FILTER_GAUSSIAN = 2 };
 enum { /* integrator_type, renderprocess.rs:1399-1499 */
@@ -120,6 +120,8 @@ typedef struct rrt_light {
   int32_t shape_type;   /* RRT_PRIM_* of light_shape (diffuse only)   */
   uint32_t shape;       /* index into spheres / tris                  */
   double area;
+  double w_light[3];    /* distant: normalize(light_to_world(from - to)), lights/distant.rs:30 */
+  double world_radius;  /* distant: bounding sphere of aggregate.world_bound(), distant.rs:31-33, geometry.rs:1656-1668 */
 } rrt_light;
 
 /* LinearBVHNode, bvh.rs:103-109 (f64 bounds as built; device narrows conservatively) */

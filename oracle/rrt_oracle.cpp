@@ -1120,6 +1120,14 @@ LightSample light_sample_li(const Scene& sc, const rrt_light& L, V3 ref_p, doubl
     s.li = Rgb(L.spectrum) / len2(pl - ref_p);
     return s;
   }
+  if (L.type == RRT_LIGHT_DISTANT) {  // distant.rs:67-92: wi = w_light, pdf = 1, p1 = p + w_light * 2 * world_radius
+    V3 w(L.w_light[0], L.w_light[1], L.w_light[2]);
+    s.wi = w;
+    s.pdf = 1.0;
+    s.p1 = ref_p + w * (2.0 * L.world_radius); s.n1 = V3(); s.have_vis = true;
+    s.li = Rgb(L.spectrum);
+    return s;
+  }
   // DiffuseAreaLight::sample_li diffuse.rs:63-79 over Shape::sample_ref shape/mod.rs:33-48
   V3 p, n;
   double pdf;
@@ -1139,7 +1147,7 @@ LightSample light_sample_li(const Scene& sc, const rrt_light& L, V3 ref_p, doubl
   s.li = (dot(n, -s.wi) > 0.0) ? Rgb(L.spectrum) : Rgb();  // AreaLight::l diffuse.rs:133-141
   return s;
 }
-inline bool is_delta_light(const rrt_light& L) { return L.type == RRT_LIGHT_POINT; }
+inline bool is_delta_light(const rrt_light& L) { return L.type == RRT_LIGHT_POINT || L.type == RRT_LIGHT_DISTANT; }  // LIGHT_DELTAPOSITION / _DELTADIRECTION
 
 // pnt3_offset_ray_origin geometry.rs:721-749 with p_error == 0 everywhere (Q8): offset = n*0, sign flips
 // only produce -0.0 components and `offset[i] > 0 / < 0` never fires -> po = p + (+-0).

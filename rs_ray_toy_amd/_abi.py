@@ -16,7 +16,7 @@ RRT_FIX_BVH_LBVH_SLICE, RRT_FIX_BVH_SAH, RRT_SKIP_MIS_BSDF_RAY = 1, 2, 4
 RRT_FIXED_BVH = RRT_FIX_BVH_LBVH_SLICE | RRT_FIX_BVH_SAH
 RRT_PRIM_TRIANGLE, RRT_PRIM_SPHERE = 0, 1
 RRT_MAT_MATTE, RRT_MAT_PLASTIC, RRT_MAT_METAL, RRT_MAT_MIRROR, RRT_MAT_DEBUG = range(5)
-RRT_LIGHT_POINT, RRT_LIGHT_DIFFUSE = 0, 1
+RRT_LIGHT_POINT, RRT_LIGHT_DIFFUSE, RRT_LIGHT_DISTANT = 0, 1, 2
 RRT_SAMPLER_HALTON, RRT_SAMPLER_STRATIFIED = 0, 1
 RRT_FILTER_BOX, RRT_FILTER_TRIANGLE, RRT_FILTER_GAUSSIAN = 0, 1, 2
 RRT_INT_PATH, RRT_INT_DIRECT, RRT_INT_DEBUG, RRT_INT_AO = range(4)
@@ -51,7 +51,8 @@ class Material(C.Structure):
 
 class Light(C.Structure):
     _fields_ = [("type", C.c_int32), ("n_samples", C.c_int32), ("spectrum", C.c_double * 3),
-                ("p_light", C.c_double * 3), ("shape_type", C.c_int32), ("shape", C.c_uint32), ("area", C.c_double)]
+                ("p_light", C.c_double * 3), ("shape_type", C.c_int32), ("shape", C.c_uint32), ("area", C.c_double),
+                ("w_light", C.c_double * 3), ("world_radius", C.c_double)]
 
 
 class BvhNode(C.Structure):

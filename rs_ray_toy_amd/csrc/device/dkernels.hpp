@@ -570,6 +570,13 @@ RRT_DEV Rgb<R> light_sample_li(const Light<R>& L, V3<R> ref_p, R u0, R u1, V3<R>
     *p1 = pl; *n1 = V3<R>();
     return Rgb<R>(L.spectrum) / len2(pl - ref_p);
   }
+  if (L.type == 2) {   // DistantLight::sample_li distant.rs:67-92
+    const V3<R> w(L.w_light);
+    *wi = w;
+    *pdf = R(1);
+    *p1 = ref_p + w * (R(2) * L.world_radius); *n1 = V3<R>();
+    return Rgb<R>(L.spectrum);
+  }
   V3<R> p, n;
   if (L.shape_type == 1) {
     V3<R> p_obj = uniform_sample_sphere(u0, u1) * L.radius;
@@ -659,7 +666,7 @@ RRT_DEV bool estimate_direct_light(const Surf<R>& si, const Bsdf<R>& bsdf, const
   // and keeps t_max = 1 - SHADOW_EPSILON (Q9)
   *so = si.p;
   *sd = vnormalize(p1 - si.p);
-  if (L.type == 0) *ld = f * li / light_pdf;
+  if (L.type != 1) *ld = f * li / light_pdf;   // delta lights (point, distant): no MIS
   else { R w = power_heuristic1(light_pdf, scattering_pdf); *ld = li * f * w / light_pdf; }
   return true;
 }

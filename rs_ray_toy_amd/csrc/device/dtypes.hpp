@@ -69,6 +69,7 @@ struct Light {
   R tp[3][3];                      // triangle vertices
   R tn[3][3];                      // triangle vertex normals (if tri_has_n)
   uint32_t tri_has_n;
+  R w_light[3], world_radius;      // DistantLight (lights/distant.rs)
 };
 
 template <typename R>

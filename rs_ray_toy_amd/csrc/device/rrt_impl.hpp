@@ -549,7 +549,8 @@ class Handle : public HandleBase {
       Light<R>& o = lights[i];
       memset(&o, 0, sizeof(o));
       o.type = l.type; o.shape_type = l.shape_type; o.area = (R)l.area;
-      for (int k = 0; k < 3; k++) { o.spectrum[k] = (R)l.spectrum[k]; o.p_light[k] = (R)l.p_light[k]; }
+      for (int k = 0; k < 3; k++) { o.spectrum[k] = (R)l.spectrum[k]; o.p_light[k] = (R)l.p_light[k]; o.w_light[k] = (R)l.w_light[k]; }
+      o.world_radius = (R)l.world_radius;
       if (l.type == RRT_LIGHT_DIFFUSE && l.shape_type == RRT_PRIM_SPHERE) {
         const rrt_sphere& sp = d->spheres[l.shape];
         affine_rows(d->xforms[sp.xform].m, o.m, "sphere light");

@@ -442,7 +442,19 @@ struct Loader {
       }
     } else if (lt->str == "distant") {
       if (infinite_list) { warn("infinite_lights entry of type distant contributes Le = 0; ignored"); return false; }
-      throw Unsupported("light_type distant is out of scope this round (SURVEY §8f rank 3)");
+      // DistantLight::new lights/distant.rs:23-43 (renderprocess.rs:1018-1031)
+      l.type = RRT_LIGHT_DISTANT;
+      l.n_samples = 1;
+      Rgb li = make_spectrum(lc, "l", 1.0), sc = make_spectrum(lc, "scale", 1.0);
+      for (int k = 0; k < 3; k++) l.spectrum[k] = li.c[k] * sc.c[k];
+      V3 from = fetch_v3(lc, "from", {0, 0, 0}), to = fetch_v3(lc, "to", {0, 0, 1});
+      V3 w = normalize(xf_vector(make_to_world(lc), from - to));
+      l.w_light[0] = w.x; l.w_light[1] = w.y; l.w_light[2] = w.z;
+      // Bounds3f::bounding_sphere(aggregate.world_bound()) geometry.rs:1656-1668
+      const double* wb = s.desc.world_bound;
+      V3 c{(wb[0] + wb[3]) / 2.0, (wb[1] + wb[4]) / 2.0, (wb[2] + wb[5]) / 2.0};
+      bool inside = c.x >= wb[0] && c.x <= wb[3] && c.y >= wb[1] && c.y <= wb[4] && c.z >= wb[2] && c.z <= wb[5];
+      l.world_radius = inside ? length(V3{wb[3], wb[4], wb[5]} - c) : 0.0;
     } else if (lt->str == "infinite") {
       throw Unsupported("light_type infinite needs MIPMap/Distribution2D (out of scope, SURVEY §2 row 24)");
     } else {

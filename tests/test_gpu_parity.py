@@ -130,7 +130,18 @@ def _cfg3_tilted(wd):
     return cfg, root
 
 
+def _cfg4_distant(wd):
+    """cfg4 lit by a DistantLight (lights/distant.rs) next to one point light: delta-direction light, shadow rays aimed at
+    p + w_light * 2 * world_radius (then normalised with t_max = 1 - 1e-4, Q9)."""
+    cfg, root = scenes.cfg4(wd, xres=64, yres=64, nsamp=5, max_depth=6, n=48)
+    cfg["lights"] = [{"light_type": "distant", "l": {"values": [3.0, 2.5, 2.0]}, "scale": {"values": [1.5, 1.5, 1.5]},
+                      "from": [20.0, 30.0, 10.0], "to": [35.0, 0.0, 0.0], "rotation_axis": [0.0, 0.0, 1.0], "rotation_angle": 10},
+                     cfg["lights"][0]]
+    return cfg, root
+
+
 RENDER_CASES = {
+    "cfg4_distant": _cfg4_distant,
     "cfg2_path": lambda wd: scenes.cfg2(wd, xres=96, yres=96, nsamp=9, max_depth=4),
     "cfg3_path": lambda wd: _cfg3_tilted(wd),
     "cfg4_path": lambda wd: scenes.cfg4(wd, xres=64, yres=64, nsamp=5, max_depth=8, n=48),

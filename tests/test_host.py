@@ -214,3 +214,22 @@ def test_resolve_and_png(tmp_path):
     p = str(tmp_path / "o.png")
     write_png(p, out)
     assert np.array_equal(np.array(Image.open(p)), out)
+
+
+def test_distant_light_construction(tmp_path):
+    """DistantLight::new (lights/distant.rs:23-43, renderprocess.rs:1018-1031): w_light = normalize(light_to_world(from - to)),
+    world radius = bounding sphere of the aggregate's world bound (geometry.rs:1656-1668)."""
+    cfg, root = scenes.cfg2(str(tmp_path), xres=16, yres=16, nsamp=2)
+    cfg["lights"] = [{"light_type": "distant", "l": {"values": [2.0, 3.0, 4.0]}, "scale": {"values": [0.5, 0.5, 2.0]},
+                      "from": [1.0, 2.0, 3.0], "to": [0.0, 0.0, 1.0], "rotation_axis": [0.0, 0.0, 1.0], "rotation_angle": 90}]
+    sc = Scene.loads(cfg, root)
+    d = sc.desc
+    assert d.n_lights == 1
+    L = d.lights[0]
+    assert L.type == 2
+    assert list(L.spectrum) == [1.0, 1.5, 8.0]
+    v = np.array([1.0, 2.0, 2.0])                      # from - to, rotated 90 degrees about z: (x, y) -> (-y, x)
+    w = np.array([-v[1], v[0], v[2]]) / np.linalg.norm(v)
+    np.testing.assert_allclose(list(L.w_light), w, atol=1e-15)
+    wb = np.array(list(d.world_bound))
+    assert L.world_radius == pytest.approx(np.linalg.norm(wb[3:] - (wb[:3] + wb[3:]) / 2), rel=1e-15)
