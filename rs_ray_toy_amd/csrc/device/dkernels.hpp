@@ -21,6 +21,7 @@ enum { ERR_SHADING_NORMAL = 1, ERR_STACK = 2, ERR_BETA = 4 };
 template <typename R>
 struct RayCtx {
   V3<R> o, d, inv;
+  V3<R> lo;   // o = o_hi + lo (fp32 spawned rays; zero otherwise)
   int neg[3];
   R tmax;
 };
@@ -32,9 +33,11 @@ RRT_DEV uint32_t real_to_bits(float v) { return __float_as_uint(v); }
 RRT_DEV uint32_t real_to_bits(double v) { return (uint32_t)__double_as_longlong(v); }
 template <typename R> RRT_DEV typename Vec4T<R>::type mk4(R x, R y, R z, R w) { typename Vec4T<R>::type v; v.x = x; v.y = y; v.z = z; v.w = w; return v; }
 template <typename R> RRT_DEV typename Vec4T<R>::type mk4u(R x, R y, R z, uint32_t w) { return mk4<R>(x, y, z, bits_to_real(w, R(0))); }
-template <typename R> RRT_DEV void store_ray(typename Vec4T<R>::type* ro, typename Vec4T<R>::type* rd, uint32_t i, V3<R> o, V3<R> d, R tmax, int skip) {
+template <typename R> RRT_DEV void store_ray(typename Vec4T<R>::type* ro, typename Vec4T<R>::type* rd, typename Vec4T<R>::type* rl, uint32_t i, V3<R> o, V3<R> lo,
+                                             V3<R> d, R tmax, int skip) {
   ro[i] = mk4<R>(o.x, o.y, o.z, tmax);
   rd[i] = mk4u<R>(d.x, d.y, d.z, (uint32_t)skip);
+  rl[i] = mk4<R>(lo.x, lo.y, lo.z, R(0));
 }
 
 // Bounds3::intersect_p geometry.rs:1767-1800 with gamma(3) of the arithmetic type
@@ -69,6 +72,7 @@ RRT_DEV bool tri_closest(const Tri<R>& t, const RayCtx<R>& r, R* th, R* uh, R* v
   if (a > R(-0.0000001) && a < R(0.0000001)) return false;
   R f = rcp_r(a);
   V3<R> T = r.o - p0;
+  if (sizeof(R) == 4) T = T + r.lo;   // double-float origin: o_hi - p0 is exact for nearby vertices
   R u = f * dot(T, P);
   if (u < R(0) || u > R(1)) return false;
   V3<R> Q = cross(T, E1);
@@ -89,6 +93,7 @@ RRT_DEV bool tri_any(const Tri<R>& t, const RayCtx<R>& r) {
   if (a > R(-0.0000001) && a < R(0.0000001)) return false;
   R f = rcp_r(a);
   V3<R> T = r.o - p0;
+  if (sizeof(R) == 4) T = T + r.lo;   // double-float origin: o_hi - p0 is exact for nearby vertices
   R u = f * dot(T, P);
   if (u < R(0) || u > R(1)) return false;
   V3<R> Q = cross(T, E1);
@@ -100,9 +105,9 @@ RRT_DEV bool tri_any(const Tri<R>& t, const RayCtx<R>& r) {
 }
 
 template <typename R>
-RRT_DEV RayCtx<R> make_ctx(V3<R> o, V3<R> d, R tmax) {
+RRT_DEV RayCtx<R> make_ctx(V3<R> o, V3<R> d, R tmax, V3<R> lo = V3<R>()) {
   RayCtx<R> c;
-  c.o = o; c.d = d; c.tmax = tmax;
+  c.o = o; c.d = d; c.tmax = tmax; c.lo = lo;
   c.inv = V3<R>(R(1) / d.x, R(1) / d.y, R(1) / d.z);
   c.neg[0] = c.inv.x < R(0); c.neg[1] = c.inv.y < R(0); c.neg[2] = c.inv.z < R(0);
   return c;
@@ -289,8 +294,8 @@ __global__ void __launch_bounds__(kBlock) k_closest(SceneDev<R> s, Pools<R> p, c
   const uint32_t i = blockIdx.x * blockDim.x + threadIdx.x;
   const uint32_t n = count ? *count : n_fixed;
   if (i >= n) return;
-  const typename Vec4T<R>::type ro = p.ray_o[i], rd = p.ray_d[i];
-  RayCtx<R> r = make_ctx(V3<R>(ro.x, ro.y, ro.z), V3<R>(rd.x, rd.y, rd.z), ro.w);
+  const typename Vec4T<R>::type ro = p.ray_o[i], rd = p.ray_d[i], rl = p.ray_l[i];
+  RayCtx<R> r = make_ctx(V3<R>(ro.x, ro.y, ro.z), V3<R>(rd.x, rd.y, rd.z), ro.w, V3<R>(rl.x, rl.y, rl.z));
   R hu = 0, hv = 0;
   uint32_t nn = 0, np = 0;
   int hit;
@@ -320,8 +325,8 @@ __global__ void __launch_bounds__(kBlock) k_shadow(SceneDev<R> s, Pools<R> p, co
                                                     uint32_t* deep_stack, uint32_t deep_stride, unsigned long long* totals) {
   const uint32_t i = blockIdx.x * blockDim.x + threadIdx.x;
   if (i >= *count) return;
-  const typename Vec4T<R>::type ro = p.sray_o[i], rd = p.sray_d[i];
-  RayCtx<R> r = make_ctx(V3<R>(ro.x, ro.y, ro.z), V3<R>(rd.x, rd.y, rd.z), ro.w);
+  const typename Vec4T<R>::type ro = p.sray_o[i], rd = p.sray_d[i], rl = p.sray_l[i];
+  RayCtx<R> r = make_ctx(V3<R>(ro.x, ro.y, ro.z), V3<R>(rd.x, rd.y, rd.z), ro.w, V3<R>(rl.x, rl.y, rl.z));
   uint32_t nn = 0, np = 0;
   bool occ;
   const int skip = (int)real_to_bits(rd.w);
@@ -337,7 +342,7 @@ __global__ void __launch_bounds__(kBlock) k_pack_rays(Pools<R> p, const R* ox, c
                                                        const int32_t* skip, uint32_t n) {
   const uint32_t i = blockIdx.x * blockDim.x + threadIdx.x;
   if (i >= n) return;
-  store_ray<R>(p.ray_o, p.ray_d, i, V3<R>(ox[i], oy[i], oz[i]), V3<R>(dx[i], dy[i], dz[i]), tmax[i], skip ? skip[i] : -1);
+  store_ray<R>(p.ray_o, p.ray_d, p.ray_l, i, V3<R>(ox[i], oy[i], oz[i]), V3<R>(), V3<R>(dx[i], dy[i], dz[i]), tmax[i], skip ? skip[i] : -1);
 }
 template <typename R>
 __global__ void __launch_bounds__(kBlock) k_unpack_hits(Pools<R> p, R* t, int32_t* prim, R* u, R* v, uint32_t n) {
@@ -354,8 +359,8 @@ template <typename R, bool DEEP>
 __global__ void __launch_bounds__(kBlock) k_any_public(SceneDev<R> s, Pools<R> p, uint32_t n, uint8_t* occluded, uint32_t* deep_stack, uint32_t deep_stride) {
   const uint32_t i = blockIdx.x * blockDim.x + threadIdx.x;
   if (i >= n) return;
-  const typename Vec4T<R>::type ro = p.ray_o[i], rd = p.ray_d[i];
-  RayCtx<R> r = make_ctx(V3<R>(ro.x, ro.y, ro.z), V3<R>(rd.x, rd.y, rd.z), ro.w);
+  const typename Vec4T<R>::type ro = p.ray_o[i], rd = p.ray_d[i], rl = p.ray_l[i];
+  RayCtx<R> r = make_ctx(V3<R>(ro.x, ro.y, ro.z), V3<R>(rd.x, rd.y, rd.z), ro.w, V3<R>(rl.x, rl.y, rl.z));
   uint32_t nn, np;
   bool occ;
   const int skip = (int)real_to_bits(rd.w);
@@ -408,7 +413,7 @@ __global__ void __launch_bounds__(kBlock) k_raygen(SceneDev<R> s, Pools<R> p, Pa
     p.weight[slot] = alive ? w : R(0);
     p.pfx[slot] = pfx; p.pfy[slot] = pfy;
     if (alive) {
-      store_ray<R>(p.nray_o, p.nray_d, slot, ray.o, ray.d, Const<R>::inf, -1);
+      store_ray<R>(p.nray_o, p.nray_d, p.nray_l, slot, ray.o, V3<R>(), ray.d, Const<R>::inf, -1);
       p.lensx[slot] = lx; p.lensy[slot] = ly;
     }
     if (dbg_dims) {
@@ -452,7 +457,7 @@ __global__ void __launch_bounds__(kBlock) k_raygen_aux(SceneDev<R> s, Pools<R> p
   if (enq) {
     p.q_active[q] = QEnt{slot, 5u};   // five camera dimensions consumed, bounce 0
     p.path[q] = mk4u<R>(R(1), R(1), R(1), p.hindex[slot]);
-    p.ray_o[q] = p.nray_o[slot]; p.ray_d[q] = p.nray_d[slot];
+    p.ray_o[q] = p.nray_o[slot]; p.ray_d[q] = p.nray_d[slot]; p.ray_l[q] = p.nray_l[slot];
   }
   if (alive) p.L[slot] = mk4<R>(R(0), R(0), R(0), R(0));
   (void)block_push(&p.counters[C_CAMERA_RAYS], alive, push_lds);
@@ -482,10 +487,28 @@ __global__ void __launch_bounds__(kBlock) k_camera_dump(Pools<R> p, PassDesc pd,
 // ------------------------------------------------------------------------------------------------------------
 template <typename R>
 struct Surf {   // the parts of SurfaceInteraction (interaction.rs:95-181) the in-scope materials read
-  V3<R> p, n, wo, sn, sdpdu;
+  V3<R> p, p_lo, n, wo, sn, sdpdu;   // p_lo: see spawn_point()
   uint32_t material;
   bool ok;
 };
+
+// Hit point. The reference uses o + d * t in f64 and then relies on its `t < 1e-7` rejection to swallow the ~1e-15
+// by which that point misses the surface. In fp32 the same expression misses by ~3e-6 at scene coordinates of ~50,
+// more than the threshold: a spawned ray that starts just below the plane of the *adjacent* triangle (origin within
+// ~1e-4 of a shared edge) then "hits" it at t ~ 1e-5 - about 1e-4 of all shadow rays on the 100k-triangle config,
+// 3-4 % of its pixels off by a whole sample. So the fp32 mode builds the point from the barycentrics on the stored
+// (fp32) triangle as an unevaluated sum p_hi + p_lo (TwoSum), and the triangle tests form (o_hi - p0) + o_lo:
+// o_hi - p0 is exact for nearby vertices, so the origin lies on its triangle to ~1e-9 and on the right side of every
+// neighbour. f64 mode: the reference expression, p_lo = 0.
+template <typename R>
+RRT_DEV void spawn_point(V3<R> o, V3<R> d, R t, R u, R v, V3<R> p0, V3<R> p1, V3<R> p2, V3<R>* p, V3<R>* p_lo) {
+  if (sizeof(R) == 8) { *p = o + d * t; *p_lo = V3<R>(); return; }
+  const V3<R> w = (p1 - p0) * u + (p2 - p0) * v;
+  const V3<R> s = p0 + w;
+  const V3<R> bb = s - p0;
+  *p = s;
+  *p_lo = (p0 - (s - bb)) + (w - bb);
+}
 
 // Triangle::intersect's SurfaceInteraction (shape/triangle.rs:267-390) rebuilt from (triangle, t, u, v)
 template <typename R>
@@ -496,7 +519,7 @@ RRT_DEV Surf<R> build_surface(const SceneDev<R>& s, int prim, V3<R> o, V3<R> d, 
     SphereSI<R> ss;
     R th;
     si.ok = sphere_prim_hit<R, false>(s.spheres[tr.shade], o, d, &th, &ss);
-    si.p = ss.p; si.n = ss.n; si.wo = ss.wo; si.sn = ss.sn; si.sdpdu = ss.sdpdu;
+    si.p = ss.p; si.p_lo = V3<R>(); si.n = ss.n; si.wo = ss.wo; si.sn = ss.sn; si.sdpdu = ss.sdpdu;
     si.material = tr.material;
     if (!(dot(si.n, si.sn) >= R(0))) si.ok = false;   // primitives.rs:66
     return si;
@@ -525,7 +548,7 @@ RRT_DEV Surf<R> build_surface(const SceneDev<R>& s, int prim, V3<R> o, V3<R> d, 
     V3<R> ng = cross(p2 - p0, p1 - p0);
     coordinate_system(vnormalize(ng), &dpdu, &dpdv);
   }
-  si.p = o + d * t;
+  spawn_point(o, d, t, u, v, p0, p1, p2, &si.p, &si.p_lo);
   si.wo = -d;
   si.n = vnormalize(cross(dp02, dp12));
   si.sn = si.n;
@@ -695,7 +718,7 @@ __global__ void __launch_bounds__(ShadeBlock<R>::n) k_shade_path(SceneDev<R> s, 
   bool want_shadow = false, want_next = false;
   uint32_t slot = 0;
   int prim = -1;
-  V3<R> sh_o, sh_d, nx_o, nx_d;   // shadow ray / next ray + path state, stored at their queue positions at the end
+  V3<R> sh_o, sh_d, nx_o, nx_d, o_lo;   // shadow ray / next ray + path state, stored at their queue positions at the end
   Rgb<R> sh_ld, nx_beta;
   uint32_t index = 0, nx_db = 0;
   if (i < n) {
@@ -731,6 +754,7 @@ __global__ void __launch_bounds__(ShadeBlock<R>::n) k_shade_path(SceneDev<R> s, 
             want_shadow = true;
           }
         }
+        o_lo = si.p_lo;
         // Sample BSDF to get new path direction (:125-148)
         R u0 = to_real<R>(halton_dim(s, index, dim)), u1 = to_real<R>(halton_dim(s, index, dim + 1));
         dim += 2;
@@ -766,14 +790,14 @@ __global__ void __launch_bounds__(ShadeBlock<R>::n) k_shade_path(SceneDev<R> s, 
   }
   const uint32_t qs = block_push(&p.counters[C_SHADOW], want_shadow, push_lds);
   if (want_shadow) {
-    store_ray<R>(p.sray_o, p.sray_d, qs, sh_o, sh_d, R(1) - R(0.0001), self_prim<R>(prim));
+    store_ray<R>(p.sray_o, p.sray_d, p.sray_l, qs, sh_o, o_lo, sh_d, R(1) - R(0.0001), self_prim<R>(prim));
     p.sld[qs] = mk4u<R>(sh_ld.r, sh_ld.g, sh_ld.b, slot);
   }
   const uint32_t qn = block_push(&p.counters[C_NEXT], want_next, push_lds);
   if (want_next) {
     p.q_next[qn] = QEnt{slot, nx_db};
     p.npath[qn] = mk4u<R>(nx_beta.r, nx_beta.g, nx_beta.b, index);
-    store_ray<R>(p.nray_o, p.nray_d, qn, nx_o, nx_d, Const<R>::inf, self_prim<R>(prim));
+    store_ray<R>(p.nray_o, p.nray_d, p.nray_l, qn, nx_o, o_lo, nx_d, Const<R>::inf, self_prim<R>(prim));
   }
 }
 
@@ -790,7 +814,7 @@ __global__ void __launch_bounds__(ShadeBlock<R>::n) k_shade_nee(SceneDev<R> s, P
   bool want_shadow = false;
   uint32_t slot = 0;
   int prim = -1;
-  V3<R> sh_o, sh_d;
+  V3<R> sh_o, sh_d, o_lo;
   Rgb<R> sh_ld;
   if (i < n) {
     const QEnt qe = p.q_active[i];
@@ -832,7 +856,7 @@ __global__ void __launch_bounds__(ShadeBlock<R>::n) k_shade_nee(SceneDev<R> s, P
         Rgb<R> ld;
         if (estimate_direct_light(si, bsdf, s.lights[ln], ul0, ul1, &so, &sd, &ld)) {
           sh_ld = beta * (ld / pick_pdf);
-          sh_o = so; sh_d = sd;
+          sh_o = so; sh_d = sd; o_lo = si.p_lo;
           want_shadow = true;
         }
         p.q_active[i].db = (dim & 0xffffu) | (db & 0xffff0000u);
@@ -841,7 +865,7 @@ __global__ void __launch_bounds__(ShadeBlock<R>::n) k_shade_nee(SceneDev<R> s, P
   }
   const uint32_t qs = block_push(&p.counters[C_SHADOW], want_shadow, push_lds);
   if (want_shadow) {
-    store_ray<R>(p.sray_o, p.sray_d, qs, sh_o, sh_d, R(1) - R(0.0001), self_prim<R>(prim));
+    store_ray<R>(p.sray_o, p.sray_d, p.sray_l, qs, sh_o, o_lo, sh_d, R(1) - R(0.0001), self_prim<R>(prim));
     p.sld[qs] = mk4u<R>(sh_ld.r, sh_ld.g, sh_ld.b, slot);
   }
 }
@@ -859,7 +883,7 @@ __global__ void __launch_bounds__(ShadeBlock<R>::n) k_shade_specular(SceneDev<R>
   bool want_next = false;
   uint32_t slot = 0;
   int prim = -1;
-  V3<R> nx_o, nx_d;
+  V3<R> nx_o, nx_d, o_lo;
   Rgb<R> nx_beta;
   uint32_t index = 0, nx_db = 0;
   if (i < n) {
@@ -894,7 +918,7 @@ __global__ void __launch_bounds__(ShadeBlock<R>::n) k_shade_specular(SceneDev<R>
           Rgb<R> f = bsdf.sample_f(si.wo, &wi, u0, u1, &pdf, BXDF_SPECULAR | BXDF_REFLECTION, &st);
           if (pdf > R(0) && !f.is_black() && absdot(wi, si.sn) != R(0)) {
             nx_beta = beta * (f * absdot(wi, si.sn) / pdf);
-            nx_o = si.p; nx_d = vnormalize(wi);
+            nx_o = si.p; nx_d = vnormalize(wi); o_lo = si.p_lo;
             nx_db = (dim & 0xffffu) | (depth << 16);
             want_next = true;
           }
@@ -906,7 +930,7 @@ __global__ void __launch_bounds__(ShadeBlock<R>::n) k_shade_specular(SceneDev<R>
   if (want_next) {
     p.q_next[qn] = QEnt{slot, nx_db};
     p.npath[qn] = mk4u<R>(nx_beta.r, nx_beta.g, nx_beta.b, index);
-    store_ray<R>(p.nray_o, p.nray_d, qn, nx_o, nx_d, Const<R>::inf, self_prim<R>(prim));
+    store_ray<R>(p.nray_o, p.nray_d, p.nray_l, qn, nx_o, o_lo, nx_d, Const<R>::inf, self_prim<R>(prim));
   }
 }
 

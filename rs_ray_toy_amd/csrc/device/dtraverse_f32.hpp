@@ -38,6 +38,7 @@ RRT_DEV F4 ld4(const float* p) { const float4 v = *reinterpret_cast<const float4
 
 struct LaneRay {
   float ox, oy, oz, dx, dy, dz, ix, iy, iz, tmax;
+  float lx, ly, lz;   // low word of the double-float origin (dkernels.hpp spawn_point())
   uint32_t neg;       // bit k: inv_dir[k] < 0
   uint32_t skip_plane;
 };
@@ -78,7 +79,7 @@ RRT_DEV bool tri_test_f32(const float* tp, const LaneRay& r, float* th, float* u
   const V3<float> P = cross(D, E2);
   const float a = dot(E1, P);
   const float f = rcp_r(a);
-  const V3<float> T = O - p0;
+  const V3<float> T = (O - p0) + V3<float>(r.lx, r.ly, r.lz);
   const float u = f * dot(T, P);
   const V3<float> Q = cross(T, E1);
   const float v = f * dot(D, Q);
@@ -124,7 +125,9 @@ __global__ void __launch_bounds__(kTravBlock) k_trace_pairs_f32(TravScene ts, Po
   int sk;
   {
     const float4 ro = (ANY && !occluded) ? p.sray_o[gid] : p.ray_o[gid], rd = (ANY && !occluded) ? p.sray_d[gid] : p.ray_d[gid];
+    const float4 rl = (ANY && !occluded) ? p.sray_l[gid] : p.ray_l[gid];
     r.ox = ro.x; r.oy = ro.y; r.oz = ro.z; r.tmax = ro.w; r.dx = rd.x; r.dy = rd.y; r.dz = rd.z; sk = (int)__float_as_uint(rd.w);
+    r.lx = rl.x; r.ly = rl.y; r.lz = rl.z;
   }
   r.skip_plane = sk >= 0 ? __float_as_uint(ts.tris[(size_t)sk * 12 + 11]) : 0xffffffffu;
   r.ix = 1.0f / r.dx; r.iy = 1.0f / r.dy; r.iz = 1.0f / r.dz;
@@ -246,7 +249,7 @@ __global__ void __launch_bounds__(kPtBlock) k_trace_pt_f32(TravScene ts, Pools<f
   enum { ST_IDLE = 0, ST_NODE = 1, ST_TRI = 2 };
   int state = ST_IDLE;
   LaneRay r;
-  r.ox = r.oy = r.oz = r.dx = r.dy = r.dz = r.ix = r.iy = r.iz = r.tmax = 0.0f; r.neg = 0; r.skip_plane = 0xffffffffu;
+  r.ox = r.oy = r.oz = r.dx = r.dy = r.dz = r.ix = r.iy = r.iz = r.tmax = r.lx = r.ly = r.lz = 0.0f; r.neg = 0; r.skip_plane = 0xffffffffu;
   uint32_t qidx = 0, cur = 0, sp = 0, lf = 0, ln = 0;
   int hit = -1;
   float hu = 0.0f, hv = 0.0f;
@@ -308,7 +311,9 @@ __global__ void __launch_bounds__(kPtBlock) k_trace_pt_f32(TravScene ts, Pools<f
           int sk;
           {
             const float4 ro = (ANY && !occluded) ? p.sray_o[qidx] : p.ray_o[qidx], rd = (ANY && !occluded) ? p.sray_d[qidx] : p.ray_d[qidx];
+            const float4 rl = (ANY && !occluded) ? p.sray_l[qidx] : p.ray_l[qidx];
             r.ox = ro.x; r.oy = ro.y; r.oz = ro.z; r.tmax = ro.w; r.dx = rd.x; r.dy = rd.y; r.dz = rd.z; sk = (int)__float_as_uint(rd.w);
+            r.lx = rl.x; r.ly = rl.y; r.lz = rl.z;
           }
           r.skip_plane = sk >= 0 ? __float_as_uint(ts.tris[(size_t)sk * 12 + 11]) : 0xffffffffu;
           r.ix = 1.0f / r.dx; r.iy = 1.0f / r.dy; r.iz = 1.0f / r.dz;
@@ -519,7 +524,7 @@ static __global__ void __launch_bounds__(kRgBlock) k_raygen_pt_f32(SceneDev<floa
             const RayT<float> rc = flip_z(rl);
             const V3<float> wo = aff_pt(s.cam_m, rc.o);
             const V3<float> wd = vnormalize(vnormalize(vnormalize(aff_vec(s.cam_m, rc.d))));
-            store_ray<float>(p.nray_o, p.nray_d, slot, wo, wd, Const<float>::inf, -1);   // by slot, until k_compact_alive
+            store_ray<float>(p.nray_o, p.nray_d, p.nray_l, slot, wo, V3<float>(), wd, Const<float>::inf, -1);   // by slot, until k_compact_alive
             L.phase = 1; begin = true;
           }
         } else if (L.phase == 1) { L.phase = pass ? 3 : 2; begin = true; }
@@ -567,7 +572,7 @@ static __global__ void __launch_bounds__(kBlock) k_compact_alive(Pools<float> p,
       const uint32_t q = out + (uint32_t)__popcll(m & ((1ull << lane) - 1ull));
       p.q_active[q] = QEnt{(uint32_t)slot, 5u};   // five camera dimensions consumed, bounce 0
       p.path[q] = make_float4(1.0f, 1.0f, 1.0f, __uint_as_float(p.hindex[slot]));
-      p.ray_o[q] = p.nray_o[slot]; p.ray_d[q] = p.nray_d[slot];
+      p.ray_o[q] = p.nray_o[slot]; p.ray_d[q] = p.nray_d[slot]; p.ray_l[q] = make_float4(0.0f, 0.0f, 0.0f, 0.0f);
       p.L[slot] = make_float4(0.0f, 0.0f, 0.0f, 0.0f);
     }
     out += (uint32_t)__popcll(m);
