@@ -32,7 +32,7 @@
 extern "C" {
 #endif
 
-#define RRT_ABI_VERSION 2
+#define RRT_ABI_VERSION 3
 
 /* ---- error codes ------------------------------------------------------- */
 enum {
@@ -58,7 +58,8 @@ enum {
 /* ---- enums mirrored from the reference's scene.json vocabulary ---------- */
 enum { RRT_PRIM_TRIANGLE = 0, RRT_PRIM_SPHERE = 1 };
 enum { /* material_type, renderprocess.rs:664-871 */
-  RRT_MAT_MATTE = 0, RRT_MAT_PLASTIC = 1, RRT_MAT_METAL = 2, RRT_MAT_MIRROR = 3, RRT_MAT_DEBUG = 4
+  RRT_MAT_MATTE = 0, RRT_MAT_PLASTIC = 1, RRT_MAT_METAL = 2, RRT_MAT_MIRROR = 3, RRT_MAT_DEBUG = 4,
+  RRT_MAT_GLASS = 5, RRT_MAT_TRANSLUCENT = 6   /* material/glass.rs, material/translucent.rs (Path integrator only) */
 };
 enum { RRT_LIGHT_POINT = 0, RRT_LIGHT_DIFFUSE = 1, RRT_LIGHT_DISTANT = 2 };  /* renderprocess.rs:991-1031 */
 enum { RRT_SAMPLER_HALTON = 0, RRT_SAMPLER_STRATIFIED = 1 };    /* renderprocess.rs:1306-1325 */
@@ -109,6 +110,9 @@ typedef struct rrt_material {
   double kd[3], ks[3], kr[3];
   double eta[3], k[3];
   double sigma, roughness, u_roughness, v_roughness;
+  double kt[3];         /* glass */
+  double reflect[3], transmit[3];   /* translucent */
+  double index;         /* glass "eta" (a float texture there; `eta` above is MetalMaterial's spectrum) */
 } rrt_material;
 
 /* PointLight lights/point.rs:13-19, DiffuseAreaLight lights/diffuse.rs:13-22 */

@@ -765,7 +765,7 @@ bool scene_intersect_p(const Scene& sc, const Ray& r, Counters* cnt, uint32_t* n
 
 // ---- BxDFs / Bsdf (reflection.rs, microfacet.rs) ------------------------------------------------------
 enum : uint8_t { BXDF_REFLECTION = 1, BXDF_TRANSMISSION = 2, BXDF_DIFFUSE = 4, BXDF_GLOSSY = 8, BXDF_SPECULAR = 16, BXDF_ALL = 31, BXDF_NONE = 0 };
-enum LobeKind { LAMBERT, OREN_NAYAR, MICROFACET, SPEC_REFL, DEBUG_DIFFUSE, DEBUG_SPECULAR };
+enum LobeKind { LAMBERT, OREN_NAYAR, MICROFACET, SPEC_REFL, DEBUG_DIFFUSE, DEBUG_SPECULAR, SPEC_TRANS, FRESNEL_SPEC, LAMBERT_TRANS, MICROFACET_TRANS };
 enum FresnelKind { FR_NOOP, FR_DIELECTRIC, FR_CONDUCTOR };
 
 inline double cos_theta(V3 w) { return w.z; }
@@ -819,7 +819,18 @@ struct Lobe {
   double alpha_x = 0, alpha_y = 0;   // TrowbridgeReitz (sample_visible_area = true)
   FresnelKind fr = FR_NOOP;
   Rgb eta_i, eta_t, k;               // conductor;  dielectric uses eta_i.c[0], eta_t.c[0]
+  Rgb t;                             // transmission colour (FresnelSpecular carries r and t)
+  double eta_a = 1.0, eta_b = 1.0;   // transmissive lobes (always 1.0 / material eta)
 };
+inline bool bsdf_refract(V3 wi, V3 n, double eta, V3* wt) {  // reflection.rs:122-134
+  double cos_i = dot(n, wi);
+  double sin2_i = rmax(0.0, 1.0 - cos_i * cos_i);
+  double sin2_t = eta * eta * sin2_i;
+  if (sin2_t >= 1.0) return false;
+  double cos_t = std::sqrt(1.0 - sin2_t);
+  *wt = (-wi) * eta + n * (eta * cos_i - cos_t);
+  return true;
+}
 
 // TrowbridgeReitzDistribution microfacet.rs:253-425
 double tr_d(const Lobe& l, V3 wh) {
@@ -910,6 +921,21 @@ Rgb lobe_f(const Lobe& l, V3 wo, V3 wi) {
       return l.r * tr_d(l, wh) * tr_g(l, wo, wi) * f / (4.0 * cos_i * cos_o);
     }
     case SPEC_REFL: return Rgb();   // :635-637
+    case SPEC_TRANS: case FRESNEL_SPEC: return Rgb();   // :682-684, :750-752
+    case LAMBERT_TRANS: return l.t / PI;                 // :854-856
+    case MICROFACET_TRANS: {                             // :1059-1097 (mode = Radiance)
+      if (same_hemisphere(wo, wi)) return Rgb();
+      double cos_o = cos_theta(wo), cos_i = cos_theta(wi);
+      if (cos_i == 0.0 || cos_o == 0.0) return Rgb();
+      double eta = cos_theta(wo) > 0.0 ? l.eta_b / l.eta_a : l.eta_a / l.eta_b;
+      V3 wh = vnormalize(wo + wi * eta);
+      if (wh.z < 0.0) wh = -wh;
+      double f = fr_dielectric(dot(wo, wh), l.eta_a, l.eta_b);
+      double sqrt_denom = dot(wo, wh) + eta * dot(wi, wh);
+      double factor = 1.0 / eta;
+      return (Rgb(1.0) - Rgb(f)) * l.t *
+             std::fabs(tr_d(l, wh) * tr_g(l, wo, wi) * eta * eta * absdot(wi, wh) * absdot(wo, wh) * factor * factor / (cos_i * cos_o * sqrt_denom * sqrt_denom));
+    }
     case DEBUG_DIFFUSE: return Rgb(0.0, 1.0, 0.0);   // debug_material.rs:13-15
     case DEBUG_SPECULAR: return Rgb(0.0, 0.0, 1.0);  // debug_material.rs:25-27
   }
@@ -921,10 +947,54 @@ double lobe_pdf(const Lobe& l, V3 wo, V3 wi) {
     V3 wh = vnormalize(wo + wi);
     return tr_pdf(l, wo, wh) / (4.0 * dot(wo, wh));
   }
-  if (l.kind == SPEC_REFL) return 0.0;
+  if (l.kind == SPEC_REFL || l.kind == SPEC_TRANS || l.kind == FRESNEL_SPEC) return 0.0;
+  if (l.kind == LAMBERT_TRANS) return !same_hemisphere(wo, wi) ? abs_cos_theta(wi) / PI : 0.0;  // :887-893
+  if (l.kind == MICROFACET_TRANS) {  // :1124-1144
+    if (same_hemisphere(wo, wi)) return 0.0;
+    double eta = cos_theta(wo) > 0.0 ? l.eta_b / l.eta_a : l.eta_a / l.eta_b;
+    V3 wh = vnormalize(wo + wi * eta);
+    double sqrt_denom = dot(wo, wh) + dot(wi, wh) * eta;
+    double dwh_dwi = std::fabs((eta * eta * dot(wi, wh)) / (sqrt_denom * sqrt_denom));
+    return tr_pdf(l, wo, wh) * dwh_dwi;
+  }
   return same_hemisphere(wo, wi) ? abs_cos_theta(wi) / PI : 0.0;  // BxDF::pdf default :492-498
 }
-Rgb lobe_sample_f(const Lobe& l, V3 wo, V3* wi, double u0, double u1, double* pdf) {
+Rgb lobe_sample_f(const Lobe& l, V3 wo, V3* wi, double u0, double u1, double* pdf, uint8_t* sampled_type = nullptr) {
+  if (l.kind == SPEC_TRANS || l.kind == FRESNEL_SPEC) {  // :690-716, :754-795 (mode = Radiance)
+    double fr = 0.0;
+    if (l.kind == FRESNEL_SPEC) {
+      fr = fr_dielectric(cos_theta(wo), l.eta_a, l.eta_b);
+      if (u0 < fr) {
+        *wi = V3(-wo.x, -wo.y, wo.z);
+        if (sampled_type) *sampled_type = BXDF_SPECULAR | BXDF_REFLECTION;
+        *pdf = fr;
+        return l.r * fr / abs_cos_theta(*wi);
+      }
+    }
+    bool entering = cos_theta(wo) > 0.0;
+    double eta_i = entering ? l.eta_a : l.eta_b, eta_t = entering ? l.eta_b : l.eta_a;
+    if (!bsdf_refract(wo, faceforward(V3(0.0, 0.0, 1.0), wo), eta_i / eta_t, wi)) return Rgb();
+    Rgb ft;
+    if (l.kind == FRESNEL_SPEC) { ft = l.t * (1.0 - fr); *pdf = 1.0 - fr; if (sampled_type) *sampled_type = BXDF_SPECULAR | BXDF_TRANSMISSION; }
+    else { ft = l.t * (Rgb(1.0) - Rgb(fr_dielectric(cos_theta(*wi), l.eta_a, l.eta_b))); *pdf = 1.0; }
+    ft = ft * ((eta_i * eta_i) / (eta_t * eta_t));
+    return ft / abs_cos_theta(*wi);
+  }
+  if (l.kind == LAMBERT_TRANS) {  // :857-869
+    *wi = cosine_sample_hemisphere(u0, u1);
+    if (wo.z > 0.0) wi->z *= -1.0;
+    *pdf = lobe_pdf(l, wo, *wi);
+    return lobe_f(l, wo, *wi);
+  }
+  if (l.kind == MICROFACET_TRANS) {  // :1098-1123
+    if (wo.z == 0.0) return Rgb();
+    V3 wh = tr_sample_wh(l, wo, u0, u1);
+    if (dot(wo, wh) < 0.0) return Rgb();
+    double eta = cos_theta(wo) > 0.0 ? l.eta_a / l.eta_b : l.eta_b / l.eta_a;
+    if (!bsdf_refract(wo, wh, eta, wi)) return Rgb();
+    *pdf = lobe_pdf(l, wo, *wi);
+    return lobe_f(l, wo, *wi);
+  }
   if (l.kind == MICROFACET) {  // :993-1018
     if (wo.z == 0.0) return Rgb();
     V3 wh = tr_sample_wh(l, wo, u0, u1);
@@ -957,6 +1027,7 @@ struct Bsdf {  // reflection.rs:205-405
   Lobe lobes[8];
   int n = 0;
   bool present = false;
+  double eta = 1.0;   // Bsdf::new(si, eta): only glass / translucent pass something else than 1
 
   void init(const SI& si) {  // Bsdf::new :215-226
     ns = si.sn; ss = vnormalize(si.sdpdu); ng = si.n; ts = cross(ns, ss); n = 0; present = true;
@@ -1003,7 +1074,7 @@ struct Bsdf {  // reflection.rs:205-405
     if (wo.z == 0.0) return Rgb();  // pdf / sampled_type are left as the caller initialised them
     *pdf_out = 0.0;
     *sampled = bx.type;
-    Rgb f = lobe_sample_f(bx, wo, &wi, ur0, ur1, pdf_out);
+    Rgb f = lobe_sample_f(bx, wo, &wi, ur0, ur1, pdf_out, sampled);
     if (*pdf_out == 0.0) { *sampled = BXDF_NONE; return Rgb(); }
     *wi_w = to_world(wi);
     if (!(bx.type & BXDF_REFLECTION) && matching > 1)
@@ -1014,7 +1085,7 @@ struct Bsdf {  // reflection.rs:205-405
 };
 
 // Material::compute_scattering_functions for the in-scope materials (constant textures)
-void compute_scattering(const Scene& sc, const SI& si, Bsdf* bsdf) {
+void compute_scattering(const Scene& sc, const SI& si, Bsdf* bsdf, bool allow_multiple_lobes = true) {
   if (!(dot(si.n, si.sn) >= 0.0)) throw OraclePanic{"primitives.rs:100 assert!(dot3(&si.ist.n, &si.shading.n) >= 0.0)"};
   const rrt_material& m = sc.d->materials[sc.d->prims[si.prim].material];
   bsdf->init(si);
@@ -1064,6 +1135,59 @@ void compute_scattering(const Scene& sc, const SI& si, Bsdf* bsdf) {
     case RRT_MAT_DEBUG: {  // debug_material.rs:37-48
       Lobe a; a.kind = DEBUG_DIFFUSE; a.type = BXDF_DIFFUSE | BXDF_REFLECTION; bsdf->add(a);
       Lobe b; b.kind = DEBUG_SPECULAR; b.type = BXDF_SPECULAR | BXDF_REFLECTION; bsdf->add(b);
+      break;
+    }
+    case RRT_MAT_GLASS: {  // glass.rs:52-112 (allow_multiple_lobes as passed by the integrator, mode = Radiance)
+      if (sc.d->integrator.type != RRT_INT_PATH) throw OraclePanic{"transmissive materials are in scope for the Path integrator only (specular_transmit branches, integrator/mod.rs:199-301)"};
+      double eta = m.index, ur = m.u_roughness, vr = m.v_roughness;
+      Rgb r = rclamp0(Rgb(m.kr)), t = rclamp0(Rgb(m.kt));
+      bsdf->eta = eta;
+      if (r.is_black() && t.is_black()) throw OraclePanic{"glass.rs:70 null BSDF: path.rs:103 `bounces -= 1` underflows"};
+      bool is_specular = ur == 0.0 && vr == 0.0;
+      if (is_specular && allow_multiple_lobes) {
+        Lobe l; l.kind = FRESNEL_SPEC; l.type = BXDF_SPECULAR | BXDF_ALL; l.r = r; l.t = t; l.eta_a = 1.0; l.eta_b = eta; bsdf->add(l);
+      } else {
+        if (m.remap_roughness) { ur = roughness_to_alpha(ur); vr = roughness_to_alpha(vr); }
+        if (!r.is_black()) {
+          Lobe l; l.r = r; l.fr = FR_DIELECTRIC; l.eta_i = Rgb(1.0); l.eta_t = Rgb(eta);
+          if (is_specular) { l.kind = SPEC_REFL; l.type = BXDF_REFLECTION | BXDF_SPECULAR; }
+          else { l.kind = MICROFACET; l.type = BXDF_GLOSSY | BXDF_REFLECTION; l.alpha_x = ur; l.alpha_y = vr; }
+          bsdf->add(l);
+        }
+        if (!t.is_black()) {
+          Lobe l; l.t = t; l.eta_a = 1.0; l.eta_b = eta;
+          if (is_specular) { l.kind = SPEC_TRANS; l.type = BXDF_SPECULAR | BXDF_TRANSMISSION; }
+          else { l.kind = MICROFACET_TRANS; l.type = BXDF_GLOSSY | BXDF_TRANSMISSION; l.alpha_x = ur; l.alpha_y = vr; }
+          bsdf->add(l);
+        }
+      }
+      break;
+    }
+    case RRT_MAT_TRANSLUCENT: {  // translucent.rs:50-107
+      if (sc.d->integrator.type != RRT_INT_PATH) throw OraclePanic{"transmissive materials are in scope for the Path integrator only (specular_transmit branches, integrator/mod.rs:199-301)"};
+      const double eta = 1.5;
+      bsdf->eta = eta;
+      Rgb r = rclamp0(Rgb(m.reflect)), t = rclamp0(Rgb(m.transmit));
+      if (r.is_black() && t.is_black()) throw OraclePanic{"translucent.rs:66 null BSDF: path.rs:103 `bounces -= 1` underflows"};
+      Rgb kd = rclamp0(Rgb(m.kd));
+      if (!kd.is_black()) {
+        if (!r.is_black()) { Lobe l; l.kind = LAMBERT; l.type = BXDF_DIFFUSE | BXDF_REFLECTION; l.r = r * kd; bsdf->add(l); }
+        if (!t.is_black()) { Lobe l; l.kind = LAMBERT_TRANS; l.type = BXDF_DIFFUSE | BXDF_TRANSMISSION; l.t = t * kd; bsdf->add(l); }
+      }
+      Rgb ks = rclamp0(Rgb(m.ks));
+      if (!ks.is_black() && (!r.is_black() || !t.is_black())) {
+        double rough = m.roughness;
+        if (m.remap_roughness) rough = roughness_to_alpha(rough);
+        if (!r.is_black()) {
+          Lobe l; l.kind = MICROFACET; l.type = BXDF_GLOSSY | BXDF_REFLECTION; l.r = r * ks; l.alpha_x = rough; l.alpha_y = rough;
+          l.fr = FR_DIELECTRIC; l.eta_i = Rgb(1.0); l.eta_t = Rgb(eta);
+          bsdf->add(l);
+        }
+        if (!t.is_black()) {
+          Lobe l; l.kind = MICROFACET_TRANS; l.type = BXDF_GLOSSY | BXDF_TRANSMISSION; l.t = t * ks; l.alpha_x = rough; l.alpha_y = rough; l.eta_a = 1.0; l.eta_b = eta;
+          bsdf->add(l);
+        }
+      }
       break;
     }
     default: throw OraclePanic{"unknown material type in scene desc"};
@@ -1309,6 +1433,10 @@ struct Integ {
       if (!(beta.y() > 0.0)) throw OraclePanic{"path.rs:146 assert!(beta.y() > 0.0)"};
       if (!std::isfinite(beta.y())) throw OraclePanic{"path.rs:147 assert!(beta.y().is_finite())"};
       specular_bounce = (flags & BXDF_SPECULAR) != 0;
+      if ((flags & BXDF_SPECULAR) && (flags & BXDF_TRANSMISSION)) {   // path.rs:150-162
+        double eta = bsdf.eta;
+        eta_scale *= (dot(wo, isect.n) > 0.0) ? eta * eta : 1.0 / (eta * eta);
+      }
       ray = ray_new(isect.p, wi, INF);  // spawn_ray: no origin offset (Q8)
       Rgb rr_beta = beta * eta_scale;
       if (rr_beta.max_component() < in.rr_threshold && bounces > 3) {

@@ -46,7 +46,8 @@ class Prim(C.Structure):
 class Material(C.Structure):
     _fields_ = [("type", C.c_int32), ("remap_roughness", C.c_int32), ("kd", C.c_double * 3), ("ks", C.c_double * 3),
                 ("kr", C.c_double * 3), ("eta", C.c_double * 3), ("k", C.c_double * 3), ("sigma", C.c_double),
-                ("roughness", C.c_double), ("u_roughness", C.c_double), ("v_roughness", C.c_double)]
+                ("roughness", C.c_double), ("u_roughness", C.c_double), ("v_roughness", C.c_double),
+                ("kt", C.c_double * 3), ("reflect", C.c_double * 3), ("transmit", C.c_double * 3), ("index", C.c_double)]
 
 
 class Light(C.Structure):

@@ -149,11 +149,19 @@ template <typename R> RRT_DEV uint32_t skip_plane_of(const SceneDev<R>& s, int s
 template <typename R>
 struct SphereSI { V3<R> p, n, wo, sn, sdpdu; };
 
+// The rays the sphere code works with: the ray handed to the sphere (instance space, Q16) and the object-space ray.
+template <typename R>
+RRT_DEV void sphere_rays(const SphereDev<R>& S, V3<R> wo_, V3<R> wd_, V3<R>* ro, V3<R>* rd, V3<R>* oo, V3<R>* od) {
+  *ro = wo_; *rd = wd_;
+  if (S.has_inst) { *ro = aff_pt(S.imi, wo_); *rd = vnormalize(vnormalize(aff_vec(S.imi, wd_))); }   // xf_ray + Ray::new
+  *oo = aff_pt(S.mi, *ro); *od = vnormalize(vnormalize(aff_vec(S.mi, *rd)));
+}
+// Hit decision. *branch = 1 when the accepted hit is the second root after the clipping test (sphere.rs:170-191):
+// the hit record keeps it so that the shading kernel rebuilds the surface without deciding anything again.
 template <typename R, bool ANY>
-RRT_DEV bool sphere_prim_hit(const SphereDev<R>& S, V3<R> wo_, V3<R> wd_, R* t_out, SphereSI<R>* si) {
-  V3<R> ro = wo_, rd = wd_;
-  if (S.has_inst) { ro = aff_pt(S.imi, wo_); rd = vnormalize(vnormalize(aff_vec(S.imi, wd_))); }   // xf_ray + Ray::new
-  const V3<R> oo = aff_pt(S.mi, ro), od = vnormalize(vnormalize(aff_vec(S.mi, rd)));
+RRT_DEV bool sphere_prim_hit(const SphereDev<R>& S, V3<R> wo_, V3<R> wd_, R* t_out, R* branch) {
+  V3<R> ro, rd, oo, od;
+  sphere_rays(S, wo_, wd_, &ro, &rd, &oo, &od);
   const R a = od.x * od.x + od.y * od.y + od.z * od.z;
   const R b = R(2) * (od.x * oo.x + od.y * oo.y + od.z * oo.z);
   const R c = oo.x * oo.x + oo.y * oo.y + oo.z * oo.z - S.radius * S.radius;
@@ -170,6 +178,7 @@ RRT_DEV bool sphere_prim_hit(const SphereDev<R>& S, V3<R> wo_, V3<R> wd_, R* t_o
     phi = atan2(ph.y, ph.x);
     if (phi < R(0)) phi += R(2) * R(RRT_PI);
   }
+  *branch = R(0);
   if ((S.z_min > -S.radius && ph.z < S.z_min) || (S.z_max < S.radius && ph.z > S.z_max) || (phi > S.phi_max)) {
     if (th == t1) return false;
     if (t1 > kMax) return false;
@@ -180,33 +189,41 @@ RRT_DEV bool sphere_prim_hit(const SphereDev<R>& S, V3<R> wo_, V3<R> wd_, R* t_o
     phi = atan2(ph.y, ph.x);
     if (phi < R(0)) phi += R(2) * R(RRT_PI);
     if ((S.z_min > -S.radius && ph.z < S.z_min) || (S.z_max < S.radius && ph.z > S.z_max) || (phi > S.phi_max)) return false;
+    *branch = R(1);
   }
-  if (ANY) return true;
   *t_out = th;
-  if (si) {
-    const R theta = acos(clampr(ph.z / S.radius, R(-1), R(1)));
-    const R z_radius = sqrt(ph.x * ph.x + ph.y * ph.y);
-    const R inv_zr = R(1) / z_radius;
-    const R cphi = ph.x * inv_zr, sphi = ph.y * inv_zr;
-    const V3<R> dpdu(-S.phi_max * ph.y, S.phi_max * ph.x, R(0));
-    const V3<R> dpdv = V3<R>(ph.z * cphi, ph.z * sphi, -S.radius * R(sin(theta))) * (S.theta_max - S.theta_min);
-    // SurfaceInteraction::new (interaction.rs:131-181) then obj_to_world.t(&ist) (transform.rs:628-655)
-    V3<R> n = vnormalize(cross(dpdu, dpdv));
-    si->p = aff_pt(S.m, ph);
-    si->wo = aff_vec(S.m, -od);
-    si->n = aff_nrm(S.mi, n);
-    si->sn = faceforward(nnormalize(aff_nrm(S.mi, n)), si->n);
-    si->sdpdu = aff_vec(S.m, dpdu);
-    if (S.has_inst && !S.inst_identity) {   // TransformedPrimitive::intersect primitives.rs:131-136
-      si->p = aff_pt(S.im, si->p);
-      si->wo = aff_vec(S.im, si->wo);
-      const V3<R> n2 = aff_nrm(S.imi, si->n);
-      si->sn = faceforward(nnormalize(aff_nrm(S.imi, si->sn)), n2);
-      si->n = n2;
-      si->sdpdu = aff_vec(S.im, si->sdpdu);
-    }
-  }
   return true;
+}
+// SurfaceInteraction of an accepted sphere hit (sphere.rs:192-259) from (t, branch)
+template <typename R>
+RRT_DEV void sphere_surface(const SphereDev<R>& S, V3<R> wo_, V3<R> wd_, R th, R branch, SphereSI<R>* si) {
+  V3<R> ro, rd, oo, od;
+  sphere_rays(S, wo_, wd_, &ro, &rd, &oo, &od);
+  V3<R> ph;
+  if (branch == R(0)) ph = ro + rd * th;
+  else { ph = oo + od * th; ph = ph * (S.radius / len(ph)); }
+  if (ph.x == R(0) && ph.y == R(0)) ph.x = R(1e-5) * S.radius;
+  const R theta = acos(clampr(ph.z / S.radius, R(-1), R(1)));
+  const R z_radius = sqrt(ph.x * ph.x + ph.y * ph.y);
+  const R inv_zr = R(1) / z_radius;
+  const R cphi = ph.x * inv_zr, sphi = ph.y * inv_zr;
+  const V3<R> dpdu(-S.phi_max * ph.y, S.phi_max * ph.x, R(0));
+  const V3<R> dpdv = V3<R>(ph.z * cphi, ph.z * sphi, -S.radius * R(sin(theta))) * (S.theta_max - S.theta_min);
+  // SurfaceInteraction::new (interaction.rs:131-181) then obj_to_world.t(&ist) (transform.rs:628-655)
+  V3<R> n = vnormalize(cross(dpdu, dpdv));
+  si->p = aff_pt(S.m, ph);
+  si->wo = aff_vec(S.m, -od);
+  si->n = aff_nrm(S.mi, n);
+  si->sn = faceforward(nnormalize(aff_nrm(S.mi, n)), si->n);
+  si->sdpdu = aff_vec(S.m, dpdu);
+  if (S.has_inst && !S.inst_identity) {   // TransformedPrimitive::intersect primitives.rs:131-136
+    si->p = aff_pt(S.im, si->p);
+    si->wo = aff_vec(S.im, si->wo);
+    const V3<R> n2 = aff_nrm(S.imi, si->n);
+    si->sn = faceforward(nnormalize(aff_nrm(S.imi, si->sn)), n2);
+    si->n = n2;
+    si->sdpdu = aff_vec(S.im, si->sdpdu);
+  }
 }
 
 template <typename R, typename Stack>
@@ -226,7 +243,7 @@ RRT_DEV int traverse_closest(const SceneDev<R>& s, RayCtx<R>& r, Stack& st, int 
           R t, u, v;
           const Tri<R> tr = s.tris[nd.offset + i];
           if (tr.plane == kSphereMark) {
-            if (sphere_prim_hit<R, false>(s.spheres[tr.shade], r.o, r.d, &t, (SphereSI<R>*)nullptr)) { r.tmax = t; hit = (int)(nd.offset + i); *hu = R(0); *hv = R(0); }
+            if (sphere_prim_hit<R, false>(s.spheres[tr.shade], r.o, r.d, &t, &u)) { r.tmax = t; hit = (int)(nd.offset + i); *hu = u; *hv = R(0); }   // u carries the root branch
             continue;
           }
           if (tr.plane == skip_plane) continue;
@@ -262,8 +279,8 @@ RRT_DEV bool traverse_any(const SceneDev<R>& s, const RayCtx<R>& r, Stack& st, i
           cp++;
           const Tri<R> tr = s.tris[nd.offset + i];
           if (tr.plane == kSphereMark) {
-            R t;
-            if (sphere_prim_hit<R, true>(s.spheres[tr.shade], r.o, r.d, &t, (SphereSI<R>*)nullptr)) { found = true; break; }
+            R t, br;
+            if (sphere_prim_hit<R, true>(s.spheres[tr.shade], r.o, r.d, &t, &br)) { found = true; break; }
             continue;
           }
           if (tr.plane == skip_plane) continue;
@@ -345,12 +362,13 @@ __global__ void __launch_bounds__(kBlock) k_pack_rays(Pools<R> p, const R* ox, c
   store_ray<R>(p.ray_o, p.ray_d, p.ray_l, i, V3<R>(ox[i], oy[i], oz[i]), V3<R>(), V3<R>(dx[i], dy[i], dz[i]), tmax[i], skip ? skip[i] : -1);
 }
 template <typename R>
-__global__ void __launch_bounds__(kBlock) k_unpack_hits(Pools<R> p, R* t, int32_t* prim, R* u, R* v, uint32_t n) {
+__global__ void __launch_bounds__(kBlock) k_unpack_hits(Pools<R> p, const Tri<R>* tris, R* t, int32_t* prim, R* u, R* v, uint32_t n) {
   const uint32_t i = blockIdx.x * blockDim.x + threadIdx.x;
   if (i >= n) return;
   const typename Vec4T<R>::type h = p.hit[i];
-  t[i] = h.x; prim[i] = (int32_t)real_to_bits(h.y);
-  if (u) u[i] = h.z;
+  const int32_t pr = (int32_t)real_to_bits(h.y);
+  t[i] = h.x; prim[i] = pr;
+  if (u) u[i] = (pr >= 0 && tris[pr].plane == kSphereMark) ? R(0) : h.z;   // sphere hits keep their root branch there internally
   if (v) v[i] = h.w;
 }
 
@@ -423,7 +441,7 @@ __global__ void __launch_bounds__(kBlock) k_raygen(SceneDev<R> s, Pools<R> p, Pa
   }
   __shared__ uint32_t push_lds[kBlock / 64 + 1];
   const uint32_t q = block_push(&p.counters[C_NEXT], alive, push_lds);
-  if (alive) p.q_next[q] = QEnt{slot, 0u};
+  if (alive) p.q_next[q] = QEnt{slot, 0u, 0u, 0u};
 }
 
 // Stage 2 (survivors): the auxiliary rays of generate_ray_differential (camera.rs:582-628) at p_film +- 0.05 px in
@@ -455,8 +473,8 @@ __global__ void __launch_bounds__(kBlock) k_raygen_aux(SceneDev<R> s, Pools<R> p
   const bool enq = alive && enqueue;
   const uint32_t q = block_push(&p.counters[C_ACTIVE], enq, push_lds);
   if (enq) {
-    p.q_active[q] = QEnt{slot, 5u};   // five camera dimensions consumed, bounce 0
-    p.path[q] = mk4u<R>(R(1), R(1), R(1), p.hindex[slot]);
+    p.q_active[q] = QEnt{slot, 5u, p.hindex[slot], 0u};   // five camera dimensions consumed, bounce 0
+    p.path[q] = mk4<R>(R(1), R(1), R(1), R(1));
     p.ray_o[q] = p.nray_o[slot]; p.ray_d[q] = p.nray_d[slot]; p.ray_l[q] = p.nray_l[slot];
   }
   if (alive) p.L[slot] = mk4<R>(R(0), R(0), R(0), R(0));
@@ -515,10 +533,10 @@ template <typename R>
 RRT_DEV Surf<R> build_surface(const SceneDev<R>& s, int prim, V3<R> o, V3<R> d, R t, R u, R v) {
   Surf<R> si;
   const Tri<R> tr = s.tris[prim];
-  if (tr.plane == kSphereMark) {   // redo the accepted test with the interaction outputs switched on
+  if (tr.plane == kSphereMark) {   // u = root branch recorded by the traversal (public API reports 0, 0 for spheres)
     SphereSI<R> ss;
-    R th;
-    si.ok = sphere_prim_hit<R, false>(s.spheres[tr.shade], o, d, &th, &ss);
+    sphere_surface(s.spheres[tr.shade], o, d, t, u, &ss);
+    si.ok = true;
     si.p = ss.p; si.p_lo = V3<R>(); si.n = ss.n; si.wo = ss.wo; si.sn = ss.sn; si.sdpdu = ss.sdpdu;
     si.material = tr.material;
     if (!(dot(si.n, si.sn) >= R(0))) si.ok = false;   // primitives.rs:66
@@ -573,8 +591,8 @@ RRT_DEV Surf<R> build_surface(const SceneDev<R>& s, int prim, V3<R> o, V3<R> d, 
   return si;
 }
 
-template <typename R>
-RRT_DEV void build_bsdf(const SceneDev<R>& s, const Surf<R>& si, Bsdf<R>* b) {  // Bsdf::new reflection.rs:215-226
+template <typename R, int NL>
+RRT_DEV void build_bsdf(const SceneDev<R>& s, const Surf<R>& si, Bsdf<R, NL>* b) {  // Bsdf::new reflection.rs:215-226
   b->ns = si.sn;
   b->ss = vnormalize(si.sdpdu);
   b->ng = si.n;
@@ -675,8 +693,8 @@ RRT_DEV bool sphere_hit_for_pdf(const Light<R>& L, V3<R> ro, V3<R> rd, V3<R>* p_
 // Returns true and fills the shadow ray + contribution when a visibility test is needed.
 // The BSDF-sampling half (:483-556) can only add `li * f * weight / pdf` with li = 0 (no primitive carries an
 // area light, Q18; DiffuseAreaLight::le is the trait default 0), so it is not executed: see DESIGN.md.
-template <typename R>
-RRT_DEV bool estimate_direct_light(const Surf<R>& si, const Bsdf<R>& bsdf, const Light<R>& L, R ul0, R ul1, V3<R>* so, V3<R>* sd, Rgb<R>* ld) {
+template <typename R, int NL>
+RRT_DEV bool estimate_direct_light(const Surf<R>& si, const Bsdf<R, NL>& bsdf, const Light<R>& L, R ul0, R ul1, V3<R>* so, V3<R>* sd, Rgb<R>* ld) {
   const uint32_t flags = BXDF_ALL & ~BXDF_SPECULAR;
   V3<R> wi, p1, n1;
   R light_pdf = R(0);
@@ -708,7 +726,7 @@ RRT_DEV uint32_t sample_light_discrete(const SceneDev<R>& s, R u) {
 }
 
 // PathIntegrator::li loop body (path.rs:74-223) for one bounce of every active path.
-template <typename R>
+template <typename R, int NL>
 __global__ void __launch_bounds__(ShadeBlock<R>::n) k_shade_path(SceneDev<R> s, Pools<R> p) {
   __shared__ uint32_t push_lds[ShadeBlock<R>::n / 64 + 1];
   const uint32_t i = blockIdx.x * blockDim.x + threadIdx.x;
@@ -720,6 +738,7 @@ __global__ void __launch_bounds__(ShadeBlock<R>::n) k_shade_path(SceneDev<R> s, 
   int prim = -1;
   V3<R> sh_o, sh_d, nx_o, nx_d, o_lo;   // shadow ray / next ray + path state, stored at their queue positions at the end
   Rgb<R> sh_ld, nx_beta;
+  R nx_eta_scale = R(1);
   uint32_t index = 0, nx_db = 0;
   if (i < n) {
     const QEnt qe = p.q_active[i];
@@ -735,11 +754,12 @@ __global__ void __launch_bounds__(ShadeBlock<R>::n) k_shade_path(SceneDev<R> s, 
       Surf<R> si = build_surface(s, prim, o, d, h.x, h.z, h.w);
       if (!si.ok) { atomicOr(&p.counters[C_ERROR], (uint32_t)ERR_SHADING_NORMAL); }
       else {
-        Bsdf<R> bsdf;
+        Bsdf<R, NL> bsdf;
         build_bsdf(s, si, &bsdf);
         const V4 st_b = p.path[i];
-        index = real_to_bits(st_b.w);
+        index = qe.index;
         Rgb<R> beta(st_b.x, st_b.y, st_b.z);
+        R eta_scale = st_b.w;
         // uniform_sample_one_light integrator/mod.rs:359-401 with the uniform Distribution1D (path.rs:47-49)
         if (bsdf.num_components(BXDF_ALL & ~BXDF_SPECULAR) > 0 && s.n_lights > 0) {
           R u_pick = to_real<R>(halton_dim(s, index, dim));
@@ -765,11 +785,14 @@ __global__ void __launch_bounds__(ShadeBlock<R>::n) k_shade_path(SceneDev<R> s, 
         if (!(f.is_black() || pdf == R(0))) {
           beta = beta * (f * absdot(wi, si.sn) / pdf);
           if (!(beta.y() > R(0)) || isinf(beta.y()) || beta.y() != beta.y()) atomicOr(&p.counters[C_ERROR], (uint32_t)ERR_BETA);  // path.rs:146-147 asserts
+          if ((flags & BXDF_SPECULAR) && (flags & BXDF_TRANSMISSION))   // path.rs:150-162
+            eta_scale *= dot(si.wo, si.n) > R(0) ? bsdf.eta * bsdf.eta : R(1) / (bsdf.eta * bsdf.eta);
           V3<R> nd = vnormalize(wi);  // spawn_ray -> Ray::new_od (Q8: no origin offset)
           bool cont = true;
-          // Russian roulette (:214-222); eta_scale stays 1 without transmission
-          if (beta.max_component() < s.rr_threshold && bounces > 3) {
-            R q = rmax(R(1) - beta.max_component(), R(0.05));
+          // Russian roulette (:214-222) on beta * eta_scale
+          const R rr_max = (beta * eta_scale).max_component();
+          if (rr_max < s.rr_threshold && bounces > 3) {
+            R q = rmax(R(1) - rr_max, R(0.05));
             R ur = to_real<R>(halton_dim(s, index, dim));
             dim += 1;
             if (ur < q) cont = false;
@@ -780,7 +803,7 @@ __global__ void __launch_bounds__(ShadeBlock<R>::n) k_shade_path(SceneDev<R> s, 
           // hit (emission is 0): that dead closest-hit query is not issued.
           if (cont && (int)bounces < s.max_depth) {
             nx_o = si.p; nx_d = nd;
-            nx_beta = beta;
+            nx_beta = beta; nx_eta_scale = eta_scale;
             nx_db = (dim & 0xffffu) | (bounces << 16);
             want_next = true;
           }
@@ -795,8 +818,8 @@ __global__ void __launch_bounds__(ShadeBlock<R>::n) k_shade_path(SceneDev<R> s, 
   }
   const uint32_t qn = block_push(&p.counters[C_NEXT], want_next, push_lds);
   if (want_next) {
-    p.q_next[qn] = QEnt{slot, nx_db};
-    p.npath[qn] = mk4u<R>(nx_beta.r, nx_beta.g, nx_beta.b, index);
+    p.q_next[qn] = QEnt{slot, nx_db, index, 0u};
+    p.npath[qn] = mk4<R>(nx_beta.r, nx_beta.g, nx_beta.b, nx_eta_scale);
     store_ray<R>(p.nray_o, p.nray_d, p.nray_l, qn, nx_o, o_lo, nx_d, Const<R>::inf, self_prim<R>(prim));
   }
 }
@@ -832,7 +855,7 @@ __global__ void __launch_bounds__(ShadeBlock<R>::n) k_shade_nee(SceneDev<R> s, P
         const uint32_t db = qe.db;
         uint32_t dim = db & 0xffffu;
         const V4 st_b = p.path[i];
-        const uint32_t index = real_to_bits(st_b.w);
+        const uint32_t index = qe.index;
         Rgb<R> beta(st_b.x, st_b.y, st_b.z);
         if (first && s.integrator == 2) {  // Debug: l = Spectrum(0.1) on a hit (intersect_debug.rs:66-70)
           V4 l = p.L[slot];
@@ -897,7 +920,7 @@ __global__ void __launch_bounds__(ShadeBlock<R>::n) k_shade_specular(SceneDev<R>
       uint32_t dim = db & 0xffffu;
       const uint32_t depth = (db >> 16) + 1;
       Rgb<R> beta(st_b.x, st_b.y, st_b.z);
-      index = real_to_bits(st_b.w);
+      index = qe.index;
       if (grey_only) {  // Debug with no lights still adds the 0.1 grey
         V4 l = p.L[slot];
         l.x += beta.r * R(0.1); l.y += beta.g * R(0.1); l.z += beta.b * R(0.1);
@@ -928,8 +951,8 @@ __global__ void __launch_bounds__(ShadeBlock<R>::n) k_shade_specular(SceneDev<R>
   }
   const uint32_t qn = block_push(&p.counters[C_NEXT], want_next, push_lds);
   if (want_next) {
-    p.q_next[qn] = QEnt{slot, nx_db};
-    p.npath[qn] = mk4u<R>(nx_beta.r, nx_beta.g, nx_beta.b, index);
+    p.q_next[qn] = QEnt{slot, nx_db, index, 0u};
+    p.npath[qn] = mk4<R>(nx_beta.r, nx_beta.g, nx_beta.b, R(1));
     store_ray<R>(p.nray_o, p.nray_d, p.nray_l, qn, nx_o, o_lo, nx_d, Const<R>::inf, self_prim<R>(prim));
   }
 }

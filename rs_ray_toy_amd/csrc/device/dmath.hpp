@@ -361,7 +361,8 @@ template <typename R> RRT_DEV R generate_ray_differential(const SceneDev<R>& s, 
 
 // ---- BxDFs (reflection.rs, microfacet.rs) ---------------------------------------------------------------------
 enum : uint32_t { BXDF_REFLECTION = 1, BXDF_TRANSMISSION = 2, BXDF_DIFFUSE = 4, BXDF_GLOSSY = 8, BXDF_SPECULAR = 16, BXDF_ALL = 31, BXDF_NONE = 0 };
-enum : uint32_t { LOBE_LAMBERT = 0, LOBE_OREN_NAYAR, LOBE_MICROFACET, LOBE_SPEC_REFL, LOBE_DEBUG_DIFFUSE, LOBE_DEBUG_SPECULAR };
+enum : uint32_t { LOBE_LAMBERT = 0, LOBE_OREN_NAYAR, LOBE_MICROFACET, LOBE_SPEC_REFL, LOBE_DEBUG_DIFFUSE, LOBE_DEBUG_SPECULAR,
+                  LOBE_SPEC_TRANS, LOBE_FRESNEL_SPEC, LOBE_LAMBERT_TRANS, LOBE_MICROFACET_TRANS };
 enum : uint32_t { FR_NOOP = 0, FR_DIELECTRIC, FR_CONDUCTOR };
 
 template <typename R> RRT_DEV R cos_theta(V3<R> w) { return w.z; }
@@ -408,9 +409,9 @@ template <typename R>
 struct Lobe {
   uint32_t kind, type, fr;
   Rgb<R> r;
-  R a, b;              // OrenNayar A, B
+  R a, b;              // OrenNayar A, B; transmissive lobes: eta_a, eta_b
   R alpha_x, alpha_y;  // TrowbridgeReitz, sample_visible_area = true
-  Rgb<R> eta_i, eta_t, k;
+  Rgb<R> eta_i, eta_t, k;   // transmissive lobes keep T in `r` (FresnelSpecular: R in `r`, T in `k`)
 };
 
 // TrowbridgeReitzDistribution microfacet.rs:253-425
@@ -502,7 +503,21 @@ template <typename R> RRT_DEV Rgb<R> lobe_f(const Lobe<R>& l, V3<R> wo, V3<R> wi
     }
     case LOBE_DEBUG_DIFFUSE: return Rgb<R>(R(0), R(1), R(0));
     case LOBE_DEBUG_SPECULAR: return Rgb<R>(R(0), R(0), R(1));
-    default: return Rgb<R>();  // SpecularReflection::f
+    case LOBE_LAMBERT_TRANS: return l.r / R(RRT_PI);   // reflection.rs:854-856
+    case LOBE_MICROFACET_TRANS: {   // reflection.rs:1059-1097, mode = Radiance
+      if (same_hemisphere(wo, wi)) return Rgb<R>();
+      const R cos_o = cos_theta(wo), cos_i = cos_theta(wi);
+      if (cos_i == R(0) || cos_o == R(0)) return Rgb<R>();
+      const R eta = cos_theta(wo) > R(0) ? l.b / l.a : l.a / l.b;
+      V3<R> wh = vnormalize(wo + wi * eta);
+      if (wh.z < R(0)) wh = -wh;
+      const R f = fr_dielectric(dot(wo, wh), l.a, l.b);
+      const R sqrt_denom = dot(wo, wh) + eta * dot(wi, wh);
+      const R factor = R(1) / eta;
+      return (Rgb<R>(R(1)) - Rgb<R>(f)) * l.r *
+             rabs(tr_d(l, wh) * tr_g(l, wo, wi) * eta * eta * absdot(wi, wh) * absdot(wo, wh) * factor * factor / (cos_i * cos_o * sqrt_denom * sqrt_denom));
+    }
+    default: return Rgb<R>();  // SpecularReflection / SpecularTransmission / FresnelSpecular ::f
   }
 }
 template <typename R> RRT_DEV R lobe_pdf(const Lobe<R>& l, V3<R> wo, V3<R> wi) {
@@ -511,10 +526,54 @@ template <typename R> RRT_DEV R lobe_pdf(const Lobe<R>& l, V3<R> wo, V3<R> wi) {
     V3<R> wh = vnormalize(wo + wi);
     return tr_pdf(l, wo, wh) / (R(4) * dot(wo, wh));
   }
-  if (l.kind == LOBE_SPEC_REFL) return R(0);
+  if (l.kind == LOBE_SPEC_REFL || l.kind == LOBE_SPEC_TRANS || l.kind == LOBE_FRESNEL_SPEC) return R(0);
+  if (l.kind == LOBE_LAMBERT_TRANS) return !same_hemisphere(wo, wi) ? abs_cos_theta(wi) / R(RRT_PI) : R(0);  // :887-893
+  if (l.kind == LOBE_MICROFACET_TRANS) {  // :1124-1144
+    if (same_hemisphere(wo, wi)) return R(0);
+    const R eta = cos_theta(wo) > R(0) ? l.b / l.a : l.a / l.b;
+    const V3<R> wh = vnormalize(wo + wi * eta);
+    const R sqrt_denom = dot(wo, wh) + dot(wi, wh) * eta;
+    const R dwh_dwi = rabs((eta * eta * dot(wi, wh)) / (sqrt_denom * sqrt_denom));
+    return tr_pdf(l, wo, wh) * dwh_dwi;
+  }
   return same_hemisphere(wo, wi) ? abs_cos_theta(wi) / R(RRT_PI) : R(0);  // BxDF::pdf default :492-498
 }
-template <typename R> RRT_DEV Rgb<R> lobe_sample_f(const Lobe<R>& l, V3<R> wo, V3<R>* wi, R u0, R u1, R* pdf) {
+template <typename R> RRT_DEV Rgb<R> lobe_sample_f(const Lobe<R>& l, V3<R> wo, V3<R>* wi, R u0, R u1, R* pdf, uint32_t* sampled) {
+  if (l.kind == LOBE_SPEC_TRANS || l.kind == LOBE_FRESNEL_SPEC) {  // reflection.rs:690-716, :754-795, mode = Radiance
+    R fr = R(0);
+    if (l.kind == LOBE_FRESNEL_SPEC) {
+      fr = fr_dielectric(cos_theta(wo), l.a, l.b);
+      if (u0 < fr) {
+        *wi = V3<R>(-wo.x, -wo.y, wo.z);
+        *sampled = BXDF_SPECULAR | BXDF_REFLECTION;
+        *pdf = fr;
+        return l.r * fr / abs_cos_theta(*wi);
+      }
+    }
+    const bool entering = cos_theta(wo) > R(0);
+    const R eta_i = entering ? l.a : l.b, eta_t = entering ? l.b : l.a;
+    if (!refract(wo, faceforward(V3<R>(R(0), R(0), R(1)), wo), eta_i / eta_t, wi)) return Rgb<R>();
+    Rgb<R> ft;
+    if (l.kind == LOBE_FRESNEL_SPEC) { ft = l.k * (R(1) - fr); *pdf = R(1) - fr; *sampled = BXDF_SPECULAR | BXDF_TRANSMISSION; }
+    else { ft = l.r * (Rgb<R>(R(1)) - Rgb<R>(fr_dielectric(cos_theta(*wi), l.a, l.b))); *pdf = R(1); }
+    ft = ft * ((eta_i * eta_i) / (eta_t * eta_t));
+    return ft / abs_cos_theta(*wi);
+  }
+  if (l.kind == LOBE_LAMBERT_TRANS) {  // :857-869
+    *wi = cosine_sample_hemisphere(u0, u1);
+    if (wo.z > R(0)) wi->z *= R(-1);
+    *pdf = lobe_pdf(l, wo, *wi);
+    return lobe_f(l, wo, *wi);
+  }
+  if (l.kind == LOBE_MICROFACET_TRANS) {  // :1098-1123
+    if (wo.z == R(0)) return Rgb<R>();
+    const V3<R> wh = tr_sample_wh(l, wo, u0, u1);
+    if (dot(wo, wh) < R(0)) return Rgb<R>();
+    const R eta = cos_theta(wo) > R(0) ? l.a / l.b : l.b / l.a;
+    if (!refract(wo, wh, eta, wi)) return Rgb<R>();
+    *pdf = lobe_pdf(l, wo, *wi);
+    return lobe_f(l, wo, *wi);
+  }
   if (l.kind == LOBE_MICROFACET) {  // reflection.rs:993-1018
     if (wo.z == R(0)) return Rgb<R>();
     V3<R> wh = tr_sample_wh(l, wo, u0, u1);
@@ -540,12 +599,13 @@ template <typename R> RRT_DEV R roughness_to_alpha(R roughness) {  // microfacet
   return R(1.62142) + R(0.819955) * x + R(0.1734) * x * x + R(0.0171201) * x * x * x + R(0.000640711) * x * x * x * x;
 }
 
-// Bsdf reflection.rs:205-405; at most two lobes for the in-scope materials
-template <typename R>
+// Bsdf reflection.rs:205-405. NL = lobe capacity: 2 covers every material except TranslucentMaterial (4)
+template <typename R, int NL = 2>
 struct Bsdf {
   V3<R> ns, ng, ss, ts;
-  Lobe<R> lobes[2];
+  Lobe<R> lobes[NL];
   int n;
+  R eta;   // Bsdf::new(si, eta): 1 except glass / translucent
 
   RRT_DEV static bool match(const Lobe<R>& l, uint32_t flags) { return (l.type & flags) == l.type; }
   RRT_DEV int num_components(uint32_t flags) const { int c = 0; for (int i = 0; i < n; i++) if (match(lobes[i], flags)) c++; return c; }
@@ -590,7 +650,7 @@ struct Bsdf {
     if (wo.z == R(0)) return Rgb<R>();
     *pdf_out = R(0);
     *sampled = bx.type;
-    Rgb<R> f = lobe_sample_f(bx, wo, &wi, ur0, u1, pdf_out);
+    Rgb<R> f = lobe_sample_f(bx, wo, &wi, ur0, u1, pdf_out, sampled);
     if (*pdf_out == R(0)) { *sampled = BXDF_NONE; return Rgb<R>(); }
     *wi_w = to_world(wi);
     if (!(bx.type & BXDF_REFLECTION) && matching > 1)
@@ -602,8 +662,9 @@ struct Bsdf {
 
 // Material::compute_scattering_functions (matte.rs:35-60, plastic.rs:42-73, metal.rs:48-89, mirror.rs:27-47,
 // debug_material.rs:37-48) with constant textures
-template <typename R> RRT_DEV void build_lobes(const Material<R>& m, Bsdf<R>* b) {
+template <typename R, int NL> RRT_DEV void build_lobes(const Material<R>& m, Bsdf<R, NL>* b) {
   b->n = 0;
+  b->eta = R(1);
   switch (m.type) {
     case 0: {  // MatteMaterial
       Rgb<R> r = rgb_clamp0(Rgb<R>(m.kd));
@@ -648,6 +709,55 @@ template <typename R> RRT_DEV void build_lobes(const Material<R>& m, Bsdf<R>* b)
       if (!r.is_black()) {
         Lobe<R>& l = b->lobes[b->n++];
         l.kind = LOBE_SPEC_REFL; l.type = BXDF_REFLECTION | BXDF_SPECULAR; l.r = r; l.fr = FR_NOOP;
+      }
+      break;
+    }
+    case 5: {  // GlassMaterial glass.rs:52-112 (Path: allow_multiple_lobes = true, mode = Radiance)
+      const R eta = m.index;
+      R ur = m.u_roughness, vr = m.v_roughness;
+      const Rgb<R> r = rgb_clamp0(Rgb<R>(m.kr)), t = rgb_clamp0(Rgb<R>(m.kt));
+      b->eta = eta;
+      const bool is_specular = ur == R(0) && vr == R(0);
+      if (is_specular) {
+        Lobe<R>& l = b->lobes[b->n++];
+        l.kind = LOBE_FRESNEL_SPEC; l.type = BXDF_SPECULAR | BXDF_ALL; l.r = r; l.k = t; l.a = R(1); l.b = eta; l.fr = FR_NOOP;
+      } else {
+        if (m.remap_roughness) { ur = roughness_to_alpha(ur); vr = roughness_to_alpha(vr); }
+        if (!r.is_black()) {
+          Lobe<R>& l = b->lobes[b->n++];
+          l.kind = LOBE_MICROFACET; l.type = BXDF_GLOSSY | BXDF_REFLECTION; l.r = r; l.alpha_x = ur; l.alpha_y = vr;
+          l.fr = FR_DIELECTRIC; l.eta_i = Rgb<R>(R(1)); l.eta_t = Rgb<R>(eta);
+        }
+        if (!t.is_black()) {
+          Lobe<R>& l = b->lobes[b->n++];
+          l.kind = LOBE_MICROFACET_TRANS; l.type = BXDF_GLOSSY | BXDF_TRANSMISSION; l.r = t; l.alpha_x = ur; l.alpha_y = vr; l.a = R(1); l.b = eta; l.fr = FR_NOOP;
+        }
+      }
+      break;
+    }
+    case 6: {  // TranslucentMaterial translucent.rs:50-107 (needs NL = 4)
+      if (NL < 4) break;
+      const R eta = R(1.5);
+      b->eta = eta;
+      const Rgb<R> r = rgb_clamp0(Rgb<R>(m.reflect)), t = rgb_clamp0(Rgb<R>(m.transmit));
+      const Rgb<R> kd = rgb_clamp0(Rgb<R>(m.kd));
+      if (!kd.is_black()) {
+        if (!r.is_black()) { Lobe<R>& l = b->lobes[b->n++]; l.kind = LOBE_LAMBERT; l.type = BXDF_DIFFUSE | BXDF_REFLECTION; l.r = r * kd; l.fr = FR_NOOP; }
+        if (!t.is_black()) { Lobe<R>& l = b->lobes[b->n++]; l.kind = LOBE_LAMBERT_TRANS; l.type = BXDF_DIFFUSE | BXDF_TRANSMISSION; l.r = t * kd; l.fr = FR_NOOP; }
+      }
+      const Rgb<R> ks = rgb_clamp0(Rgb<R>(m.ks));
+      if (!ks.is_black() && (!r.is_black() || !t.is_black())) {
+        R rough = m.roughness;
+        if (m.remap_roughness) rough = roughness_to_alpha(rough);
+        if (!r.is_black()) {
+          Lobe<R>& l = b->lobes[b->n++];
+          l.kind = LOBE_MICROFACET; l.type = BXDF_GLOSSY | BXDF_REFLECTION; l.r = r * ks; l.alpha_x = rough; l.alpha_y = rough;
+          l.fr = FR_DIELECTRIC; l.eta_i = Rgb<R>(R(1)); l.eta_t = Rgb<R>(eta);
+        }
+        if (!t.is_black()) {
+          Lobe<R>& l = b->lobes[b->n++];
+          l.kind = LOBE_MICROFACET_TRANS; l.type = BXDF_GLOSSY | BXDF_TRANSMISSION; l.r = t * ks; l.alpha_x = rough; l.alpha_y = rough; l.a = R(1); l.b = eta; l.fr = FR_NOOP;
+        }
       }
       break;
     }

@@ -570,8 +570,8 @@ static __global__ void __launch_bounds__(kBlock) k_compact_alive(Pools<float> p,
     const uint64_t m = __ballot(alive);
     if (alive) {
       const uint32_t q = out + (uint32_t)__popcll(m & ((1ull << lane) - 1ull));
-      p.q_active[q] = QEnt{(uint32_t)slot, 5u};   // five camera dimensions consumed, bounce 0
-      p.path[q] = make_float4(1.0f, 1.0f, 1.0f, __uint_as_float(p.hindex[slot]));
+      p.q_active[q] = QEnt{(uint32_t)slot, 5u, p.hindex[slot], 0u};   // five camera dimensions consumed, bounce 0
+      p.path[q] = make_float4(1.0f, 1.0f, 1.0f, 1.0f);   // beta, eta_scale
       p.ray_o[q] = p.nray_o[slot]; p.ray_d[q] = p.nray_d[slot]; p.ray_l[q] = make_float4(0.0f, 0.0f, 0.0f, 0.0f);
       p.L[slot] = make_float4(0.0f, 0.0f, 0.0f, 0.0f);
     }

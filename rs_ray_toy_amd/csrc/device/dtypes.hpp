@@ -55,6 +55,7 @@ struct Material {
   int32_t type, remap_roughness;
   R kd[3], ks[3], kr[3], eta[3], k[3];
   R sigma, roughness, u_roughness, v_roughness;
+  R kt[3], reflect[3], transmit[3], index;   // glass / translucent
 };
 
 template <typename R>
@@ -135,7 +136,7 @@ template <typename R> struct Vec4T;
 template <> struct Vec4T<float> { using type = float4; };
 template <> struct Vec4T<double> { using type = double4; };
 
-struct QEnt { uint32_t slot, db; };
+struct alignas(16) QEnt { uint32_t slot, db, index, pad; };   // slot, dimension | bounces << 16, Halton global sample index
 
 template <typename R>
 struct Pools {
@@ -148,8 +149,8 @@ struct Pools {
   V4 *sray_o, *sray_d, *sray_l;   // shadow rays, in shadow-queue order
   V4* sld;               // {Ld.r, Ld.g, Ld.b, slot}: pending contribution of the shadow ray at the same position
   // path state that changes every bounce travels with the queue too (cur / next, swapped with the rays)
-  V4 *path, *npath;      // {beta.r, beta.g, beta.b, Halton global sample index}
-  QEnt *q_active, *q_next;   // {slot, dimension counter (low 16) | bounces (high 16)}
+  V4 *path, *npath;      // {beta.r, beta.g, beta.b, eta_scale (path.rs:70, 150-162)}
+  QEnt *q_active, *q_next;   // {slot, dimension counter (low 16) | bounces (high 16), Halton index, -}
   // per-slot state: only what outlives a path's queue entries
   V4* L;                 // {L.r, L.g, L.b, -}: radiance; touched by unoccluded shadow rays and the film kernel
   R* weight;             // camera ray weight (0 = dead sample: its L is never read)

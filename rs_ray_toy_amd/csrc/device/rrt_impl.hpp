@@ -122,7 +122,7 @@ class Handle : public HandleBase {
     // launches beat many small ones (whole 1024^2 x 256 spp frame in one pass: 268 M slots x 172 B = 46 GB).
     size_t free_b = 0, total_b = 0;
     HIP_CHECK(hipMemGetInfo(&free_b, &total_b));
-    const size_t per_slot = (14 * 4 + 5) * sizeof(R) + 5 * sizeof(uint32_t);
+    const size_t per_slot = (14 * 4 + 5) * sizeof(R) + 9 * sizeof(uint32_t);
     max_paths_ = std::max<size_t>(1u << 16, std::min(max_paths_, (free_b / 2) / per_slot));
   }
   ~Handle() override {
@@ -157,11 +157,11 @@ class Handle : public HandleBase {
     auto kind = out->mem == RRT_MEM_DEVICE ? hipMemcpyDeviceToDevice : hipMemcpyDeviceToHost;
     const uint32_t ug = (uint32_t)((n + kBlock - 1) / kBlock);
     if (out->mem == RRT_MEM_DEVICE) {
-      hipLaunchKernelGGL((k_unpack_hits<R>), dim3(ug), dim3(kBlock), 0, st_, pool_, (R*)out->t, (int32_t*)out->prim, (R*)out->u, (R*)out->v, (uint32_t)n);
+      hipLaunchKernelGGL((k_unpack_hits<R>), dim3(ug), dim3(kBlock), 0, st_, pool_, (const Tri<R>*)tris_.p, (R*)out->t, (int32_t*)out->prim, (R*)out->u, (R*)out->v, (uint32_t)n);
     } else {
       DevBuf<R> hr; DevBuf<int32_t> hp;
       hr.alloc(3 * n); hp.alloc(n);
-      hipLaunchKernelGGL((k_unpack_hits<R>), dim3(ug), dim3(kBlock), 0, st_, pool_, hr.p, hp.p, hr.p + n, hr.p + 2 * n, (uint32_t)n);
+      hipLaunchKernelGGL((k_unpack_hits<R>), dim3(ug), dim3(kBlock), 0, st_, pool_, (const Tri<R>*)tris_.p, hr.p, hp.p, hr.p + n, hr.p + 2 * n, (uint32_t)n);
       HIP_CHECK(hipMemcpyAsync(out->t, hr.p, n * sizeof(R), kind, st_));
       HIP_CHECK(hipMemcpyAsync(out->prim, hp.p, n * sizeof(int32_t), kind, st_));
       if (out->u) HIP_CHECK(hipMemcpyAsync(out->u, hr.p + n, n * sizeof(R), kind, st_));
@@ -294,7 +294,8 @@ class Handle : public HandleBase {
             launch_closest(nullptr, &counters_.p[C_ACTIVE], 0, count_traversal_, nullptr, nullptr, count_traversal_ ? totals_.p : nullptr, grid);
             tock(e); n_closest_launch++;
             e = tick(3);
-            hipLaunchKernelGGL((k_shade_path<R>), dim3(sgrid), dim3(ShadeBlock<R>::n), 0, st_, scene_, pool_);
+            if (has_translucent_) hipLaunchKernelGGL((k_shade_path<R, 4>), dim3((uint32_t)((nslots + 255) / 256)), dim3(256), 0, st_, scene_, pool_);
+            else hipLaunchKernelGGL((k_shade_path<R, 2>), dim3(sgrid), dim3(ShadeBlock<R>::n), 0, st_, scene_, pool_);
             tock(e);
             hipLaunchKernelGGL(k_accumulate_shadow, dim3(1), dim3(1), 0, st_, counters_.p, totals_.p);
             e = tick(2);
@@ -403,6 +404,7 @@ class Handle : public HandleBase {
   bool pairs_ok_ = false;
   uint32_t trav_grid_ = 0, pt_grid_ = 0, rg_grid_ = 0;
   bool raygen_pt_ = true;
+  bool has_transmissive_ = false, has_translucent_ = false;
   int trav_mode_ = 3;   // 1 = LDS-treelet grid-stride kernel, 2 = persistent-thread kernel, 3 = by queue size
   uint32_t pt_split_closest_ = 600000u, pt_split_any_ = 2500000u;
   DevBuf<uint32_t> pt_overflow_;
@@ -426,7 +428,25 @@ class Handle : public HandleBase {
   DevBuf<unsigned long long> totals_;
   DevBuf<R> film_;
 
+  // which materials the aggregate really uses (declared-but-unused ones never reach a kernel)
+  void scan_materials(const rrt_scene_desc* d) {
+    has_transmissive_ = has_translucent_ = false;
+    for (size_t i = 0; i < d->n_prims; i++) {
+      const rrt_material& m = d->materials[d->prims[i].material];
+      auto black = [](const double* c) { return !(c[0] > 0.0) && !(c[1] > 0.0) && !(c[2] > 0.0); };
+      if (m.type == RRT_MAT_GLASS) {
+        has_transmissive_ = true;
+        if (black(m.kr) && black(m.kt)) throw PanicError("glass.rs:70 null BSDF: path.rs:103 `bounces -= 1` underflows at the first bounce");
+      }
+      if (m.type == RRT_MAT_TRANSLUCENT) {
+        has_transmissive_ = has_translucent_ = true;
+        if (black(m.reflect) && black(m.transmit)) throw PanicError("translucent.rs:66 null BSDF: path.rs:103 `bounces -= 1` underflows at the first bounce");
+      }
+    }
+  }
   void check_renderable() {
+    if (has_transmissive_ && desc_.integrator.type != RRT_INT_PATH)
+      throw UnsupportedError("Glass / Translucent materials are in scope for the Path integrator only: specular_transmit (integrator/mod.rs:199-301) makes DirectLighting a branching recursion");
     if (desc_.sampler.type != RRT_SAMPLER_HALTON)
       throw UnsupportedError("device sampler: only HaltonSampler (StratifiedSampler draws from thread_rng in the reference, SURVEY Q25 / §8f rank 4)");
     const uint64_t max_index = desc_.sampler.sample_stride * (desc_.sampler.samples_per_pixel + 1);
@@ -535,6 +555,7 @@ class Handle : public HandleBase {
       std::vector<uint32_t> ids = plane_ids(world, d->n_prim_order, d->world_bound);
       for (size_t i = 0; i < d->n_prim_order; i++) if (tris[i].plane != kSphereMark) tris[i].plane = ids[i];
     }
+    scan_materials(d);
     std::vector<Material<R>> mats(d->n_materials);
     for (size_t i = 0; i < d->n_materials; i++) {
       const rrt_material& m = d->materials[i];
@@ -542,6 +563,8 @@ class Handle : public HandleBase {
       o.type = m.type; o.remap_roughness = m.remap_roughness;
       for (int k = 0; k < 3; k++) { o.kd[k] = (R)m.kd[k]; o.ks[k] = (R)m.ks[k]; o.kr[k] = (R)m.kr[k]; o.eta[k] = (R)m.eta[k]; o.k[k] = (R)m.k[k]; }
       o.sigma = (R)m.sigma; o.roughness = (R)m.roughness; o.u_roughness = (R)m.u_roughness; o.v_roughness = (R)m.v_roughness;
+      for (int k = 0; k < 3; k++) { o.kt[k] = (R)m.kt[k]; o.reflect[k] = (R)m.reflect[k]; o.transmit[k] = (R)m.transmit[k]; }
+      o.index = (R)m.index;
     }
     std::vector<Light<R>> lights(d->n_lights);
     for (size_t i = 0; i < d->n_lights; i++) {
@@ -653,7 +676,7 @@ class Handle : public HandleBase {
     HIP_CHECK(hipStreamSynchronize(st_));
     cap_ = n;
     using V4 = typename Vec4T<R>::type;
-    const size_t NV = 14, NR = 5, NU = 5;   // 4-word records, reals, u32 per slot
+    const size_t NV = 14, NR = 5, NU = 9;   // 4-word records, reals, u32 per slot
     vpool_.alloc(NV * cap_);
     rpool_.alloc(NR * cap_);
     upool_.alloc(NU * cap_);
@@ -667,7 +690,7 @@ class Handle : public HandleBase {
     p.weight = nr(); p.pfx = nr(); p.pfy = nr(); p.lensx = nr(); p.lensy = nr();
     uint32_t* u = upool_.p;
     auto nu = [&]() { uint32_t* x = u; u += cap_; return x; };
-    p.q_active = (QEnt*)u; u += 2 * cap_; p.q_next = (QEnt*)u; u += 2 * cap_; p.hindex = nu();
+    p.q_active = (QEnt*)u; u += 4 * cap_; p.q_next = (QEnt*)u; u += 4 * cap_; p.hindex = nu();
     p.counters = counters_.p;
     if (deep_) deep_stack_.alloc((size_t)scene_.stack_depth * cap_);
 

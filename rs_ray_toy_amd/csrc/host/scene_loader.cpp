@@ -261,7 +261,25 @@ struct Loader {
         no_bump();
       } else if (type == "Debug") {
         m.type = RRT_MAT_DEBUG;
-      } else if (type == "GlassMaterial" || type == "TranslucentMaterial" || type == "DisneyMaterial") {
+      } else if (type == "GlassMaterial") {   // renderprocess.rs:772-798
+        m.type = RRT_MAT_GLASS;
+        put(fetch_rgb(mc, "kr", rgb1(1.0), name), m.kr);
+        put(fetch_rgb(mc, "kt", rgb1(1.0), name), m.kt);
+        m.index = fetch_float(mc, "eta", 1.5, name);
+        m.u_roughness = fetch_float(mc, "u_roughness", 0.0, name);
+        m.v_roughness = fetch_float(mc, "v_roughness", 0.0, name);
+        no_bump();
+        m.remap_roughness = read_bool(mc, "remap_roughness", false);
+      } else if (type == "TranslucentMaterial") {   // renderprocess.rs:695-720
+        m.type = RRT_MAT_TRANSLUCENT;
+        put(fetch_rgb(mc, "kd", rgb1(0.25), name), m.kd);
+        put(fetch_rgb(mc, "ks", rgb1(0.25), name), m.ks);
+        m.roughness = fetch_float(mc, "roughness", 0.1, name);
+        put(fetch_rgb(mc, "reflect", rgb1(0.25), name), m.reflect);
+        put(fetch_rgb(mc, "transmit", rgb1(0.25), name), m.transmit);
+        no_bump();
+        m.remap_roughness = read_bool(mc, "remap_roughness", false);
+      } else if (type == "DisneyMaterial") {
         materials[name] = MatEntry{-1, type};  // loads in the reference; RRT_EUNSUP only if a primitive uses it
         continue;
       } else if (type == "MixMaterial") {

@@ -147,11 +147,16 @@ def test_loader_error_behaviour(tmp_path):
     bad = json.loads(json.dumps(cfg)); bad["Integrator"] = {"integrator_type": "SPPM"}
     with pytest.raises(RrtUnsupported):
         Scene.loads(bad, root)
-    bad = json.loads(json.dumps(cfg)); bad["materials"].append({"material_type": "GlassMaterial", "material_name": "g"})
+    bad = json.loads(json.dumps(cfg)); bad["materials"].append({"material_type": "DisneyMaterial", "material_name": "g"})
     Scene.loads(bad, root)                                  # declared but unused: loads, like the reference
     bad["Aggregate"]["primitives"][0]["material_name"] = "g"
-    with pytest.raises(RrtUnsupported, match="GlassMaterial"):
+    with pytest.raises(RrtUnsupported, match="DisneyMaterial"):
         Scene.loads(bad, root)
+    glass = json.loads(json.dumps(cfg)); glass["materials"].append({"material_type": "GlassMaterial", "material_name": "g"})
+    glass["Aggregate"]["primitives"][0]["material_name"] = "g"
+    gm = Scene.loads(glass, root)                           # glass.rs defaults: kr = kt = 1, eta 1.5, smooth
+    m = gm.desc.materials[gm.desc.prims[0].material]
+    assert m.type == 5 and list(m.kr) == [1.0] * 3 and list(m.kt) == [1.0] * 3 and m.index == 1.5 and m.u_roughness == 0.0
     with pytest.raises(RrtError):
         Scene.loads("{ not json", root)
     # unknown material / primitive types are skipped with a diagnostic, not fatal (renderprocess.rs:864,1290)
