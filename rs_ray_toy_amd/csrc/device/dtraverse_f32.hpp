@@ -19,6 +19,13 @@
 #pragma once
 #include "dkernels.hpp"
 
+// refill thresholds of the persistent-thread kernels: idle lanes of a wave before it fetches new work
+#ifndef RRT_RG_REFILL
+#define RRT_RG_REFILL 32u
+#endif
+#ifndef RRT_TR_REFILL
+#define RRT_TR_REFILL 16u
+#endif
 namespace rrtd {
 
 constexpr int kTravBlock = 512;     // 8 waves share one LDS copy of the treelet
@@ -295,7 +302,7 @@ __global__ void __launch_bounds__(kPtBlock) k_trace_pt_f32(TravScene ts, Pools<f
     // ---- refill idle lanes ---------------------------------------------------------------------------------------
     const uint64_t idle = __ballot(state == ST_IDLE);
     const uint32_t n_idle = (uint32_t)__popcll(idle);
-    if (!exhausted && (n_idle >= 16u)) {
+    if (!exhausted && (n_idle >= RRT_TR_REFILL)) {
       if (lo == hi) {
         uint32_t base = 0;
         if (lane == 0) base = atomicAdd(work, grain);
@@ -459,29 +466,29 @@ static __global__ void __launch_bounds__(kBlock) k_sample_f32(SceneDev<float> s,
   if (dims_out) { double* dd = dims_out + 5 * (size_t)(pl * pd.ns + sl); dd[0] = d0; dd[1] = d1; dd[2] = d2; dd[3] = d3; dd[4] = halton_dim(s, index, 4); }
 }
 
-// Stage 2, persistent threads: the lens traces. A lane holds one sample and walks (trace, interface); a decided lane
-// (blocked or through all five traces' logic) takes the next sample of its wave's reserved range. Exactly one
-// rg_begin site and one rg_step site per loop iteration, so lanes in different traces still execute together.
-// Only survivors write: the camera ray and the weight (dead samples keep the 0 from stage 1).
+// Stage 2, persistent threads: the MAIN lens trace of every sample (generate_ray, camera.rs:534-580). 69 % of the
+// samples are blocked at some interface (29 % at the second, 16 % at the third, ...): a lane whose sample is decided
+// takes the next sample of its wave's reserved range, so the 13-interface loop runs with full lanes. A sample that
+// gets through writes its camera ray (by slot, until stage 4 knows whether it lives) and its weight.
 static __global__ void __launch_bounds__(kRgBlock) k_raygen_pt_f32(SceneDev<float> s, Pools<float> p, PassDesc pd, uint32_t* work) {
   __shared__ float4 lens_s[32];
   const uint32_t tid = threadIdx.x, lane = tid & 63u;
   if (tid < (uint32_t)s.n_lens) { const LensElem<float> e = s.lens[tid]; lens_s[tid] = make_float4(e.curvature_radius, e.thickness, e.eta, e.aperture_radius); }
   __syncthreads();
   const uint32_t total = pd.npix * pd.ns;
-  bool busy = false, exhausted = false, begin = false;
+  bool busy = false, exhausted = false;
   uint32_t slot = 0, lo = 0, hi = 0;
-  float pfx = 0, pfy = 0, lx = 0, ly = 0, w_main = 0, w_cur = 0;
+  float w_main = 0;
   RgLane L; L.i = -1; L.phase = 0; L.element_z = 0;
   const uint32_t n_waves = gridDim.x * (kRgBlock / 64);
   uint32_t grain = (total / (4u * n_waves) + 63u) & ~63u;
   grain = grain < 64u ? 64u : (grain > 1024u ? 1024u : grain);
 
   while (true) {
-    // ---- refill -------------------------------------------------------------------------------------------------
+    // ---- refill: new samples start their trace together --------------------------------------------------------------
     const uint64_t idle = __ballot(!busy);
     const uint32_t n_idle = (uint32_t)__popcll(idle);
-    if (!exhausted && n_idle >= 16u) {
+    if (!exhausted && n_idle >= RRT_RG_REFILL) {
       if (lo == hi) {
         uint32_t base = 0;
         if (lane == 0) base = atomicAdd(work, grain);
@@ -494,58 +501,37 @@ static __global__ void __launch_bounds__(kRgBlock) k_raygen_pt_f32(SceneDev<floa
         const uint32_t rank = (uint32_t)__popcll(idle & ((1ull << lane) - 1ull));
         if (!busy && rank < take) {
           slot = lo + rank;
-          pfx = p.pfx[slot]; pfy = p.pfy[slot]; lx = p.lensx[slot]; ly = p.lensy[slot];
-          L.phase = 0;
-          busy = true; begin = true;
+          rg_begin(s, p.pfx[slot], p.pfy[slot], p.lensx[slot], p.lensy[slot], &L, &w_main);
+          busy = true;
         }
         lo += take;
       }
     }
     if (__ballot(busy) == 0ull) { if (exhausted) break; else continue; }
-
-    // ---- start of a trace (main, x+, x-, y+, y-: camera.rs:589-624) -------------------------------------------------
-    if (begin) {
-      const float ox = L.phase == 1 ? 0.05f : (L.phase == 2 ? -0.05f : 0.0f);
-      const float oy = L.phase == 3 ? 0.05f : (L.phase == 4 ? -0.05f : 0.0f);
-      rg_begin(s, pfx + ox, pfy + oy, lx, ly, &L, &w_cur);
-      if (L.phase == 0) w_main = w_cur;
-      begin = false;
-    }
     // ---- one lens interface per busy lane -------------------------------------------------------------------------
     if (busy) {
       const bool ok = rg_step(lens_s, &L);
-      const bool through = ok && L.i < 0;
-      const bool pass = through && w_cur != 0.0f;           // this trace returned a non-zero weight
-      if (!ok || through) {
-        if (L.phase == 0) {
-          if (!pass) busy = false;                            // `if wt == 0.0 { return 0.0 }`
-          else {   // ray out of the lens = flip_z, camera_to_world (double normalise), ray.d.normalize() (camera.rs:558-565)
-            RayT<float> rl; rl.o = L.o; rl.d = L.d;
-            const RayT<float> rc = flip_z(rl);
-            const V3<float> wo = aff_pt(s.cam_m, rc.o);
-            const V3<float> wd = vnormalize(vnormalize(vnormalize(aff_vec(s.cam_m, rc.d))));
-            store_ray<float>(p.nray_o, p.nray_d, p.nray_l, slot, wo, V3<float>(), wd, Const<float>::inf, -1);   // by slot, until k_compact_alive
-            L.phase = 1; begin = true;
-          }
-        } else if (L.phase == 1) { L.phase = pass ? 3 : 2; begin = true; }
-        else if (L.phase == 2) { if (pass) { L.phase = 3; begin = true; } else busy = false; }
-        else if (L.phase == 3 && !pass) { L.phase = 4; begin = true; }
-        else {
-          if (pass) p.weight[slot] = w_main;   // alive: weight of the main ray (dead samples keep stage 1's 0)
-          busy = false;
+      if (!ok) busy = false;
+      else if (L.i < 0) {
+        if (w_main != 0.0f) {   // ray out of the lens = flip_z, camera_to_world (double normalise), ray.d.normalize() (camera.rs:558-565)
+          RayT<float> rl; rl.o = L.o; rl.d = L.d;
+          const RayT<float> rc = flip_z(rl);
+          const V3<float> wo = aff_pt(s.cam_m, rc.o);
+          const V3<float> wd = vnormalize(vnormalize(vnormalize(aff_vec(s.cam_m, rc.d))));
+          store_ray<float>(p.nray_o, p.nray_d, p.nray_l, slot, wo, V3<float>(), wd, Const<float>::inf, -1);
+          p.weight[slot] = w_main;   // dead samples keep stage 1's 0
         }
+        busy = false;
       }
     }
   }
 }
 
-// Stage 3: alive samples (weight > 0) -> q_active in slot order, with their rays moved to the same queue positions;
-// counts the reference's "rays generated". Each wave scans kCompactRun consecutive 64-slot groups, reserves its output
-// range with ONE atomic and then writes, so a 268 M-slot frame issues 65 k atomics on the queue counter instead of
-// 4 M (which serialise on one L2 atomic unit). Slot order keeps the per-slot state gathers of the first bounces
-// nearly coalesced (and makes the queue order deterministic).
+// Stage 3: samples whose main ray got through (weight > 0) -> staging queue q_next, in slot order. Each wave scans
+// kCompactRun consecutive 64-slot groups, reserves its output range with ONE atomic and then writes, so a 268 M-slot
+// frame issues 65 k atomics on the queue counter instead of 4 M (which serialise on one L2 atomic unit).
 constexpr uint32_t kCompactRun = 64;
-static __global__ void __launch_bounds__(kBlock) k_compact_alive(Pools<float> p, uint32_t total, int enqueue) {
+static __global__ void __launch_bounds__(kBlock) k_compact_alive(Pools<float> p, uint32_t total) {
   const uint32_t lane = threadIdx.x & 63u;
   const uint32_t wave = (blockIdx.x * blockDim.x + threadIdx.x) >> 6;
   const uint64_t base_slot = (uint64_t)wave * 64u * kCompactRun;
@@ -558,25 +544,61 @@ static __global__ void __launch_bounds__(kBlock) k_compact_alive(Pools<float> p,
   }
   if (n_alive == 0) return;
   uint32_t out = 0;
-  if (lane == 0) {
-    atomicAdd(&p.counters[C_CAMERA_RAYS], n_alive);
-    if (enqueue) out = atomicAdd(&p.counters[C_ACTIVE], n_alive);
-  }
-  if (!enqueue) return;
+  if (lane == 0) out = atomicAdd(&p.counters[C_NEXT], n_alive);
   out = __shfl(out, 0);
   for (uint32_t k = 0; k < kCompactRun; k++) {
     const uint64_t slot = base_slot + (uint64_t)k * 64u + lane;
     const bool alive = slot < total && p.weight[slot] > 0.0f;
     const uint64_t m = __ballot(alive);
-    if (alive) {
-      const uint32_t q = out + (uint32_t)__popcll(m & ((1ull << lane) - 1ull));
-      p.q_active[q] = QEnt{(uint32_t)slot, 5u, p.hindex[slot], 0u};   // five camera dimensions consumed, bounce 0
-      p.path[q] = make_float4(1.0f, 1.0f, 1.0f, 1.0f);   // beta, eta_scale
-      p.ray_o[q] = p.nray_o[slot]; p.ray_d[q] = p.nray_d[slot]; p.ray_l[q] = make_float4(0.0f, 0.0f, 0.0f, 0.0f);
-      p.L[slot] = make_float4(0.0f, 0.0f, 0.0f, 0.0f);
-    }
+    if (alive) p.q_next[out + (uint32_t)__popcll(m & ((1ull << lane) - 1ull))] = QEnt{(uint32_t)slot, 0u, 0u, 0u};
     out += (uint32_t)__popcll(m);
   }
+}
+
+// Stage 4, dense over the staging queue: the auxiliary rays of generate_ray_differential (camera.rs:582-628) at
+// p_film + 0.05 px in x (then - 0.05 if that one is blocked), then the same in y. Nearly every main-ray survivor
+// passes x+ and y+, so all lanes run the same 2 x 13 interfaces. A sample whose x or y pair is blocked both ways
+// gets weight 0; the others enter q_active with ray, path record and a zeroed L. `enqueue` = 0 for AOIntegrator.
+RRT_DEV bool rg_trace(const SceneDev<float>& s, const float4* lens_s, float pfx, float pfy, float lx, float ly) {
+  RgLane L; L.phase = 0;
+  float w = 0.0f;
+  rg_begin(s, pfx, pfy, lx, ly, &L, &w);
+  while (L.i >= 0) if (!rg_step(lens_s, &L)) return false;
+  return w != 0.0f;
+}
+static __global__ void __launch_bounds__(kRgBlock) k_raygen_aux_f32(SceneDev<float> s, Pools<float> p, int enqueue) {
+  __shared__ float4 lens_s[32];
+  __shared__ uint32_t push_lds[kRgBlock / 64 + 1];
+  const uint32_t tid = threadIdx.x;
+  const uint32_t n = p.counters[C_NEXT];
+  if (blockIdx.x * blockDim.x >= n) return;   // the grid is sized for the worst case
+  if (tid < (uint32_t)s.n_lens) { const LensElem<float> e = s.lens[tid]; lens_s[tid] = make_float4(e.curvature_radius, e.thickness, e.eta, e.aperture_radius); }
+  __syncthreads();
+  const uint32_t i = blockIdx.x * blockDim.x + tid;
+  bool alive = false;
+  uint32_t slot = 0;
+  if (i < n) {
+    slot = p.q_next[i].slot;
+    const float pfx = p.pfx[slot], pfy = p.pfy[slot], lx = p.lensx[slot], ly = p.lensy[slot];
+    bool okx = rg_trace(s, lens_s, pfx + 0.05f, pfy, lx, ly);
+    if (!okx) okx = rg_trace(s, lens_s, pfx - 0.05f, pfy, lx, ly);
+    bool oky = false;
+    if (okx) {
+      oky = rg_trace(s, lens_s, pfx, pfy + 0.05f, lx, ly);
+      if (!oky) oky = rg_trace(s, lens_s, pfx, pfy - 0.05f, lx, ly);
+    }
+    alive = okx && oky;
+    if (!alive) p.weight[slot] = 0.0f;
+  }
+  const bool enq = alive && enqueue;
+  const uint32_t q = block_push(&p.counters[C_ACTIVE], enq, push_lds);
+  (void)block_push(&p.counters[C_CAMERA_RAYS], alive, push_lds);
+  if (enq) {
+    p.q_active[q] = QEnt{slot, 5u, p.hindex[slot], 0u};   // five camera dimensions consumed, bounce 0
+    p.path[q] = make_float4(1.0f, 1.0f, 1.0f, 1.0f);      // beta, eta_scale
+    p.ray_o[q] = p.nray_o[slot]; p.ray_d[q] = p.nray_d[slot]; p.ray_l[q] = make_float4(0.0f, 0.0f, 0.0f, 0.0f);
+  }
+  if (alive) p.L[slot] = make_float4(0.0f, 0.0f, 0.0f, 0.0f);
 }
 
 }  // namespace rrtd

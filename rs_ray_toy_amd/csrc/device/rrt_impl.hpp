@@ -745,7 +745,9 @@ class Handle : public HandleBase {
         hipLaunchKernelGGL(k_sample_f32, dim3((total + kBlock - 1) / kBlock), dim3(kBlock), 0, st_, scene_, pool_, pd, dims_out);
         hipLaunchKernelGGL(k_raygen_pt_f32, dim3(g), dim3(kRgBlock), 0, st_, scene_, pool_, pd, &counters_.p[C_WORK_AUX]);
         const uint32_t n_cw = (total + 64u * kCompactRun - 1) / (64u * kCompactRun);   // waves
-        hipLaunchKernelGGL(k_compact_alive, dim3((n_cw * 64u + kBlock - 1) / kBlock), dim3(kBlock), 0, st_, pool_, total, enqueue);
+        hipLaunchKernelGGL(k_compact_alive, dim3((n_cw * 64u + kBlock - 1) / kBlock), dim3(kBlock), 0, st_, pool_, total);
+        hipLaunchKernelGGL(k_raygen_aux_f32, dim3((total + kRgBlock - 1) / kRgBlock), dim3(kRgBlock), 0, st_, scene_, pool_, enqueue);
+        hipLaunchKernelGGL(k_rotate, dim3(1), dim3(1), 0, st_, counters_.p, 4);   // q_next was only a staging queue
         HIP_CHECK(hipGetLastError());
         return;
       }
