@@ -520,6 +520,9 @@ struct Surf {   // the parts of SurfaceInteraction (interaction.rs:95-181) the i
 // neighbour. f64 mode: the reference expression, p_lo = 0.
 template <typename R>
 RRT_DEV void spawn_point(V3<R> o, V3<R> d, R t, R u, R v, V3<R> p0, V3<R> p1, V3<R> p2, V3<R>* p, V3<R>* p_lo) {
+#ifdef RRT_SPAWN_OLD
+  { *p = o + d * t; *p_lo = V3<R>(); return; }
+#endif
   if (sizeof(R) == 8) { *p = o + d * t; *p_lo = V3<R>(); return; }
   const V3<R> w = (p1 - p0) * u + (p2 - p0) * v;
   const V3<R> s = p0 + w;

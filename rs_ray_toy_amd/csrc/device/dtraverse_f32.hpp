@@ -200,10 +200,13 @@ __global__ void __launch_bounds__(kTravBlock) k_trace_pairs_f32(TravScene ts, Po
       const uint32_t ref0 = __float_as_uint(d.x), ref1 = __float_as_uint(d.y), meta = __float_as_uint(d.z);
       const uint32_t n0 = (meta >> 2) & 0xfffu, n1 = (meta >> 14) & 0xfffu;
       float t0, t1;
-      const bool h0 = box_slabs_f32(a.x, a.y, a.z, a.w, b.x, b.y, r, &t0) && t0 < r.tmax;
-      const bool h1 = box_slabs_f32(b.z, b.w, c.x, c.y, c.z, c.w, r, &t1) && t1 < r.tmax;
+      const bool s0 = box_slabs_f32(a.x, a.y, a.z, a.w, b.x, b.y, r, &t0), s1 = box_slabs_f32(b.z, b.w, c.x, c.y, c.z, c.w, r, &t1);
+      const bool h0 = s0 && t0 < r.tmax, h1 = s1 && t1 < r.tmax;
       const bool second_first = (r.neg >> (meta & 3u)) & 1u;   // dir_is_neg[axis]: the reference visits the second child first
-      const bool hn = second_first ? h1 : h0, hf = second_first ? h0 : h1;
+      // The near child is tested now, like the reference does. The far child's `t_min < t_max` belongs to the moment it
+      // is popped: a closest-hit t_max can also GROW in between (each accepted hit overwrites it, Q10), so it is pushed
+      // whenever its slabs are hit and judged at pop time. Shadow rays never change t_max: prune at once.
+      const bool hn = second_first ? h1 : h0, hf = ANY ? (second_first ? h0 : h1) : (second_first ? s0 : s1);
       const uint32_t refn = second_first ? ref1 : ref0, reff = second_first ? ref0 : ref1;
       const uint32_t nn = second_first ? n1 : n0, nf = second_first ? n0 : n1;
       const float tf = second_first ? t0 : t1;
@@ -347,10 +350,11 @@ __global__ void __launch_bounds__(kPtBlock) k_trace_pt_f32(TravScene ts, Pools<f
       const uint32_t ref0 = __float_as_uint(d.x), ref1 = __float_as_uint(d.y), meta = __float_as_uint(d.z);
       const uint32_t n0 = (meta >> 2) & 0xfffu, n1 = (meta >> 14) & 0xfffu;
       float t0, t1;
-      const bool h0 = box_slabs_f32(a.x, a.y, a.z, a.w, b.x, b.y, r, &t0) & (t0 < r.tmax);
-      const bool h1 = box_slabs_f32(b.z, b.w, c.x, c.y, c.z, c.w, r, &t1) & (t1 < r.tmax);
+      const bool s0 = box_slabs_f32(a.x, a.y, a.z, a.w, b.x, b.y, r, &t0), s1 = box_slabs_f32(b.z, b.w, c.x, c.y, c.z, c.w, r, &t1);
+      const bool h0 = s0 & (t0 < r.tmax), h1 = s1 & (t1 < r.tmax);
       const bool second_first = (r.neg >> (meta & 3u)) & 1u;
-      const bool hn = second_first ? h1 : h0, hf = second_first ? h0 : h1;
+      // far child: judged against t_max when popped (closest-hit t_max can grow, Q10); see k_trace_pairs_f32
+      const bool hn = second_first ? h1 : h0, hf = ANY ? (second_first ? h0 : h1) : (second_first ? s0 : s1);
       const uint32_t refn = second_first ? ref1 : ref0, reff = second_first ? ref0 : ref1;
       const uint32_t nn = second_first ? n1 : n0, nf = second_first ? n0 : n1;
       const float tf = second_first ? t0 : t1;

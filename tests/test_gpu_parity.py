@@ -79,6 +79,33 @@ def test_trace_closest_f32(which, cfg2_scene, hf_scene):
     np.testing.assert_allclose(got["t"][hit], ref["t"][hit], rtol=2e-4, atol=1e-4)
 
 
+def test_trace_closest_when_tmax_grows(workdir):
+    """Q10 makes t_max non-monotonic: a later accepted hit that is FARTHER overwrites the nearer one (closed, rotated
+    cubes: the back face's fat leaf box starts before the front hit). A far child skipped because its box began beyond
+    the t_max of that moment must therefore still be judged against the t_max at the time it is popped. Camera rays
+    through tilted cubes, fp32 product kernels vs the oracle: every winner identical."""
+    cfg, root = scenes.cfg2(workdir, xres=128, yres=128, nsamp=9, max_depth=1)
+    for inst in cfg["Aggregate"]["primitives"][0]["instances"]:
+        inst["rotation_axis"] = [1.0, 2.0, 3.0]
+    sc = Scene.loads(cfg, root)
+    _, rays, w = O.camera_samples(sc, (0, 0, 128, 128), 1, 9)
+    alive = w > 0
+    o, d = rays[alive, :3], rays[alive, 3:]
+    tmax = np.full(len(o), np.inf)
+    ref = O.trace_closest(sc, o, d, tmax, flat=True)
+    hit = ref["prim"] >= 0
+    assert hit.sum() > 2000
+    r = Renderer(sc, 0, RRT_F32)
+    got = r.trace_closest(o, d, tmax)
+    big = Renderer(sc, 0, RRT_F32)
+    big.set_option("persistent_traversal", 2)      # the persistent-thread kernel regardless of the queue size
+    got_pt = big.trace_closest(o, d, tmax)
+    r.close(); big.close()
+    assert (got["prim"] == ref["prim"]).mean() > 0.9999, (got["prim"] != ref["prim"]).sum()
+    assert (got_pt["prim"] == ref["prim"]).mean() > 0.9999, (got_pt["prim"] != ref["prim"]).sum()
+    np.testing.assert_allclose(got["t"][hit & (got["prim"] == ref["prim"])], ref["t"][hit & (got["prim"] == ref["prim"])], rtol=2e-6)
+
+
 @pytest.mark.parametrize("prec", [RRT_F64, RRT_F32])
 def test_trace_any(prec, hf_scene):
     sc = hf_scene
@@ -317,6 +344,7 @@ def test_full_size_frame_properties(workdir):
     # of the vertices themselves to fp32 (2e-6 at coordinates of ~35): a shadow ray passing within that distance of a
     # silhouette edge flips, ~4e-5 of the samples, i.e. ~1.5 % of the pixels hold one. Bar: 97.5 % of the pixels
     # within the stated 1e-4, none beyond one sample (3e-2), mean deviation below 1e-4 of the brightest pixel.
+    print("full-size fp32 vs oracle: within 1e-4: %.4f, max %.3e, mean %.3e" % ((diff < 1e-4).mean(), diff.max(), diff.mean()))
     assert (diff < 1e-4).mean() > 0.975, (diff < 1e-4).mean()
     assert diff.max() < 3e-2, diff.max()
     assert diff.mean() < 1e-4, diff.mean()
