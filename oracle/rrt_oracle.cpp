@@ -1633,6 +1633,40 @@ int oracle_sphere_intersect_p(const rrt_scene_desc* d, uint32_t sphere, const do
   return sphere_intersect_p(sphere_ref(sc, sphere), r) ? 1 : 0;
 }
 
+// Bsdf of material `material` on a surface with n = ns = +z, dpdu = +x (local frame = world frame), for unit tests of
+// the BxDFs against closed forms: out = {f.rgb, pdf(wo, wi), sampled wi.xyz, sampled f.rgb, sampled pdf, sampled flags,
+// bsdf.eta, number of lobes, num_components(ALL & !SPECULAR)}.
+int oracle_bsdf_eval(const rrt_scene_desc* d, uint32_t material, int allow_multiple_lobes, const double* wo_in, const double* wi_in,
+                     double u0, double u1, double* out16) {
+  return guarded([&]() {
+    if (material >= d->n_materials) throw OraclePanic{"oracle_bsdf_eval: material index out of range"};
+    // a prim that carries this material is needed by compute_scattering(); build a private one-prim view
+    rrt_scene_desc view = *d;
+    rrt_prim pr{};
+    pr.type = RRT_PRIM_TRIANGLE; pr.shape = 0; pr.instance = -1; pr.material = material;
+    view.prims = &pr; view.n_prims = 1;
+    Scene sv{&view, false};
+    SI si;
+    si_new(&si, V3(), 0.0, 0.0, V3(wo_in[0], wo_in[1], wo_in[2]), V3(1.0, 0.0, 0.0), V3(0.0, 1.0, 0.0));
+    si.prim = 0; si.valid = true;
+    Bsdf b;
+    compute_scattering(sv, si, &b, allow_multiple_lobes != 0);
+    V3 wo(wo_in[0], wo_in[1], wo_in[2]), wi(wi_in[0], wi_in[1], wi_in[2]);
+    Rgb f = b.f(wo, wi, BXDF_ALL);
+    out16[0] = f.c[0]; out16[1] = f.c[1]; out16[2] = f.c[2];
+    out16[3] = b.pdf(wo, wi, BXDF_ALL);
+    V3 ws;
+    double ps = 0.0;
+    uint8_t fl = 0;
+    Rgb fs = b.sample_f(wo, &ws, u0, u1, &ps, BXDF_ALL, &fl);
+    out16[4] = ws.x; out16[5] = ws.y; out16[6] = ws.z;
+    out16[7] = fs.c[0]; out16[8] = fs.c[1]; out16[9] = fs.c[2];
+    out16[10] = ps; out16[11] = (double)fl; out16[12] = b.eta; out16[13] = (double)b.n;
+    out16[14] = (double)b.num_components(BXDF_ALL & ~BXDF_SPECULAR);
+    out16[15] = 0.0;
+  });
+}
+
 // BVHAccel::intersect / intersect_p on ray batches (rays are used as given: d is NOT re-normalised) --------
 int oracle_trace_closest(const rrt_scene_desc* d, const double* o, const double* dir, const double* tmax, size_t n,
                          double* t_out, int32_t* prim_out, double* u_out, double* v_out, uint32_t* nodes, uint32_t* prims,
@@ -1640,13 +1674,19 @@ int oracle_trace_closest(const rrt_scene_desc* d, const double* o, const double*
                          int mode /* bit0: flat */, double* margin_out /* optional n */) {
   return guarded([&]() {
     Scene sc{d, (mode & 1) != 0};
+    std::string panic;   // an exception must not leave the OpenMP region: first message is re-thrown after the loop
 #pragma omp parallel for schedule(dynamic, 64)
     for (long i = 0; i < (long)n; i++) {
       Ray r; r.o = V3(o[3 * i], o[3 * i + 1], o[3 * i + 2]); r.d = V3(dir[3 * i], dir[3 * i + 1], dir[3 * i + 2]); r.t_max = tmax[i];
       SI si; HitInfo hi;
       uint32_t nn = 0, np = 0;
       double margin = INF;
-      bool hit = scene_intersect(sc, &r, &si, &hi, nullptr, &nn, &np, margin_out ? &margin : nullptr);
+      bool hit = false;
+      try { hit = scene_intersect(sc, &r, &si, &hi, nullptr, &nn, &np, margin_out ? &margin : nullptr); }
+      catch (const OraclePanic& e) {
+#pragma omp critical
+        if (panic.empty()) panic = e.msg;
+      }
       if (margin_out) margin_out[i] = margin;
       t_out[i] = r.t_max;
       prim_out[i] = hit ? hi.order_index : -1;
@@ -1657,22 +1697,29 @@ int oracle_trace_closest(const rrt_scene_desc* d, const double* o, const double*
       if (p_out) { p_out[3 * i] = si.p.x; p_out[3 * i + 1] = si.p.y; p_out[3 * i + 2] = si.p.z; }
       if (n_out) { n_out[3 * i] = si.n.x; n_out[3 * i + 1] = si.n.y; n_out[3 * i + 2] = si.n.z; }
     }
+    if (!panic.empty()) throw OraclePanic{panic};
   });
 }
 int oracle_trace_any(const rrt_scene_desc* d, const double* o, const double* dir, const double* tmax, size_t n, uint8_t* occluded,
                      uint32_t* nodes, uint32_t* prims, int mode, double* margin_out) {
   return guarded([&]() {
     Scene sc{d, (mode & 1) != 0};
+    std::string panic;
 #pragma omp parallel for schedule(dynamic, 64)
     for (long i = 0; i < (long)n; i++) {
       Ray r; r.o = V3(o[3 * i], o[3 * i + 1], o[3 * i + 2]); r.d = V3(dir[3 * i], dir[3 * i + 1], dir[3 * i + 2]); r.t_max = tmax[i];
       uint32_t nn = 0, np = 0;
       double margin = INF;
-      occluded[i] = scene_intersect_p(sc, r, nullptr, &nn, &np, margin_out ? &margin : nullptr) ? 1 : 0;
+      try { occluded[i] = scene_intersect_p(sc, r, nullptr, &nn, &np, margin_out ? &margin : nullptr) ? 1 : 0; }
+      catch (const OraclePanic& e) {
+#pragma omp critical
+        if (panic.empty()) panic = e.msg;
+      }
       if (margin_out) margin_out[i] = margin;
       if (nodes) nodes[i] = nn;
       if (prims) prims[i] = np;
     }
+    if (!panic.empty()) throw OraclePanic{panic};
   });
 }
 

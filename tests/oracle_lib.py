@@ -23,6 +23,8 @@ def lib():
         L.oracle_radical_inverse.argtypes = [C.c_int, C.c_uint64]
         L.oracle_vec3_ops.argtypes = [C.c_void_p] * 5
         L.oracle_sphere_intersect_p.argtypes = [C.c_void_p, C.c_uint32, C.c_void_p, C.c_void_p]
+        L.oracle_bsdf_eval.argtypes = [C.c_void_p, C.c_uint32, C.c_int, C.c_void_p, C.c_void_p, C.c_double, C.c_double, C.c_void_p]
+        L.oracle_bsdf_eval.restype = C.c_int
         L.oracle_trace_closest.argtypes = [C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_size_t] + [C.c_void_p] * 8 + [C.c_int, C.c_void_p]
         L.oracle_trace_any.argtypes = [C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_size_t, C.c_void_p, C.c_void_p, C.c_void_p, C.c_int, C.c_void_p]
         L.oracle_camera_samples.argtypes = [C.c_void_p, C.c_void_p, C.c_uint64, C.c_uint64, C.c_void_p, C.c_void_p, C.c_void_p]
@@ -110,3 +112,12 @@ def random_rays(scene, n, seed=0):
     d = tgt - o
     d /= np.linalg.norm(d, axis=1, keepdims=True)
     return o, d, np.full(n, np.inf)
+
+
+def bsdf_eval(scene, material, wo, wi, u0=0.5, u1=0.5, allow_multiple_lobes=True):
+    """Bsdf of `material` in its local frame (n = +z): dict with f, pdf and one sample_f draw."""
+    wo = np.ascontiguousarray(wo, np.float64); wi = np.ascontiguousarray(wi, np.float64)
+    out = np.zeros(16)
+    _check(lib().oracle_bsdf_eval(_d(scene), material, 1 if allow_multiple_lobes else 0, wo.ctypes.data, wi.ctypes.data, u0, u1, out.ctypes.data))
+    return dict(f=out[0:3].copy(), pdf=out[3], s_wi=out[4:7].copy(), s_f=out[7:10].copy(), s_pdf=out[10], s_flags=int(out[11]), eta=out[12],
+                n_lobes=int(out[13]), n_nonspecular=int(out[14]))
