@@ -263,7 +263,8 @@ int rrt_write_png(const char* path, const uint8_t* rgba, int w, int h);
 
 /* ---- device side --------------------------------------------------------- */
 int rrt_device_count(void);
-/* uploads scene (flattened to world space, SoA), allocates wavefront pools */
+/* uploads the scene (rigid triangle instances flattened to world space; spheres keep their transforms); the wavefront
+ * pools are allocated on first use. RRT_EDEVICE without a HIP device: there is no CPU fallback. */
 int rrt_create(int device, const rrt_scene_desc* desc, int precision, rrt_handle** out);
 void rrt_destroy(rrt_handle*);
 /* raw hipStream_t of the handle (for event timing by the caller) */
@@ -288,12 +289,15 @@ int rrt_render_rect(rrt_handle*, const int32_t rect[4], void* film_xyzw, int fil
                     rrt_render_stats* stats /* may be NULL */);
 
 /* Multi-GPU film partition: the same, for the rows of the interleaved 16-row tile bands b with
- * b % world == rank (tile height of integrator/mod.rs:55), rendered as one pixel set. Disjoint across ranks under
- * the box filter, so summing the ranks' films (one RCCL reduce) reassembles Film::pixels. */
+ * b % world == rank (tile height of integrator/mod.rs:55), rendered as one pixel set. Box filter: the ranks' films are
+ * disjoint; wider filters: a sample's splat may land in a neighbour's rows of this rank's film. Either way summing
+ * the ranks' films (one RCCL reduce) reassembles Film::pixels. */
 int rrt_render_bands(rrt_handle*, int rank, int world, void* film_xyzw, int film_mem, rrt_render_stats* stats);
 
-/* handle options: "max_paths" (wavefront pool slots), "count_traversal" (per-kernel node/triangle counters),
- * "persistent_traversal" (0 = generic traversal kernels) */
+/* handle options: "max_paths" (wavefront pool slots; default 2^28 clamped to half of the free HBM), "count_traversal"
+ * (exact node / triangle-test counters in rrt_render_stats, generic kernels), "persistent_traversal" (fp32: 0 generic
+ * kernels, 1 grid-stride pair-node kernel, 2 persistent-thread kernel, 3 = default, by queue size), "pt_split_closest" /
+ * "pt_split_any" (queue sizes at which 3 switches), "raygen_pt" (fp32: 0 = the generic two-stage raygen) */
 int rrt_set_option(rrt_handle*, const char* key, double value);
 
 const char* rrt_last_error(void);
