@@ -49,7 +49,14 @@ def cpu_baseline(scene, target_seconds):
         rays += st2.camera_rays
         secs += dt2
         rows += 16 * bands
+    # "reference-faithful" variant: the reference rebuilds the 3.67 M-entry Halton permutation table
+    # for every 16x16 tile (integrator/mod.rs:73); one band with that cost model, reported next to the fair number
+    t0 = time.perf_counter()
+    _, stf = O.render(scene, (0, mid, W, mid + 16), stats=True, faithful_sampler_rebuild=True)
+    dtf = time.perf_counter() - t0
+    faithful = (stf.closest_queries + stf.any_queries) / dtf / 1e6
     return {"value": round(q / secs / 1e6, 4), "unit": "Mrays/s", "cores": cores, "kind": "port",
+            "faithful_value": round(faithful, 4),
             "sample": "rows %d..%d of the same %dx%d frame at full spp/depth (%d ray queries, %.1f s, f64 oracle incl. the "
                       "reference's BSDF-sampled MIS ray and final dead bounce)" % (mid, mid + rows, W, H, q, secs),
             "camera_mrays_per_s": round(rays / secs / 1e6, 4), "est_full_frame_s": round(secs * H / rows, 1)}
@@ -68,6 +75,7 @@ def main():
     ap.add_argument("--cpu-seconds", type=float, default=15.0, help="target wall time of the cpu_baseline sample")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--max-paths", type=int, default=0)
+    ap.add_argument("--opt", action="append", default=[], help="handle option key=value (rrt_set_option), e.g. pt_split_any=1e9")
     args = ap.parse_args()
 
     import numpy as np
@@ -101,6 +109,9 @@ def main():
     r = Renderer(scene, local_rank, RRT_F32)
     if args.max_paths:
         r.set_option("max_paths", args.max_paths)
+    for kv in args.opt:
+        k, v = kv.split("=")
+        r.set_option(k, float(v))
     film = torch.zeros((H, W, 4), dtype=torch.float32, device=f"cuda:{local_rank}")
 
     def step(collect=False):
