@@ -429,10 +429,9 @@ __global__ void __launch_bounds__(kBlock) k_raygen(SceneDev<R> s, Pools<R> p, Pa
     alive = w != R(0);
     p.hindex[slot] = index;
     p.weight[slot] = alive ? w : R(0);
-    p.pfx[slot] = pfx; p.pfy[slot] = pfy;
+    p.samp[slot] = mk4<R>(pfx, pfy, lx, ly);
     if (alive) {
       store_ray<R>(p.nray_o, p.nray_d, p.nray_l, slot, ray.o, V3<R>(), ray.d, Const<R>::inf, -1);
-      p.lensx[slot] = lx; p.lensy[slot] = ly;
     }
     if (dbg_dims) {
       double* dd = dbg_dims + 5 * (size_t)(pl * pd.ns + sl);   // [pixel][sample]
@@ -457,7 +456,8 @@ __global__ void __launch_bounds__(kBlock) k_raygen_aux(SceneDev<R> s, Pools<R> p
   uint32_t slot = 0;
   if (i < n) {
     slot = p.q_next[i].slot;
-    const R pfx = p.pfx[slot], pfy = p.pfy[slot], lx = p.lensx[slot], ly = p.lensy[slot];
+    const typename Vec4T<R>::type cs = p.samp[slot];
+    const R pfx = cs.x, pfy = cs.y, lx = cs.z, ly = cs.w;
     RayT<R> aux;
     R wtx = generate_ray(s, pfx + R(0.05), pfy, lx, ly, &aux);
     if (wtx == R(0)) wtx = generate_ray(s, pfx + R(-0.05), pfy, lx, ly, &aux);
@@ -1039,7 +1039,8 @@ __global__ void __launch_bounds__(kBlock) k_film_wide(SceneDev<R> s, Pools<R> p,
       if (sx < 0 || sx >= s.xres || !pass_pixel_inverse(pd, sx, sy, &pl)) continue;
       for (uint32_t sl = 0; sl < pd.ns; sl++) {
         const uint32_t slot = sl * pd.npix + pl;
-        const R dx = p.pfx[slot] - R(0.5), dy = p.pfy[slot] - R(0.5);
+        const typename Vec4T<R>::type cs = p.samp[slot];
+        const R dx = cs.x - R(0.5), dy = cs.y - R(0.5);
         // p0 = ceil(d - r), p1 = trunc(d + r) + 1 (Point2i::from truncates), clipped to the film by the tile bounds
         const R p0x = ceil(dx - s.filter_rx), p0y = ceil(dy - s.filter_ry);
         const R p1x = trunc(dx + s.filter_rx) + R(1), p1y = trunc(dy + s.filter_ry) + R(1);

@@ -454,7 +454,7 @@ RRT_DEV bool rg_step(const float4* lens_s, RgLane* L) {
 
 // Stage 1, dense (one thread per slot, every lane busy): get_camerasample (samplers/mod.rs:28-34) = Halton index and
 // the four film / lens dimensions, plus the initial path state. All stores are coalesced in slot order, which is why
-// the sample of every slot is written: 6 streamed words per slot. `dims_out` (optional): the five sampler dimensions per slot, [pixel][sample] order (rrt_camera_samples)
+// the sample of every slot is written: 6 streamed words per slot (one 128-bit sample record, index, weight). `dims_out` (optional): the five sampler dimensions per slot, [pixel][sample] order (rrt_camera_samples)
 static __global__ void __launch_bounds__(kBlock) k_sample_f32(SceneDev<float> s, Pools<float> p, PassDesc pd, double* dims_out) {
   const uint32_t slot = blockIdx.x * blockDim.x + threadIdx.x;
   if (slot >= pd.npix * pd.ns) return;
@@ -463,8 +463,7 @@ static __global__ void __launch_bounds__(kBlock) k_sample_f32(SceneDev<float> s,
   pass_pixel(pd, pd.pix_begin + pl, &px, &py);
   const uint32_t index = halton_pixel_offset(s, px, py) + (pd.s_begin + sl) * s.stride;
   const double d0 = halton_dim(s, index, 0), d1 = halton_dim(s, index, 1), d2 = halton_cam_dim(s, index, 0), d3 = halton_cam_dim(s, index, 1);
-  p.pfx[slot] = (float)px + to_real<float>(d0); p.pfy[slot] = (float)py + to_real<float>(d1);
-  p.lensx[slot] = to_real<float>(d2) + 0.5f; p.lensy[slot] = to_real<float>(d3) + 0.5f;   // p_lens (Q5)
+  p.samp[slot] = make_float4((float)px + to_real<float>(d0), (float)py + to_real<float>(d1), to_real<float>(d2) + 0.5f, to_real<float>(d3) + 0.5f);   // p_film, p_lens (Q5)
   p.hindex[slot] = index;
   p.weight[slot] = 0.0f;
   if (dims_out) { double* dd = dims_out + 5 * (size_t)(pl * pd.ns + sl); dd[0] = d0; dd[1] = d1; dd[2] = d2; dd[3] = d3; dd[4] = halton_dim(s, index, 4); }
@@ -505,7 +504,8 @@ static __global__ void __launch_bounds__(kRgBlock) k_raygen_pt_f32(SceneDev<floa
         const uint32_t rank = (uint32_t)__popcll(idle & ((1ull << lane) - 1ull));
         if (!busy && rank < take) {
           slot = lo + rank;
-          rg_begin(s, p.pfx[slot], p.pfy[slot], p.lensx[slot], p.lensy[slot], &L, &w_main);
+          const float4 cs = p.samp[slot];
+          rg_begin(s, cs.x, cs.y, cs.z, cs.w, &L, &w_main);
           busy = true;
         }
         lo += take;
@@ -583,7 +583,8 @@ static __global__ void __launch_bounds__(kRgBlock) k_raygen_aux_f32(SceneDev<flo
   uint32_t slot = 0;
   if (i < n) {
     slot = p.q_next[i].slot;
-    const float pfx = p.pfx[slot], pfy = p.pfy[slot], lx = p.lensx[slot], ly = p.lensy[slot];
+    const float4 cs = p.samp[slot];
+    const float pfx = cs.x, pfy = cs.y, lx = cs.z, ly = cs.w;
     bool okx = rg_trace(s, lens_s, pfx + 0.05f, pfy, lx, ly);
     if (!okx) okx = rg_trace(s, lens_s, pfx - 0.05f, pfy, lx, ly);
     bool oky = false;

@@ -154,8 +154,7 @@ struct Pools {
   // per-slot state: only what outlives a path's queue entries
   V4* L;                 // {L.r, L.g, L.b, -}: radiance; touched by unoccluded shadow rays and the film kernel
   R* weight;             // camera ray weight (0 = dead sample: its L is never read)
-  R *pfx, *pfy;          // p_film
-  R *lensx, *lensy;      // p_lens (raygen only)
+  V4* samp;              // camera sample {p_film.x, p_film.y, p_lens.x, p_lens.y}: one 128-bit gather per survivor
   uint32_t* hindex;      // Halton index (raygen -> first queue entry)
   uint32_t* counters;    // [0] active, [1] next, [2] shadow, [3] camera rays, [4..] stats
 };
