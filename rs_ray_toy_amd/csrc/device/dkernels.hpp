@@ -33,12 +33,43 @@ RRT_DEV uint32_t real_to_bits(float v) { return __float_as_uint(v); }
 RRT_DEV uint32_t real_to_bits(double v) { return (uint32_t)__double_as_longlong(v); }
 template <typename R> RRT_DEV typename Vec4T<R>::type mk4(R x, R y, R z, R w) { typename Vec4T<R>::type v; v.x = x; v.y = y; v.z = z; v.w = w; return v; }
 template <typename R> RRT_DEV typename Vec4T<R>::type mk4u(R x, R y, R z, uint32_t w) { return mk4<R>(x, y, z, bits_to_real(w, R(0))); }
-template <typename R> RRT_DEV void store_ray(typename Vec4T<R>::type* ro, typename Vec4T<R>::type* rd, typename Vec4T<R>::type* rl, uint32_t i, V3<R> o, V3<R> lo,
-                                             V3<R> d, R tmax, int skip) {
-  ro[i] = mk4<R>(o.x, o.y, o.z, tmax);
-  rd[i] = mk4u<R>(d.x, d.y, d.z, (uint32_t)skip);
-  rl[i] = mk4<R>(lo.x, lo.y, lo.z, R(0));
+// Low word of a double-float origin (spawn_point()), 3 x 10 bits: lo_k is at most half an ulp of hi_k, so it is stored
+// as round(lo_k / ulp(hi_k) * 1024) + 512 (resolution ulp / 1024 ~ 4e-9 at coordinates of ~35). Top bits 11 tag the word.
+RRT_DEV uint32_t pack_lo(V3<float> hi, V3<float> lo) {
+  auto q = [](float h, float l) -> uint32_t {
+    const uint32_t e = (__float_as_uint(h) >> 23) & 0xffu;
+    if (e < 64u || e > 250u) return 512u;
+    const float scaled = l * __uint_as_float((287u - e) << 23);   // l * 2^(33 - (e - 127)) = l / ulp(h) * 1024
+    const float r = rintf(scaled) + 512.0f;
+    return (uint32_t)fminf(fmaxf(r, 0.0f), 1023.0f);
+  };
+  return 0xC0000000u | (q(hi.x, lo.x) << 20) | (q(hi.y, lo.y) << 10) | q(hi.z, lo.z);
 }
+RRT_DEV V3<float> unpack_lo(V3<float> hi, uint32_t w) {
+  auto u = [](float h, uint32_t q) -> float {
+    const uint32_t e = (__float_as_uint(h) >> 23) & 0xffu;
+    if (e < 64u || e > 250u) return 0.0f;
+    return ((float)(int)q - 512.0f) * __uint_as_float((e - 33u) << 23);
+  };
+  return V3<float>(u(hi.x, (w >> 20) & 1023u), u(hi.y, (w >> 10) & 1023u), u(hi.z, w & 1023u));
+}
+template <typename R> RRT_DEV void store_ray(typename Vec4T<R>::type* ro, typename Vec4T<R>::type* rd, uint32_t i, V3<R> o, V3<R> lo, V3<R> d, R tmax, int skip);
+template <> RRT_DEV void store_ray<float>(float4* ro, float4* rd, uint32_t i, V3<float> o, V3<float> lo, V3<float> d, float tmax, int skip) {
+  const bool has_lo = lo.x != 0.0f || lo.y != 0.0f || lo.z != 0.0f;
+  ro[i] = make_float4(o.x, o.y, o.z, has_lo ? __uint_as_float(pack_lo(o, lo)) : tmax);
+  rd[i] = make_float4(d.x, d.y, d.z, __uint_as_float((uint32_t)skip));
+}
+template <> RRT_DEV void store_ray<double>(double4* ro, double4* rd, uint32_t i, V3<double> o, V3<double>, V3<double> d, double tmax, int skip) {
+  ro[i] = mk4<double>(o.x, o.y, o.z, tmax);
+  rd[i] = mk4u<double>(d.x, d.y, d.z, (uint32_t)skip);
+}
+// t_max and origin low word of a stored ray; `queue_tmax` = the t_max every spawned ray of this queue has
+RRT_DEV void ray_tail(const float4& ro, float queue_tmax, float* tmax, V3<float>* lo) {
+  const uint32_t w = __float_as_uint(ro.w);
+  if ((w >> 30) == 3u) { *tmax = queue_tmax; *lo = unpack_lo(V3<float>(ro.x, ro.y, ro.z), w); }
+  else { *tmax = ro.w; *lo = V3<float>(); }
+}
+RRT_DEV void ray_tail(const double4& ro, double, double* tmax, V3<double>* lo) { *tmax = ro.w; *lo = V3<double>(); }
 
 // Bounds3::intersect_p geometry.rs:1767-1800 with gamma(3) of the arithmetic type
 template <typename R>
@@ -311,8 +342,10 @@ __global__ void __launch_bounds__(kBlock) k_closest(SceneDev<R> s, Pools<R> p, c
   const uint32_t i = blockIdx.x * blockDim.x + threadIdx.x;
   const uint32_t n = count ? *count : n_fixed;
   if (i >= n) return;
-  const typename Vec4T<R>::type ro = p.ray_o[i], rd = p.ray_d[i], rl = p.ray_l[i];
-  RayCtx<R> r = make_ctx(V3<R>(ro.x, ro.y, ro.z), V3<R>(rd.x, rd.y, rd.z), ro.w, V3<R>(rl.x, rl.y, rl.z));
+  const typename Vec4T<R>::type ro = p.ray_o[i], rd = p.ray_d[i];
+  R r_tmax; V3<R> r_lo;
+  ray_tail(ro, Const<R>::inf, &r_tmax, &r_lo);
+  RayCtx<R> r = make_ctx(V3<R>(ro.x, ro.y, ro.z), V3<R>(rd.x, rd.y, rd.z), r_tmax, r_lo);
   R hu = 0, hv = 0;
   uint32_t nn = 0, np = 0;
   int hit;
@@ -342,8 +375,10 @@ __global__ void __launch_bounds__(kBlock) k_shadow(SceneDev<R> s, Pools<R> p, co
                                                     uint32_t* deep_stack, uint32_t deep_stride, unsigned long long* totals) {
   const uint32_t i = blockIdx.x * blockDim.x + threadIdx.x;
   if (i >= *count) return;
-  const typename Vec4T<R>::type ro = p.sray_o[i], rd = p.sray_d[i], rl = p.sray_l[i];
-  RayCtx<R> r = make_ctx(V3<R>(ro.x, ro.y, ro.z), V3<R>(rd.x, rd.y, rd.z), ro.w, V3<R>(rl.x, rl.y, rl.z));
+  const typename Vec4T<R>::type ro = p.sray_o[i], rd = p.sray_d[i];
+  R r_tmax; V3<R> r_lo;
+  ray_tail(ro, R(1) - R(0.0001), &r_tmax, &r_lo);
+  RayCtx<R> r = make_ctx(V3<R>(ro.x, ro.y, ro.z), V3<R>(rd.x, rd.y, rd.z), r_tmax, r_lo);
   uint32_t nn = 0, np = 0;
   bool occ;
   const int skip = (int)real_to_bits(rd.w);
@@ -359,7 +394,7 @@ __global__ void __launch_bounds__(kBlock) k_pack_rays(Pools<R> p, const R* ox, c
                                                        const int32_t* skip, uint32_t n) {
   const uint32_t i = blockIdx.x * blockDim.x + threadIdx.x;
   if (i >= n) return;
-  store_ray<R>(p.ray_o, p.ray_d, p.ray_l, i, V3<R>(ox[i], oy[i], oz[i]), V3<R>(), V3<R>(dx[i], dy[i], dz[i]), tmax[i], skip ? skip[i] : -1);
+  store_ray<R>(p.ray_o, p.ray_d, i, V3<R>(ox[i], oy[i], oz[i]), V3<R>(), V3<R>(dx[i], dy[i], dz[i]), tmax[i], skip ? skip[i] : -1);
 }
 template <typename R>
 __global__ void __launch_bounds__(kBlock) k_unpack_hits(Pools<R> p, const Tri<R>* tris, R* t, int32_t* prim, R* u, R* v, uint32_t n) {
@@ -377,8 +412,10 @@ template <typename R, bool DEEP>
 __global__ void __launch_bounds__(kBlock) k_any_public(SceneDev<R> s, Pools<R> p, uint32_t n, uint8_t* occluded, uint32_t* deep_stack, uint32_t deep_stride) {
   const uint32_t i = blockIdx.x * blockDim.x + threadIdx.x;
   if (i >= n) return;
-  const typename Vec4T<R>::type ro = p.ray_o[i], rd = p.ray_d[i], rl = p.ray_l[i];
-  RayCtx<R> r = make_ctx(V3<R>(ro.x, ro.y, ro.z), V3<R>(rd.x, rd.y, rd.z), ro.w, V3<R>(rl.x, rl.y, rl.z));
+  const typename Vec4T<R>::type ro = p.ray_o[i], rd = p.ray_d[i];
+  R r_tmax; V3<R> r_lo;
+  ray_tail(ro, Const<R>::inf, &r_tmax, &r_lo);
+  RayCtx<R> r = make_ctx(V3<R>(ro.x, ro.y, ro.z), V3<R>(rd.x, rd.y, rd.z), r_tmax, r_lo);
   uint32_t nn, np;
   bool occ;
   const int skip = (int)real_to_bits(rd.w);
@@ -431,7 +468,7 @@ __global__ void __launch_bounds__(kBlock) k_raygen(SceneDev<R> s, Pools<R> p, Pa
     p.weight[slot] = alive ? w : R(0);
     p.samp[slot] = mk4<R>(pfx, pfy, lx, ly);
     if (alive) {
-      store_ray<R>(p.nray_o, p.nray_d, p.nray_l, slot, ray.o, V3<R>(), ray.d, Const<R>::inf, -1);
+      store_ray<R>(p.nray_o, p.nray_d, slot, ray.o, V3<R>(), ray.d, Const<R>::inf, -1);
     }
     if (dbg_dims) {
       double* dd = dbg_dims + 5 * (size_t)(pl * pd.ns + sl);   // [pixel][sample]
@@ -475,7 +512,7 @@ __global__ void __launch_bounds__(kBlock) k_raygen_aux(SceneDev<R> s, Pools<R> p
   if (enq) {
     p.q_active[q] = QEnt{slot, 5u, p.hindex[slot], 0u};   // five camera dimensions consumed, bounce 0
     p.path[q] = mk4<R>(R(1), R(1), R(1), R(1));
-    p.ray_o[q] = p.nray_o[slot]; p.ray_d[q] = p.nray_d[slot]; p.ray_l[q] = p.nray_l[slot];
+    p.ray_o[q] = p.nray_o[slot]; p.ray_d[q] = p.nray_d[slot];
   }
   if (alive) p.L[slot] = mk4<R>(R(0), R(0), R(0), R(0));
   (void)block_push(&p.counters[C_CAMERA_RAYS], alive, push_lds);
@@ -816,14 +853,14 @@ __global__ void __launch_bounds__(ShadeBlock<R>::n) k_shade_path(SceneDev<R> s, 
   }
   const uint32_t qs = block_push(&p.counters[C_SHADOW], want_shadow, push_lds);
   if (want_shadow) {
-    store_ray<R>(p.sray_o, p.sray_d, p.sray_l, qs, sh_o, o_lo, sh_d, R(1) - R(0.0001), self_prim<R>(prim));
+    store_ray<R>(p.sray_o, p.sray_d, qs, sh_o, o_lo, sh_d, R(1) - R(0.0001), self_prim<R>(prim));
     p.sld[qs] = mk4u<R>(sh_ld.r, sh_ld.g, sh_ld.b, slot);
   }
   const uint32_t qn = block_push(&p.counters[C_NEXT], want_next, push_lds);
   if (want_next) {
     p.q_next[qn] = QEnt{slot, nx_db, index, 0u};
     p.npath[qn] = mk4<R>(nx_beta.r, nx_beta.g, nx_beta.b, nx_eta_scale);
-    store_ray<R>(p.nray_o, p.nray_d, p.nray_l, qn, nx_o, o_lo, nx_d, Const<R>::inf, self_prim<R>(prim));
+    store_ray<R>(p.nray_o, p.nray_d, qn, nx_o, o_lo, nx_d, Const<R>::inf, self_prim<R>(prim));
   }
 }
 
@@ -891,7 +928,7 @@ __global__ void __launch_bounds__(ShadeBlock<R>::n) k_shade_nee(SceneDev<R> s, P
   }
   const uint32_t qs = block_push(&p.counters[C_SHADOW], want_shadow, push_lds);
   if (want_shadow) {
-    store_ray<R>(p.sray_o, p.sray_d, p.sray_l, qs, sh_o, o_lo, sh_d, R(1) - R(0.0001), self_prim<R>(prim));
+    store_ray<R>(p.sray_o, p.sray_d, qs, sh_o, o_lo, sh_d, R(1) - R(0.0001), self_prim<R>(prim));
     p.sld[qs] = mk4u<R>(sh_ld.r, sh_ld.g, sh_ld.b, slot);
   }
 }
@@ -956,7 +993,7 @@ __global__ void __launch_bounds__(ShadeBlock<R>::n) k_shade_specular(SceneDev<R>
   if (want_next) {
     p.q_next[qn] = QEnt{slot, nx_db, index, 0u};
     p.npath[qn] = mk4<R>(nx_beta.r, nx_beta.g, nx_beta.b, R(1));
-    store_ray<R>(p.nray_o, p.nray_d, p.nray_l, qn, nx_o, o_lo, nx_d, Const<R>::inf, self_prim<R>(prim));
+    store_ray<R>(p.nray_o, p.nray_d, qn, nx_o, o_lo, nx_d, Const<R>::inf, self_prim<R>(prim));
   }
 }
 

@@ -132,9 +132,10 @@ __global__ void __launch_bounds__(kTravBlock) k_trace_pairs_f32(TravScene ts, Po
   int sk;
   {
     const float4 ro = (ANY && !occluded) ? p.sray_o[gid] : p.ray_o[gid], rd = (ANY && !occluded) ? p.sray_d[gid] : p.ray_d[gid];
-    const float4 rl = (ANY && !occluded) ? p.sray_l[gid] : p.ray_l[gid];
-    r.ox = ro.x; r.oy = ro.y; r.oz = ro.z; r.tmax = ro.w; r.dx = rd.x; r.dy = rd.y; r.dz = rd.z; sk = (int)__float_as_uint(rd.w);
-    r.lx = rl.x; r.ly = rl.y; r.lz = rl.z;
+    V3<float> lo;
+    ray_tail(ro, (ANY && !occluded) ? 1.0f - 0.0001f : Const<float>::inf, &r.tmax, &lo);
+    r.ox = ro.x; r.oy = ro.y; r.oz = ro.z; r.dx = rd.x; r.dy = rd.y; r.dz = rd.z; sk = (int)__float_as_uint(rd.w);
+    r.lx = lo.x; r.ly = lo.y; r.lz = lo.z;
   }
   r.skip_plane = sk >= 0 ? __float_as_uint(ts.tris[(size_t)sk * 12 + 11]) : 0xffffffffu;
   r.ix = 1.0f / r.dx; r.iy = 1.0f / r.dy; r.iz = 1.0f / r.dz;
@@ -321,9 +322,10 @@ __global__ void __launch_bounds__(kPtBlock) k_trace_pt_f32(TravScene ts, Pools<f
           int sk;
           {
             const float4 ro = (ANY && !occluded) ? p.sray_o[qidx] : p.ray_o[qidx], rd = (ANY && !occluded) ? p.sray_d[qidx] : p.ray_d[qidx];
-            const float4 rl = (ANY && !occluded) ? p.sray_l[qidx] : p.ray_l[qidx];
-            r.ox = ro.x; r.oy = ro.y; r.oz = ro.z; r.tmax = ro.w; r.dx = rd.x; r.dy = rd.y; r.dz = rd.z; sk = (int)__float_as_uint(rd.w);
-            r.lx = rl.x; r.ly = rl.y; r.lz = rl.z;
+            V3<float> lo;
+            ray_tail(ro, (ANY && !occluded) ? 1.0f - 0.0001f : Const<float>::inf, &r.tmax, &lo);
+            r.ox = ro.x; r.oy = ro.y; r.oz = ro.z; r.dx = rd.x; r.dy = rd.y; r.dz = rd.z; sk = (int)__float_as_uint(rd.w);
+            r.lx = lo.x; r.ly = lo.y; r.lz = lo.z;
           }
           r.skip_plane = sk >= 0 ? __float_as_uint(ts.tris[(size_t)sk * 12 + 11]) : 0xffffffffu;
           r.ix = 1.0f / r.dx; r.iy = 1.0f / r.dy; r.iz = 1.0f / r.dz;
@@ -522,7 +524,7 @@ static __global__ void __launch_bounds__(kRgBlock) k_raygen_pt_f32(SceneDev<floa
           const RayT<float> rc = flip_z(rl);
           const V3<float> wo = aff_pt(s.cam_m, rc.o);
           const V3<float> wd = vnormalize(vnormalize(vnormalize(aff_vec(s.cam_m, rc.d))));
-          store_ray<float>(p.nray_o, p.nray_d, p.nray_l, slot, wo, V3<float>(), wd, Const<float>::inf, -1);
+          store_ray<float>(p.nray_o, p.nray_d, slot, wo, V3<float>(), wd, Const<float>::inf, -1);
           p.weight[slot] = w_main;   // dead samples keep stage 1's 0
         }
         busy = false;
@@ -601,7 +603,7 @@ static __global__ void __launch_bounds__(kRgBlock) k_raygen_aux_f32(SceneDev<flo
   if (enq) {
     p.q_active[q] = QEnt{slot, 5u, p.hindex[slot], 0u};   // five camera dimensions consumed, bounce 0
     p.path[q] = make_float4(1.0f, 1.0f, 1.0f, 1.0f);      // beta, eta_scale
-    p.ray_o[q] = p.nray_o[slot]; p.ray_d[q] = p.nray_d[slot]; p.ray_l[q] = make_float4(0.0f, 0.0f, 0.0f, 0.0f);
+    p.ray_o[q] = p.nray_o[slot]; p.ray_d[q] = p.nray_d[slot];
   }
   if (alive) p.L[slot] = make_float4(0.0f, 0.0f, 0.0f, 0.0f);
 }

@@ -141,12 +141,14 @@ struct alignas(16) QEnt { uint32_t slot, db, index, pad; };   // slot, dimension
 template <typename R>
 struct Pools {
   using V4 = typename Vec4T<R>::type;
-  // rays of q_active (also the public rrt_rays batch): {o.x, o.y, o.z, t_max}, {d.x, d.y, d.z, skip}
+  // rays of q_active (also the public rrt_rays batch): {o.x, o.y, o.z, t_max | packed o_lo}, {d.x, d.y, d.z, skip}
   // skip = triangle (traversal order) a spawned ray starts on, -1 = none (see self_prim())
-  V4 *ray_o, *ray_d, *ray_l;   // ray_l = {o_lo.x, o_lo.y, o_lo.z, -}: low word of a double-float origin (fp32 mode, see spawn_point())
-  V4 *nray_o, *nray_d, *nray_l;   // rays being spawned for q_next (the host swaps them together with the queues)
+  // fp32 spawned rays replace t_max (a constant of their queue: inf / 1 - 1e-4) by the packed low word of a double-float
+  // origin (pack_lo() / spawn_point() in dkernels.hpp); top bits 11 mark that form (a real t_max is never negative)
+  V4 *ray_o, *ray_d;
+  V4 *nray_o, *nray_d;   // rays being spawned for q_next (the host swaps them together with the queues)
   V4* hit;               // {t, prim, u, v} for the ray at the same queue position
-  V4 *sray_o, *sray_d, *sray_l;   // shadow rays, in shadow-queue order
+  V4 *sray_o, *sray_d;   // shadow rays, in shadow-queue order
   V4* sld;               // {Ld.r, Ld.g, Ld.b, slot}: pending contribution of the shadow ray at the same position
   // path state that changes every bounce travels with the queue too (cur / next, swapped with the rays)
   V4 *path, *npath;      // {beta.r, beta.g, beta.b, eta_scale (path.rs:70, 150-162)}

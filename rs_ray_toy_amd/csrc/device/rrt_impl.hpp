@@ -122,7 +122,7 @@ class Handle : public HandleBase {
     // launches beat many small ones (whole 1024^2 x 256 spp frame in one pass: 268 M slots x 172 B = 46 GB).
     size_t free_b = 0, total_b = 0;
     HIP_CHECK(hipMemGetInfo(&free_b, &total_b));
-    const size_t per_slot = (15 * 4 + 1) * sizeof(R) + 9 * sizeof(uint32_t);
+    const size_t per_slot = (12 * 4 + 1) * sizeof(R) + 9 * sizeof(uint32_t);
     max_paths_ = std::max<size_t>(1u << 16, std::min(max_paths_, (free_b / 2) / per_slot));
   }
   ~Handle() override {
@@ -676,15 +676,15 @@ class Handle : public HandleBase {
     HIP_CHECK(hipStreamSynchronize(st_));
     cap_ = n;
     using V4 = typename Vec4T<R>::type;
-    const size_t NV = 15, NR = 1, NU = 9;   // 4-word records, reals, u32 per slot
+    const size_t NV = 12, NR = 1, NU = 9;   // 4-word records, reals, u32 per slot
     vpool_.alloc(NV * cap_);
     rpool_.alloc(NR * cap_);
     upool_.alloc(NU * cap_);
     Pools<R>& p = pool_;
     V4* v = vpool_.p;
     auto nv = [&]() { V4* x = v; v += cap_; return x; };
-    p.ray_o = nv(); p.ray_d = nv(); p.ray_l = nv(); p.nray_o = nv(); p.nray_d = nv(); p.nray_l = nv(); p.hit = nv();
-    p.sray_o = nv(); p.sray_d = nv(); p.sray_l = nv(); p.sld = nv(); p.samp = nv(); p.path = nv(); p.npath = nv(); p.L = nv();
+    p.ray_o = nv(); p.ray_d = nv(); p.nray_o = nv(); p.nray_d = nv(); p.hit = nv();
+    p.sray_o = nv(); p.sray_d = nv(); p.sld = nv(); p.samp = nv(); p.path = nv(); p.npath = nv(); p.L = nv();
     R* r = rpool_.p;
     auto nr = [&]() { R* x = r; r += cap_; return x; };
     p.weight = nr();
@@ -713,7 +713,7 @@ class Handle : public HandleBase {
     HIP_CHECK(hipStreamSynchronize(st_));   // staging buffers go out of scope
   }
   // active <- next for the queue and for the rays stored at its positions
-  void swap_queues() { std::swap(pool_.q_active, pool_.q_next); std::swap(pool_.ray_o, pool_.nray_o); std::swap(pool_.ray_d, pool_.nray_d); std::swap(pool_.ray_l, pool_.nray_l); std::swap(pool_.path, pool_.npath); }
+  void swap_queues() { std::swap(pool_.q_active, pool_.q_next); std::swap(pool_.ray_o, pool_.nray_o); std::swap(pool_.ray_d, pool_.nray_d); std::swap(pool_.path, pool_.npath); }
 
   void launch_closest(const uint32_t* queue, const uint32_t* count, uint32_t n_fixed, bool counting, uint32_t* cn, uint32_t* cp,
                       unsigned long long* totals, uint32_t grid_override = 0) {
