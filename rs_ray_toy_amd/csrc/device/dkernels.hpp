@@ -9,9 +9,13 @@ namespace rrtd {
 constexpr int kBlock = 256;
 // device counters, one 128-byte line each (atomics on different queues must not share an L2 line)
 enum { C_ACTIVE = 0, C_NEXT = 32, C_SHADOW = 64, C_CAMERA_RAYS = 96, C_ERROR = 128, C_WORK_CLOSEST = 160, C_WORK_SHADOW = 192, C_WORK_AUX = 224, C_COUNT = 256 };
-// shading kernels push to their queues once per block: big blocks where the registers allow (fp32: 118 VGPRs)
+// shading kernels push to their queues once per block (measured: 256 <= 512 <= 1024 threads by 5 %: smaller blocks retire
+// and refill a CU sooner, and one atomic per 256 paths no longer serialises)
 template <typename R> struct ShadeBlock { static constexpr int n = 256; };
-template <> struct ShadeBlock<float> { static constexpr int n = 1024; };
+#ifndef RRT_SHADE_BLOCK
+#define RRT_SHADE_BLOCK 256
+#endif
+template <> struct ShadeBlock<float> { static constexpr int n = RRT_SHADE_BLOCK; };
 enum { ERR_SHADING_NORMAL = 1, ERR_STACK = 2, ERR_BETA = 4 };
 
 // ------------------------------------------------------------------------------------------------------------

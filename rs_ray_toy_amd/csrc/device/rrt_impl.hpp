@@ -614,7 +614,7 @@ class Handle : public HandleBase {
       for (uint32_t c = 2; n < 1000; c++) {
         bool prime = true;
         for (uint32_t q = 2; q * q <= c; q++) if (c % q == 0) { prime = false; break; }
-        if (prime) { hd[n].base = c; hd[n].perm_offset = acc; hd[n].magic = ((1ull << 40) / c) + 1ull; acc += c; n++; }
+        if (prime) { hd[n].base = c; hd[n].perm_offset = acc; hd[n].magic = ((1ull << 40) / c) + 1ull; hd[n].inv = 1.0 / (double)c; acc += c; n++; }
       }
     }
     std::vector<uint16_t> perms;
