@@ -368,7 +368,7 @@ template <typename R> RRT_DEV R generate_ray_differential(const SceneDev<R>& s, 
 // ---- BxDFs (reflection.rs, microfacet.rs) ---------------------------------------------------------------------
 enum : uint32_t { BXDF_REFLECTION = 1, BXDF_TRANSMISSION = 2, BXDF_DIFFUSE = 4, BXDF_GLOSSY = 8, BXDF_SPECULAR = 16, BXDF_ALL = 31, BXDF_NONE = 0 };
 enum : uint32_t { LOBE_LAMBERT = 0, LOBE_OREN_NAYAR, LOBE_MICROFACET, LOBE_SPEC_REFL, LOBE_DEBUG_DIFFUSE, LOBE_DEBUG_SPECULAR,
-                  LOBE_SPEC_TRANS, LOBE_FRESNEL_SPEC, LOBE_LAMBERT_TRANS, LOBE_MICROFACET_TRANS };
+                  LOBE_SPEC_TRANS, LOBE_FRESNEL_SPEC, LOBE_LAMBERT_TRANS, LOBE_MICROFACET_TRANS, LOBE_NONE = 0xffffffffu };
 enum : uint32_t { FR_NOOP = 0, FR_DIELECTRIC, FR_CONDUCTOR };
 
 template <typename R> RRT_DEV R cos_theta(V3<R> w) { return w.z; }
@@ -605,16 +605,25 @@ template <typename R> RRT_DEV R roughness_to_alpha(R roughness) {  // microfacet
   return R(1.62142) + R(0.819955) * x + R(0.1734) * x * x + R(0.0171201) * x * x * x + R(0.000640711) * x * x * x * x;
 }
 
-// Bsdf reflection.rs:205-405. NL = lobe capacity: 2 covers every material except TranslucentMaterial (4)
+// Bsdf reflection.rs:205-405. NL = lobe capacity: 2 covers every material except TranslucentMaterial (4).
+// Lobes sit in FIXED slots chosen by the material (kind == LOBE_NONE marks an empty one) and every loop over them is
+// fully unrolled: with `lobes[n++]` / `lobes[chosen]` the array lived in scratch memory (212 B per lane) and each field
+// access was a memory round trip in the most latency-bound kernel of the frame. Relative order is what the reference's
+// "count-th matching component" and its sums depend on, and gaps do not change it.
 template <typename R, int NL = 2>
 struct Bsdf {
   V3<R> ns, ng, ss, ts;
   Lobe<R> lobes[NL];
-  int n;
+  int n;   // number of lobes present
   R eta;   // Bsdf::new(si, eta): 1 except glass / translucent
 
-  RRT_DEV static bool match(const Lobe<R>& l, uint32_t flags) { return (l.type & flags) == l.type; }
-  RRT_DEV int num_components(uint32_t flags) const { int c = 0; for (int i = 0; i < n; i++) if (match(lobes[i], flags)) c++; return c; }
+  RRT_DEV static bool match(const Lobe<R>& l, uint32_t flags) { return l.kind != LOBE_NONE && (l.type & flags) == l.type; }
+  RRT_DEV int num_components(uint32_t flags) const {
+    int c = 0;
+#pragma unroll
+    for (int i = 0; i < NL; i++) if (match(lobes[i], flags)) c++;
+    return c;
+  }
   RRT_DEV V3<R> to_local(V3<R> v) const { return {dot(v, ss), dot(v, ts), dot(v, ns)}; }
   RRT_DEV V3<R> to_world(V3<R> v) const {
     return {ss.x * v.x + ts.x * v.y + ns.x * v.z, ss.y * v.x + ts.y * v.y + ns.y * v.z, ss.z * v.x + ts.z * v.y + ns.z * v.z};
@@ -624,7 +633,8 @@ struct Bsdf {
     if (wo.z == R(0)) return Rgb<R>();
     bool refl = dot(wi_w, ng) * dot(wo_w, ng) > R(0);
     Rgb<R> r;
-    for (int i = 0; i < n; i++) {
+#pragma unroll
+    for (int i = 0; i < NL; i++) {
       const Lobe<R>& l = lobes[i];
       if (match(l, flags) && ((refl && (l.type & BXDF_REFLECTION)) || (!refl && (l.type & BXDF_TRANSMISSION)))) r = r + lobe_f(l, wo, wi);
     }
@@ -636,7 +646,8 @@ struct Bsdf {
     if (wo.z == R(0)) return R(0);
     R p = R(0);
     int matching = 0;
-    for (int i = 0; i < n; i++) if (match(lobes[i], flags)) { matching++; p += lobe_pdf(lobes[i], wo, wi); }
+#pragma unroll
+    for (int i = 0; i < NL; i++) if (match(lobes[i], flags)) { matching++; p += lobe_pdf(lobes[i], wo, wi); }
     return matching > 0 ? p / (R)matching : R(0);
   }
   // sample_f :302-381 (Q21). *pdf_out / *sampled keep the caller's values on the wo.z == 0 early-out.
@@ -647,10 +658,11 @@ struct Bsdf {
     int comp = (fl != fl || fl <= R(0)) ? 0 : (int)fl;
     if (comp > matching) comp = matching;
     int count = comp, chosen = -1;
-    for (int i = 0; i < n; i++)
-      if (match(lobes[i], flags)) { if (count == 0) { chosen = i; break; } count--; }
+    Lobe<R> bx = lobes[0];   // the chosen lobe, copied out with selects (no dynamic index)
+#pragma unroll
+    for (int i = 0; i < NL; i++)
+      if (chosen < 0 && match(lobes[i], flags)) { if (count == 0) { chosen = i; bx = lobes[i]; } else count--; }
     if (chosen < 0) { *pdf_out = R(0); *sampled = BXDF_NONE; return Rgb<R>(); }  // reference: expect() panic (u0 >= 1 only)
-    const Lobe<R>& bx = lobes[chosen];
     R ur0 = rmin(u0 * (R)matching - (R)comp, Const<R>::one_minus_eps);
     V3<R> wi, wo = to_local(wo_w);
     if (wo.z == R(0)) return Rgb<R>();
@@ -659,8 +671,10 @@ struct Bsdf {
     Rgb<R> f = lobe_sample_f(bx, wo, &wi, ur0, u1, pdf_out, sampled);
     if (*pdf_out == R(0)) { *sampled = BXDF_NONE; return Rgb<R>(); }
     *wi_w = to_world(wi);
-    if (!(bx.type & BXDF_REFLECTION) && matching > 1)
-      for (int i = 0; i < n; i++) if (i != chosen && match(lobes[i], flags)) *pdf_out += lobe_pdf(lobes[i], wo, wi);
+    if (!(bx.type & BXDF_REFLECTION) && matching > 1) {
+#pragma unroll
+      for (int i = 0; i < NL; i++) if (i != chosen && match(lobes[i], flags)) *pdf_out += lobe_pdf(lobes[i], wo, wi);
+    }
     if (matching > 1) *pdf_out /= (R)matching;
     return f;
   }
@@ -671,12 +685,14 @@ struct Bsdf {
 template <typename R, int NL> RRT_DEV void build_lobes(const Material<R>& m, Bsdf<R, NL>* b) {
   b->n = 0;
   b->eta = R(1);
+#pragma unroll
+  for (int i = 0; i < NL; i++) { b->lobes[i].kind = LOBE_NONE; b->lobes[i].type = 0; }
   switch (m.type) {
     case 0: {  // MatteMaterial
       Rgb<R> r = rgb_clamp0(Rgb<R>(m.kd));
       R sig = clampr(m.sigma, R(0), R(90));
       if (!r.is_black()) {
-        Lobe<R>& l = b->lobes[b->n++];
+        Lobe<R>& l = b->lobes[0]; b->n++;
         l.type = BXDF_DIFFUSE | BXDF_REFLECTION; l.r = r; l.fr = FR_NOOP;
         if (sig == R(0)) l.kind = LOBE_LAMBERT;
         else {
@@ -692,11 +708,11 @@ template <typename R, int NL> RRT_DEV void build_lobes(const Material<R>& m, Bsd
     case 1: {  // PlasticMaterial (specular lobe gated on kd: Q31)
       Rgb<R> kd = rgb_clamp0(Rgb<R>(m.kd)), ks = rgb_clamp0(Rgb<R>(m.ks));
       if (!kd.is_black()) {
-        Lobe<R>& l = b->lobes[b->n++];
+        Lobe<R>& l = b->lobes[0]; b->n++;
         l.kind = LOBE_LAMBERT; l.type = BXDF_DIFFUSE | BXDF_REFLECTION; l.r = kd; l.fr = FR_NOOP;
         R rough = m.roughness;
         if (m.remap_roughness) rough = roughness_to_alpha(rough);
-        Lobe<R>& s = b->lobes[b->n++];
+        Lobe<R>& s = b->lobes[1]; b->n++;
         s.kind = LOBE_MICROFACET; s.type = BXDF_GLOSSY | BXDF_REFLECTION; s.r = ks; s.alpha_x = rough; s.alpha_y = rough;
         s.fr = FR_DIELECTRIC; s.eta_i = Rgb<R>(R(1.5)); s.eta_t = Rgb<R>(R(1));
       }
@@ -705,7 +721,7 @@ template <typename R, int NL> RRT_DEV void build_lobes(const Material<R>& m, Bsd
     case 2: {  // MetalMaterial
       R ur = m.u_roughness, vr = m.v_roughness;
       if (m.remap_roughness) { ur = roughness_to_alpha(ur); vr = roughness_to_alpha(vr); }
-      Lobe<R>& l = b->lobes[b->n++];
+      Lobe<R>& l = b->lobes[0]; b->n++;
       l.kind = LOBE_MICROFACET; l.type = BXDF_GLOSSY | BXDF_REFLECTION; l.r = Rgb<R>(R(1)); l.alpha_x = ur; l.alpha_y = vr;
       l.fr = FR_CONDUCTOR; l.eta_i = Rgb<R>(R(1)); l.eta_t = Rgb<R>(m.eta); l.k = Rgb<R>(m.k);
       break;
@@ -713,7 +729,7 @@ template <typename R, int NL> RRT_DEV void build_lobes(const Material<R>& m, Bsd
     case 3: {  // MirrorMaterial
       Rgb<R> r = rgb_clamp0(Rgb<R>(m.kr));
       if (!r.is_black()) {
-        Lobe<R>& l = b->lobes[b->n++];
+        Lobe<R>& l = b->lobes[0]; b->n++;
         l.kind = LOBE_SPEC_REFL; l.type = BXDF_REFLECTION | BXDF_SPECULAR; l.r = r; l.fr = FR_NOOP;
       }
       break;
@@ -725,52 +741,51 @@ template <typename R, int NL> RRT_DEV void build_lobes(const Material<R>& m, Bsd
       b->eta = eta;
       const bool is_specular = ur == R(0) && vr == R(0);
       if (is_specular) {
-        Lobe<R>& l = b->lobes[b->n++];
+        Lobe<R>& l = b->lobes[0]; b->n++;
         l.kind = LOBE_FRESNEL_SPEC; l.type = BXDF_SPECULAR | BXDF_ALL; l.r = r; l.k = t; l.a = R(1); l.b = eta; l.fr = FR_NOOP;
       } else {
         if (m.remap_roughness) { ur = roughness_to_alpha(ur); vr = roughness_to_alpha(vr); }
         if (!r.is_black()) {
-          Lobe<R>& l = b->lobes[b->n++];
+          Lobe<R>& l = b->lobes[0]; b->n++;
           l.kind = LOBE_MICROFACET; l.type = BXDF_GLOSSY | BXDF_REFLECTION; l.r = r; l.alpha_x = ur; l.alpha_y = vr;
           l.fr = FR_DIELECTRIC; l.eta_i = Rgb<R>(R(1)); l.eta_t = Rgb<R>(eta);
         }
         if (!t.is_black()) {
-          Lobe<R>& l = b->lobes[b->n++];
+          Lobe<R>& l = b->lobes[1]; b->n++;
           l.kind = LOBE_MICROFACET_TRANS; l.type = BXDF_GLOSSY | BXDF_TRANSMISSION; l.r = t; l.alpha_x = ur; l.alpha_y = vr; l.a = R(1); l.b = eta; l.fr = FR_NOOP;
         }
       }
       break;
     }
-    case 6: {  // TranslucentMaterial translucent.rs:50-107 (needs NL = 4)
-      if (NL < 4) break;
+    case 6: if constexpr (NL >= 4) {  // TranslucentMaterial translucent.rs:50-107 (needs NL = 4)
       const R eta = R(1.5);
       b->eta = eta;
       const Rgb<R> r = rgb_clamp0(Rgb<R>(m.reflect)), t = rgb_clamp0(Rgb<R>(m.transmit));
       const Rgb<R> kd = rgb_clamp0(Rgb<R>(m.kd));
       if (!kd.is_black()) {
-        if (!r.is_black()) { Lobe<R>& l = b->lobes[b->n++]; l.kind = LOBE_LAMBERT; l.type = BXDF_DIFFUSE | BXDF_REFLECTION; l.r = r * kd; l.fr = FR_NOOP; }
-        if (!t.is_black()) { Lobe<R>& l = b->lobes[b->n++]; l.kind = LOBE_LAMBERT_TRANS; l.type = BXDF_DIFFUSE | BXDF_TRANSMISSION; l.r = t * kd; l.fr = FR_NOOP; }
+        if (!r.is_black()) { Lobe<R>& l = b->lobes[0]; b->n++; l.kind = LOBE_LAMBERT; l.type = BXDF_DIFFUSE | BXDF_REFLECTION; l.r = r * kd; l.fr = FR_NOOP; }
+        if (!t.is_black()) { Lobe<R>& l = b->lobes[1]; b->n++; l.kind = LOBE_LAMBERT_TRANS; l.type = BXDF_DIFFUSE | BXDF_TRANSMISSION; l.r = t * kd; l.fr = FR_NOOP; }
       }
       const Rgb<R> ks = rgb_clamp0(Rgb<R>(m.ks));
       if (!ks.is_black() && (!r.is_black() || !t.is_black())) {
         R rough = m.roughness;
         if (m.remap_roughness) rough = roughness_to_alpha(rough);
         if (!r.is_black()) {
-          Lobe<R>& l = b->lobes[b->n++];
+          Lobe<R>& l = b->lobes[2]; b->n++;
           l.kind = LOBE_MICROFACET; l.type = BXDF_GLOSSY | BXDF_REFLECTION; l.r = r * ks; l.alpha_x = rough; l.alpha_y = rough;
           l.fr = FR_DIELECTRIC; l.eta_i = Rgb<R>(R(1)); l.eta_t = Rgb<R>(eta);
         }
         if (!t.is_black()) {
-          Lobe<R>& l = b->lobes[b->n++];
+          Lobe<R>& l = b->lobes[3]; b->n++;
           l.kind = LOBE_MICROFACET_TRANS; l.type = BXDF_GLOSSY | BXDF_TRANSMISSION; l.r = t * ks; l.alpha_x = rough; l.alpha_y = rough; l.a = R(1); l.b = eta; l.fr = FR_NOOP;
         }
       }
       break;
-    }
+    } else break;
     default: {  // DebugMaterial
-      Lobe<R>& a = b->lobes[b->n++];
+      Lobe<R>& a = b->lobes[0]; b->n++;
       a.kind = LOBE_DEBUG_DIFFUSE; a.type = BXDF_DIFFUSE | BXDF_REFLECTION; a.fr = FR_NOOP;
-      Lobe<R>& c = b->lobes[b->n++];
+      Lobe<R>& c = b->lobes[1]; b->n++;
       c.kind = LOBE_DEBUG_SPECULAR; c.type = BXDF_SPECULAR | BXDF_REFLECTION; c.fr = FR_NOOP;
       break;
     }
