@@ -773,10 +773,12 @@ RRT_DEV uint32_t sample_light_discrete(const SceneDev<R>& s, R u) {
 template <typename R, int NL>
 __global__ void __launch_bounds__(ShadeBlock<R>::n) k_shade_path(SceneDev<R> s, Pools<R> p) {
   __shared__ uint32_t push_lds[ShadeBlock<R>::n / 64 + 1];
-  const uint32_t i = blockIdx.x * blockDim.x + threadIdx.x;
   const uint32_t n = p.counters[C_ACTIVE];
-  if (blockIdx.x * blockDim.x >= n) return;   // whole block past the queue end (the grid is sized for the worst case)
   using V4 = typename Vec4T<R>::type;
+  // a bounded grid walks the queue (block-uniform trip count, as block_push needs): the host does not know the queue
+  // size, and a grid sized for the whole pass costs 0.2 ms of empty blocks per launch once the queues are short
+  for (uint32_t base = blockIdx.x * blockDim.x; base < n; base += gridDim.x * blockDim.x) {
+  const uint32_t i = base + threadIdx.x;
   bool want_shadow = false, want_next = false;
   uint32_t slot = 0;
   int prim = -1;
@@ -866,6 +868,7 @@ __global__ void __launch_bounds__(ShadeBlock<R>::n) k_shade_path(SceneDev<R> s, 
     p.npath[qn] = mk4<R>(nx_beta.r, nx_beta.g, nx_beta.b, nx_eta_scale);
     store_ray<R>(p.nray_o, p.nray_d, qn, nx_o, o_lo, nx_d, Const<R>::inf, self_prim<R>(prim));
   }
+  }  // queue walk
 }
 
 // DirectLighting / Debug integrators (directlighting.rs:72-132, intersect_debug.rs:56-89) as a wavefront chain:

@@ -294,8 +294,8 @@ class Handle : public HandleBase {
             launch_closest(nullptr, &counters_.p[C_ACTIVE], 0, count_traversal_, nullptr, nullptr, count_traversal_ ? totals_.p : nullptr, grid);
             tock(e); n_closest_launch++;
             e = tick(3);
-            if (has_translucent_) hipLaunchKernelGGL((k_shade_path<R, 4>), dim3((uint32_t)((nslots + 255) / 256)), dim3(256), 0, st_, scene_, pool_);
-            else hipLaunchKernelGGL((k_shade_path<R, 2>), dim3(sgrid), dim3(ShadeBlock<R>::n), 0, st_, scene_, pool_);
+            if (has_translucent_) hipLaunchKernelGGL((k_shade_path<R, 4>), dim3(std::min((uint32_t)((nslots + 255) / 256), 16384u)), dim3(256), 0, st_, scene_, pool_);
+            else hipLaunchKernelGGL((k_shade_path<R, 2>), dim3(std::min(sgrid, 16384u)), dim3(ShadeBlock<R>::n), 0, st_, scene_, pool_);
             tock(e);
             hipLaunchKernelGGL(k_accumulate_shadow, dim3(1), dim3(1), 0, st_, counters_.p, totals_.p);
             e = tick(2);
