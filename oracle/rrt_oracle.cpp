@@ -467,20 +467,71 @@ struct Sampler {  // GlobalSampler<Halton>, samplers/mod.rs:266-447 with array_s
     if (dim >= 1000) throw OraclePanic{"halton.rs:65 HaltonSampler can only sample 1000 dimensions."};
     return scrambled_radical_inverse((int)dim, index, h->perms + primes().sums[dim]);
   }
+  // ---- StratifiedSampler = PixelSampler<Stratified> (samplers/stratified.rs, samplers/mod.rs:147-252) -------------
+  // The reference fills per-pixel arrays of jittered strata and shuffles them with rand::thread_rng; dimensions beyond
+  // `dimension` return rng.gen_range(-1.0..1.0) (mod.rs:211-226 - note the range). thread_rng cannot be reproduced, so
+  // the same structure is driven by counter-based randomness shared with the device: the stratum of
+  // sample s in dimension k of pixel P is a keyed bijection of s (the shuffle), its jitter a hash of (key, stratum).
+  int xres = 0;
+  uint32_t cur1d = 0, cur2d = 0;
+  static uint32_t st_mix(uint32_t x) { x ^= x >> 16; x *= 0x7feb352du; x ^= x >> 15; x *= 0x846ca68bu; x ^= x >> 16; return x; }
+  uint32_t st_key(uint32_t tag) const {
+    const uint32_t pixel = (uint32_t)(py * (int64_t)xres + px);
+    return st_mix(st_mix(pixel ^ (uint32_t)h->perm_seed) + tag * 0x9e3779b9u + (uint32_t)(h->perm_seed >> 32));
+  }
+  static uint32_t st_permute(uint32_t i, uint32_t n, uint32_t p) {   // Kensler 2013
+    uint32_t w = n - 1;
+    w |= w >> 1; w |= w >> 2; w |= w >> 4; w |= w >> 8; w |= w >> 16;
+    do {
+      i ^= p; i *= 0xe170893du; i ^= p >> 16; i ^= (i & w) >> 4; i ^= p >> 8; i *= 0x0929eb3fu; i ^= p >> 23; i ^= (i & w) >> 1;
+      i *= 1u | p >> 27; i *= 0x6935fa69u; i ^= (i & w) >> 11; i *= 0x74dcb303u; i ^= (i & w) >> 2; i *= 0x9e501cc3u;
+      i ^= (i & w) >> 2; i *= 0xc860a3dfu; i &= w; i ^= i >> 5;
+    } while (i >= n);
+    return (i + p) % n;
+  }
+  static double st_rand(uint32_t key, uint32_t i) { return (double)st_mix(key ^ st_mix(i + 0x632be5abu)) * 2.3283064365386963e-10; }
+  double st_get_1d() {
+    const uint32_t k = cur1d & 0xffu, sn = (uint32_t)current_pixel_sample_index;
+    cur1d = (k + 1u) & 0xffu;
+    if (k >= (uint32_t)h->dimension) return 2.0 * st_rand(st_key(0x10000u + k), sn) - 1.0;          // mod.rs:211-214
+    const uint32_t spp = (uint32_t)(h->xsamp * h->ysamp), key = st_key(k);
+    const uint32_t j = st_permute(sn, spp, key);                                                      // shuffle, stratified.rs:46-50
+    const double delta = h->jitter ? st_rand(key, j) : 0.5;                                           // stratified_sample1d :103-110
+    return rmin(((double)j + delta) * (1.0 / (double)spp), ONE_MINUS_EPSILON);
+  }
+  void st_get_2d(double* a, double* b) {
+    const uint32_t k = cur2d & 0xffu, sn = (uint32_t)current_pixel_sample_index;
+    cur2d = (k + 1u) & 0xffu;
+    if (k >= (uint32_t)h->dimension) {                                                                // mod.rs:222-226
+      const uint32_t key = st_key(0x20000u + k);
+      *a = 2.0 * st_rand(key, 2u * sn) - 1.0; *b = 2.0 * st_rand(key, 2u * sn + 1u) - 1.0;
+      return;
+    }
+    const uint32_t nx = (uint32_t)h->xsamp, ny = (uint32_t)h->ysamp, key = st_key(0x1000u + k);
+    const uint32_t j = st_permute(sn, nx * ny, key), x = j % nx, y = j / nx;                           // stratified_sample2d :112-130
+    const double jx = h->jitter ? st_rand(key, 2u * j) : 0.5, jy = h->jitter ? st_rand(key, 2u * j + 1u) : 0.5;
+    *a = rmin(((double)x + jx) * (1.0 / (double)nx), ONE_MINUS_EPSILON);
+    *b = rmin(((double)y + jy) * (1.0 / (double)ny), ONE_MINUS_EPSILON);
+  }
+
   void start_pixel(int64_t x, int64_t y) {  // samplers/mod.rs:58-65,322-372
     px = x; py = y;
     current_pixel_sample_index = 0;
-    dimension = 0;
-    interval_sample_index = get_index_for_sample(0);
+    dimension = 0; cur1d = cur2d = 0;
+    if (h->type == RRT_SAMPLER_HALTON) interval_sample_index = get_index_for_sample(0);
   }
-  bool start_next_sample() {  // :378-386 + BaseSampler::start_next_sample :71-76 (Q1)
-    dimension = 0;
-    interval_sample_index = get_index_for_sample(current_pixel_sample_index + 1);
+  bool start_next_sample() {  // :378-386 + BaseSampler::start_next_sample :71-76 (Q1); PixelSampler :195-199
+    dimension = 0; cur1d = cur2d = 0;
+    if (h->type == RRT_SAMPLER_HALTON) interval_sample_index = get_index_for_sample(current_pixel_sample_index + 1);
     current_pixel_sample_index += 1;
     return current_pixel_sample_index < h->samples_per_pixel;
   }
-  double get_1d() { dimension += 1; return sample_dimension(interval_sample_index, dimension - 1); }  // :396-409
-  void get_2d(double* a, double* b) {                                                                  // :411-433
+  double get_1d() {  // :396-409
+    if (h->type == RRT_SAMPLER_STRATIFIED) return st_get_1d();
+    dimension += 1; return sample_dimension(interval_sample_index, dimension - 1);
+  }
+  void get_2d(double* a, double* b) {  // :411-433
+    if (h->type == RRT_SAMPLER_STRATIFIED) { st_get_2d(a, b); return; }
     *a = sample_dimension(interval_sample_index, dimension);
     *b = sample_dimension(interval_sample_index, dimension + 1);
     dimension += 2;
@@ -1592,7 +1643,7 @@ void merge_film_tile(const rrt_film& f, const FilmTile& t, double* film) {
 
 void check_supported(const rrt_scene_desc* d) {
   if (d->abi_version != RRT_ABI_VERSION) throw OraclePanic{"scene desc ABI mismatch"};
-  if (d->sampler.type != RRT_SAMPLER_HALTON) throw OraclePanic{"oracle: only HaltonSampler is deterministic (StratifiedSampler uses thread_rng, SURVEY Q25)"};
+  if (d->sampler.type != RRT_SAMPLER_HALTON && d->sampler.type != RRT_SAMPLER_STRATIFIED) throw OraclePanic{"oracle: unknown sampler type"};
 }
 
 template <typename F>
@@ -1731,11 +1782,12 @@ int oracle_camera_samples(const rrt_scene_desc* d, const int32_t rect[4], uint64
     size_t k = 0;
     for (int y = rect[1]; y < rect[3]; y++)
       for (int x = rect[0]; x < rect[2]; x++) {
-        Sampler s; s.h = &d->sampler;
+        Sampler s; s.h = &d->sampler; s.xres = d->film.xres;
         s.start_pixel(x, y);
         for (uint64_t sn = s0; sn < s1; sn++, k++) {
-          s.dimension = 0;
-          s.interval_sample_index = s.get_index_for_sample(sn);
+          s.dimension = 0; s.cur1d = s.cur2d = 0;
+          s.current_pixel_sample_index = sn;
+          if (d->sampler.type == RRT_SAMPLER_HALTON) s.interval_sample_index = s.get_index_for_sample(sn);
           double f0, f1, l0, l1, tm;
           s.get_2d(&f0, &f1); s.get_2d(&l0, &l1); tm = s.get_1d();
           double* dd = &dims5[5 * k];
@@ -1797,7 +1849,7 @@ int oracle_render_rect(const rrt_scene_desc* d, const int32_t rect[4], double* f
               }
               volatile uint16_t sink = tmp[p - 1]; (void)sink;
             }
-            Sampler smp; smp.h = &d->sampler;
+            Sampler smp; smp.h = &d->sampler; smp.xres = d->film.xres;
             FilmTile ft = get_film_tile(f, x0, y0, x1, y1);
             for (int y = y0; y < y1; y++)
               for (int x = x0; x < x1; x++) {

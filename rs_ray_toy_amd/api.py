@@ -205,7 +205,7 @@ def deploy_render(filepath, save_to, device=0, precision=A.RRT_F32, flags=0, ove
     """renderprocess::deploy_render(filepath, save_to): load scene.json, render, write the PNG.
 
     `overrides` (dict) is merged into the top level of the scene config before loading, e.g. to swap the
-    non-deterministic StratifiedSampler of samples/scene.json for the HaltonSampler."""
+    StratifiedSampler of samples/scene.json for the HaltonSampler or to change the resolution."""
     with open(filepath) as f:
         cfg = json.load(f)
     if overrides:

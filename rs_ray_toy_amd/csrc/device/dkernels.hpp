@@ -460,8 +460,18 @@ __global__ void __launch_bounds__(kBlock) k_raygen(SceneDev<R> s, Pools<R> p, Pa
     uint32_t px, py;
     pass_pixel(pd, pd.pix_begin + pl, &px, &py);
     const uint32_t sample_num = pd.s_begin + sl;
-    const uint32_t index = halton_pixel_offset(s, px, py) + sample_num * s.stride;
-    const double d0 = halton_dim(s, index, 0), d1 = halton_dim(s, index, 1), d2 = halton_cam_dim(s, index, 0), d3 = halton_cam_dim(s, index, 1);
+    uint32_t index;
+    double d0, d1, d2, d3, d4 = 0.0;
+    if (s.sampler_type == 1u) {   // StratifiedSampler: get_camerasample = 2D film, 2D lens, 1D time (samplers/mod.rs:28-34)
+      index = ((py * (uint32_t)s.xres + px) << 10) | sample_num;
+      uint32_t cd = 0;
+      st_get_2d(s, index, &cd, &d0, &d1);
+      st_get_2d(s, index, &cd, &d2, &d3);
+      d4 = st_get_1d(s, index, &cd);
+    } else {
+      index = halton_pixel_offset(s, px, py) + sample_num * s.stride;
+      d0 = halton_dim(s, index, 0); d1 = halton_dim(s, index, 1); d2 = halton_cam_dim(s, index, 0); d3 = halton_cam_dim(s, index, 1);
+    }
     // dimension 4 (time) is drawn and unused by a static scene
     const R pfx = (R)px + to_real<R>(d0), pfy = (R)py + to_real<R>(d1);
     const R lx = to_real<R>(d2) + R(0.5), ly = to_real<R>(d3) + R(0.5);  // Q5
@@ -476,7 +486,7 @@ __global__ void __launch_bounds__(kBlock) k_raygen(SceneDev<R> s, Pools<R> p, Pa
     }
     if (dbg_dims) {
       double* dd = dbg_dims + 5 * (size_t)(pl * pd.ns + sl);   // [pixel][sample]
-      dd[0] = d0; dd[1] = d1; dd[2] = d2; dd[3] = d3; dd[4] = halton_dim(s, index, 4);
+      dd[0] = d0; dd[1] = d1; dd[2] = d2; dd[3] = d3; dd[4] = s.sampler_type == 1u ? d4 : halton_dim(s, index, 4);
     }
   }
   __shared__ uint32_t push_lds[kBlock / 64 + 1];
@@ -514,7 +524,7 @@ __global__ void __launch_bounds__(kBlock) k_raygen_aux(SceneDev<R> s, Pools<R> p
   const bool enq = alive && enqueue;
   const uint32_t q = block_push(&p.counters[C_ACTIVE], enq, push_lds);
   if (enq) {
-    p.q_active[q] = QEnt{slot, 5u, p.hindex[slot], 0u};   // five camera dimensions consumed, bounce 0
+    p.q_active[q] = QEnt{slot, s.cam_db, p.hindex[slot], 0u};   // camera dimensions consumed, bounce 0
     p.path[q] = mk4<R>(R(1), R(1), R(1), R(1));
     p.ray_o[q] = p.nray_o[slot]; p.ray_d[q] = p.nray_d[slot];
   }
@@ -808,9 +818,11 @@ __global__ void __launch_bounds__(ShadeBlock<R>::n) k_shade_path(SceneDev<R> s, 
         R eta_scale = st_b.w;
         // uniform_sample_one_light integrator/mod.rs:359-401 with the uniform Distribution1D (path.rs:47-49)
         if (bsdf.num_components(BXDF_ALL & ~BXDF_SPECULAR) > 0 && s.n_lights > 0) {
-          R u_pick = to_real<R>(halton_dim(s, index, dim));
-          R ul0 = to_real<R>(halton_dim(s, index, dim + 1)), ul1 = to_real<R>(halton_dim(s, index, dim + 2));
-          dim += 5;  // 1D pick, 2D u_light, 2D u_scattering (drawn, only used by the BSDF-sampling half)
+          double du0, du1;
+          R u_pick = to_real<R>(draw_1d(s, index, &dim));
+          draw_2d(s, index, &dim, &du0, &du1);
+          R ul0 = to_real<R>(du0), ul1 = to_real<R>(du1);
+          skip_2d(s, &dim);  // u_scattering: drawn, only used by the BSDF-sampling half
           uint32_t ln = sample_light_discrete(s, u_pick);
           V3<R> so, sd;
           Rgb<R> ld;
@@ -822,8 +834,9 @@ __global__ void __launch_bounds__(ShadeBlock<R>::n) k_shade_path(SceneDev<R> s, 
         }
         o_lo = si.p_lo;
         // Sample BSDF to get new path direction (:125-148)
-        R u0 = to_real<R>(halton_dim(s, index, dim)), u1 = to_real<R>(halton_dim(s, index, dim + 1));
-        dim += 2;
+        double db0, db1;
+        draw_2d(s, index, &dim, &db0, &db1);
+        R u0 = to_real<R>(db0), u1 = to_real<R>(db1);
         V3<R> wi;
         R pdf = R(0);
         uint32_t flags = 0;
@@ -839,8 +852,7 @@ __global__ void __launch_bounds__(ShadeBlock<R>::n) k_shade_path(SceneDev<R> s, 
           const R rr_max = (beta * eta_scale).max_component();
           if (rr_max < s.rr_threshold && bounces > 3) {
             R q = rmax(R(1) - rr_max, R(0.05));
-            R ur = to_real<R>(halton_dim(s, index, dim));
-            dim += 1;
+            R ur = to_real<R>(draw_1d(s, index, &dim));
             if (ur < q) cont = false;
             else beta = beta / (R(1) - q);
           }
@@ -913,15 +925,16 @@ __global__ void __launch_bounds__(ShadeBlock<R>::n) k_shade_nee(SceneDev<R> s, P
         R pick_pdf = R(1);
         if (light_j >= 0) ln = (uint32_t)light_j;
         else {
-          R u_pick = to_real<R>(halton_dim(s, index, dim));
-          dim += 1;
+          R u_pick = to_real<R>(draw_1d(s, index, &dim));
           R v = u_pick * (R)s.n_lights;
           uint32_t vi = (v != v || v <= R(0)) ? 0u : (uint32_t)v;
           ln = vi < s.n_lights - 1 ? vi : s.n_lights - 1;
           pick_pdf = R(1) / (R)s.n_lights;
         }
-        R ul0 = to_real<R>(halton_dim(s, index, dim)), ul1 = to_real<R>(halton_dim(s, index, dim + 1));
-        dim += 4;  // u_light + u_scattering
+        double du0, du1;
+        draw_2d(s, index, &dim, &du0, &du1);
+        R ul0 = to_real<R>(du0), ul1 = to_real<R>(du1);
+        skip_2d(s, &dim);  // u_scattering
         V3<R> so, sd;
         Rgb<R> ld;
         if (estimate_direct_light(si, bsdf, s.lights[ln], ul0, ul1, &so, &sd, &ld)) {
@@ -980,8 +993,9 @@ __global__ void __launch_bounds__(ShadeBlock<R>::n) k_shade_specular(SceneDev<R>
         if (si.ok) {
           Bsdf<R> bsdf;
           build_bsdf(s, si, &bsdf);
-          R u0 = to_real<R>(halton_dim(s, index, dim)), u1 = to_real<R>(halton_dim(s, index, dim + 1));
-          dim += 2;
+          double db0, db1;
+          draw_2d(s, index, &dim, &db0, &db1);
+          R u0 = to_real<R>(db0), u1 = to_real<R>(db1);
           V3<R> wi;
           R pdf = R(0);
           uint32_t st = 0;

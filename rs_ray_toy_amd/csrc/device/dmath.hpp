@@ -211,6 +211,67 @@ RRT_DEV double halton_cam_dim(const SceneDev<R>& s, uint32_t index, int which) {
   }
   return fmin(s.cam_invpow[which][k] * ((double)reversed + s.cam_tail[which]), 0.99999999999999989);
 }
+// ---- StratifiedSampler (samplers/stratified.rs, samplers/mod.rs:191-227) ---------------------------------------------
+// The reference fills, per pixel and per sampled dimension, an array of jittered strata and Fisher-Yates-shuffles it,
+// all with rand::thread_rng (not reproducible); dimensions beyond `dimension` draw rng.gen_range(-1.0..1.0) - note the
+// range. Here the same structure is driven by counter-based randomness, so a sample needs no per-pixel table:
+//   stratum of sample s in dimension k of pixel P = permute(s, spp, key(P, k))   (Kensler's keyed bijection = the shuffle)
+//   jitter = rand(key, stratum); out-of-range dimensions = 2 * rand(P, s, k) - 1.
+// The oracle restates exactly this (bit-exact parity); against the reference it is equal in distribution only.
+RRT_DEV uint32_t st_mix(uint32_t x) { x ^= x >> 16; x *= 0x7feb352du; x ^= x >> 15; x *= 0x846ca68bu; x ^= x >> 16; return x; }
+RRT_DEV uint32_t st_key(uint32_t seed_lo, uint32_t seed_hi, uint32_t pixel, uint32_t tag) { return st_mix(st_mix(pixel ^ seed_lo) + tag * 0x9e3779b9u + seed_hi); }
+RRT_DEV uint32_t st_permute(uint32_t i, uint32_t n, uint32_t p) {   // Kensler, "Correlated Multi-Jittered Sampling" (2013)
+  uint32_t w = n - 1;
+  w |= w >> 1; w |= w >> 2; w |= w >> 4; w |= w >> 8; w |= w >> 16;
+  do {
+    i ^= p; i *= 0xe170893du; i ^= p >> 16; i ^= (i & w) >> 4; i ^= p >> 8; i *= 0x0929eb3fu; i ^= p >> 23; i ^= (i & w) >> 1;
+    i *= 1u | p >> 27; i *= 0x6935fa69u; i ^= (i & w) >> 11; i *= 0x74dcb303u; i ^= (i & w) >> 2; i *= 0x9e501cc3u;
+    i ^= (i & w) >> 2; i *= 0xc860a3dfu; i &= w; i ^= i >> 5;
+  } while (i >= n);
+  return (i + p) % n;
+}
+RRT_DEV double st_rand(uint32_t key, uint32_t i) { return (double)st_mix(key ^ st_mix(i + 0x632be5abu)) * 2.3283064365386963e-10; }   // [0, 1)
+// index word of a stratified sample: pixel (22 bits) << 10 | sample number (10 bits); d = 1D counter | 2D counter << 8
+template <typename R> RRT_DEV double st_get_1d(const SceneDev<R>& s, uint32_t index, uint32_t* d) {
+  const uint32_t pixel = index >> 10, sn = index & 1023u, k = *d & 0xffu;
+  *d = (*d & ~0xffu) | ((k + 1u) & 0xffu);
+  if (k >= s.st_dims) return 2.0 * st_rand(st_key(s.st_seed_lo, s.st_seed_hi, pixel, 0x10000u + k), sn) - 1.0;
+  const uint32_t spp = s.st_nx * s.st_ny, key = st_key(s.st_seed_lo, s.st_seed_hi, pixel, k);
+  const uint32_t j = st_permute(sn, spp, key);
+  const double delta = s.st_jitter ? st_rand(key, j) : 0.5;
+  return fmin(((double)j + delta) * (1.0 / (double)spp), 0.99999999999999989);
+}
+template <typename R> RRT_DEV void st_get_2d(const SceneDev<R>& s, uint32_t index, uint32_t* d, double* a, double* b) {
+  const uint32_t pixel = index >> 10, sn = index & 1023u, k = (*d >> 8) & 0xffu;
+  *d = (*d & ~0xff00u) | (((k + 1u) & 0xffu) << 8);
+  if (k >= s.st_dims) {
+    const uint32_t key = st_key(s.st_seed_lo, s.st_seed_hi, pixel, 0x20000u + k);
+    *a = 2.0 * st_rand(key, 2u * sn) - 1.0; *b = 2.0 * st_rand(key, 2u * sn + 1u) - 1.0;
+    return;
+  }
+  const uint32_t spp = s.st_nx * s.st_ny, key = st_key(s.st_seed_lo, s.st_seed_hi, pixel, 0x1000u + k);
+  const uint32_t j = st_permute(sn, spp, key), x = j % s.st_nx, y = j / s.st_nx;
+  const double jx = s.st_jitter ? st_rand(key, 2u * j) : 0.5, jy = s.st_jitter ? st_rand(key, 2u * j + 1u) : 0.5;
+  *a = fmin(((double)x + jx) * (1.0 / (double)s.st_nx), 0.99999999999999989);
+  *b = fmin(((double)y + jy) * (1.0 / (double)s.st_ny), 0.99999999999999989);
+}
+// ISampler::get_1d / get_2d of the scene's sampler. `d` = low 16 bits of the queue entry's counter word.
+template <typename R> RRT_DEV double draw_1d(const SceneDev<R>& s, uint32_t index, uint32_t* d) {
+  if (s.sampler_type == 1u) return st_get_1d(s, index, d);
+  const double v = halton_dim(s, index, *d);
+  *d += 1u;
+  return v;
+}
+template <typename R> RRT_DEV void draw_2d(const SceneDev<R>& s, uint32_t index, uint32_t* d, double* a, double* b) {
+  if (s.sampler_type == 1u) { st_get_2d(s, index, d, a, b); return; }
+  *a = halton_dim(s, index, *d); *b = halton_dim(s, index, *d + 1u);
+  *d += 2u;
+}
+// a 2D draw whose value is never read (u_scattering of the removed BSDF-sampling half): only the counters move
+template <typename R> RRT_DEV void skip_2d(const SceneDev<R>& s, uint32_t* d) {
+  if (s.sampler_type == 1u) { const uint32_t k = (*d >> 8) & 0xffu; *d = (*d & ~0xff00u) | (((k + 1u) & 0xffu) << 8); }
+  else *d += 2u;
+}
 template <typename R> RRT_DEV R to_real(double u) { return (R)u; }
 template <> RRT_DEV float to_real<float>(double u) { return fminf((float)u, Const<float>::one_minus_eps); }  // keep u < 1 after narrowing
 

@@ -114,6 +114,10 @@ struct SceneDev {
   uint32_t nsamp, sample_at_center;
   uint32_t base_exp0, base_exp1, base_scale0, base_scale1, stride, mult_inv0, mult_inv1;
   uint32_t fast_div;           // all sample indices < 2^26
+  // StratifiedSampler (samplers/stratified.rs) with counter-based randomness, see draw_1d() in dmath.hpp
+  uint32_t sampler_type;       // RRT_SAMPLER_*
+  uint32_t st_nx, st_ny, st_jitter, st_dims, st_seed_lo, st_seed_hi;
+  uint32_t cam_db;             // dimension-counter word after the camera sample (Halton: 5; stratified: one 1D, two 2D)
   // camera lens dimensions 2 and 3 (bases 5 and 7): digit permutation packed 3 bits per digit, and the
   // reference's running product inv_base^k (lowdiscrepancy.rs:204-227) tabulated by the same f64 multiplications
   uint32_t cam_perm[2];

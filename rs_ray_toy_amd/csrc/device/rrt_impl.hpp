@@ -447,8 +447,16 @@ class Handle : public HandleBase {
   void check_renderable() {
     if (has_transmissive_ && desc_.integrator.type != RRT_INT_PATH)
       throw UnsupportedError("Glass / Translucent materials are in scope for the Path integrator only: specular_transmit (integrator/mod.rs:199-301) makes DirectLighting a branching recursion");
-    if (desc_.sampler.type != RRT_SAMPLER_HALTON)
-      throw UnsupportedError("device sampler: only HaltonSampler (StratifiedSampler draws from thread_rng in the reference, SURVEY Q25 / §8f rank 4)");
+    if (desc_.sampler.type == RRT_SAMPLER_STRATIFIED) {
+      // index word = pixel << 10 | sample number; 8-bit 1D / 2D dimension counters (<= 3 of each per bounce)
+      if (desc_.sampler.samples_per_pixel > 1024 || (uint64_t)desc_.film.xres * (uint64_t)desc_.film.yres > (1ull << 22))
+        throw UnsupportedError("StratifiedSampler on the device: at most 1024 samples per pixel and 2^22 pixels");
+      if (desc_.sampler.dimension > 255 || 3 * (int64_t)desc_.integrator.max_depth + 4 > 255)
+        throw UnsupportedError("StratifiedSampler on the device: dimension counters are 8 bits");
+      if (desc_.sampler.xsamp < 1 || desc_.sampler.ysamp < 1) throw PanicError("stratified sampler with zero strata");
+      return;
+    }
+    if (desc_.sampler.type != RRT_SAMPLER_HALTON) throw UnsupportedError("unknown sampler type");
     const uint64_t max_index = desc_.sampler.sample_stride * (desc_.sampler.samples_per_pixel + 1);
     if (max_index >= (1ull << 32)) throw UnsupportedError("Halton sample index exceeds 32 bits (nsamp too large for this build)");
   }
@@ -665,6 +673,11 @@ class Handle : public HandleBase {
       s.filter_table = filter_table_.p;
       s.filter_rx = (R)d->film.filter_radius[0]; s.filter_ry = (R)d->film.filter_radius[1];
     }
+    s.sampler_type = (uint32_t)d->sampler.type;
+    s.st_nx = (uint32_t)std::max(1, d->sampler.xsamp); s.st_ny = (uint32_t)std::max(1, d->sampler.ysamp);
+    s.st_jitter = d->sampler.jitter ? 1u : 0u; s.st_dims = (uint32_t)std::max(0, d->sampler.dimension);
+    s.st_seed_lo = (uint32_t)d->sampler.perm_seed; s.st_seed_hi = (uint32_t)(d->sampler.perm_seed >> 32);
+    s.cam_db = d->sampler.type == RRT_SAMPLER_STRATIFIED ? (1u | (2u << 8)) : 5u;
     s.integrator = d->integrator.type; s.max_depth = d->integrator.max_depth; s.light_strategy = d->integrator.light_strategy;
     s.rr_threshold = (R)d->integrator.rr_threshold;
     counters_.alloc(C_COUNT);
@@ -733,7 +746,7 @@ class Handle : public HandleBase {
   // camera ray generation: persistent-thread kernel in fp32, two-stage (main trace, compaction, auxiliary traces) in f64
   void launch_raygen(const PassDesc& pd, uint32_t grid, double* dims_out, int enqueue) {
     if constexpr (std::is_same<R, float>::value) {
-      if (raygen_pt_ && scene_.n_lens <= 32) {
+      if (raygen_pt_ && scene_.n_lens <= 32 && scene_.sampler_type == RRT_SAMPLER_HALTON) {
         if (rg_grid_ == 0) {
           int per_cu = 0, cus = 0;
           HIP_CHECK(hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, dev_));

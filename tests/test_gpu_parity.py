@@ -458,6 +458,48 @@ def test_transmissive_materials_path(which, workdir):
     r.close()
 
 
+@pytest.mark.parametrize("which", ["dims4_jitter", "dims20_nojitter", "golden_scene_json"])
+def test_stratified_sampler(which, workdir):
+    """StratifiedSampler (samplers/stratified.rs): strata + shuffle per sampled dimension, rng.gen_range(-1.0..1.0) for the
+    dimensions beyond `dimension` (samplers/mod.rs:211-226), sample 0 skipped (Q1). The reference draws from thread_rng; the
+    device and the oracle share a counter-based stand-in, so between them parity is exact.
+    `golden_scene_json` is the reference's own samples/scene.json, unmodified (it selects this sampler)."""
+    import os
+    if which == "golden_scene_json":
+        sc = Scene.load(os.path.join(os.path.dirname(__file__), "golden", "scene.json"))
+        W, H = sc.resolution
+        rect = (W // 2 - 40, H // 2 - 24, W // 2 + 40, H // 2 + 24)
+    else:
+        cfg, root = scenes.cfg4(workdir, xres=48, yres=40, nsamp=5, max_depth=5, n=24)
+        cfg["Sampler"] = {"sampler_type": "StratifiedSampler", "xsamp": 3, "ysamp": 4, "jitter": which == "dims4_jitter",
+                          "dimension": 4 if which == "dims4_jitter" else 20}
+        sc = Scene.loads(cfg, root, flags=RRT_FIXED_BVH)
+        rect = (0, 0, 48, 40)
+    assert sc.desc.sampler.type == 1
+    ref, st_ref = O.render(sc, rect, stats=True, flat=True)
+    r = Renderer(sc, 0, RRT_F64)
+    dims, rays, w = r.camera_samples(rect, 1, 4)
+    rdims, rrays, rw = O.camera_samples(sc, rect, 1, 4)
+    assert np.array_equal(dims, rdims)                                   # the sampler itself: bit-exact
+    np.testing.assert_allclose(w, rw, rtol=1e-10, atol=0)
+    film, st = r.render(rect, stats=True)
+    r.close()
+    assert np.array_equal(film[..., 3], ref[..., 3])
+    assert st.camera_rays == st_ref.camera_rays
+    scale = np.abs(ref[..., :3]).max()
+    assert scale > 0
+    d = np.abs(film[..., :3] - ref[..., :3]).max(-1) / scale
+    if which == "golden_scene_json":   # axis-aligned cubes: exact box / face ties (module docstring)
+        assert (d > 1e-9).mean() < 0.005, (d > 1e-9).mean()
+    else:
+        assert d.max() < 1e-9, d.max()
+    r = Renderer(sc, 0, RRT_F32)
+    f32 = r.render(rect).astype(np.float64)
+    r.close()
+    d32 = np.abs(f32[..., :3] - ref[..., :3]).max(-1) / scale
+    assert (d32 < 1e-4).mean() > (0.97 if which == "golden_scene_json" else 0.995), (d32 < 1e-4).mean()
+
+
 def _sphere_zoo(wd, integrator, xres=48, yres=48, nsamp=5):
     """Sphere primitives next to triangles: plain instanced spheres (cfg1 style), clipped spheres (z_min / z_max /
     phi_max), a sphere with its own to_world (Q16: first p_hit taken from the un-transformed ray), a scaled instance

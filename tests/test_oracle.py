@@ -188,10 +188,34 @@ def test_oracle_panics_like_the_reference(workdir):
     cfg["lights"] = []
     with pytest.raises(O.OracleError, match="unbounded recursion"):
         O.render(Scene.loads(cfg, root))
-    cfg, root = scenes.cfg2(workdir, xres=16, yres=16, nsamp=3)
-    cfg["Sampler"] = {"sampler_type": "StratifiedSampler"}
-    with pytest.raises(O.OracleError, match="thread_rng"):
-        O.render(Scene.loads(cfg, root))
+
+
+def test_stratified_sampler_structure(workdir):
+    """StratifiedSampler (samplers/stratified.rs): per pixel and sampled dimension the spp samples occupy spp distinct strata
+    (1D: j / spp; 2D: an nx x ny grid), in an order that differs from pixel to pixel and from dimension to dimension (the
+    shuffle); without jitter every sample sits at its stratum centre; dimensions beyond `dimension` come from
+    rng.gen_range(-1.0..1.0) (samplers/mod.rs:211-226): uniform on [-1, 1)."""
+    cfg, root = scenes.cfg2(workdir, xres=24, yres=24, nsamp=3)
+    cfg["Sampler"] = {"sampler_type": "StratifiedSampler", "xsamp": 4, "ysamp": 3, "jitter": True, "dimension": 2}
+    sc = Scene.loads(cfg, root)
+    dims = O.camera_samples(sc, (0, 0, 24, 24), 0, 12)[0].reshape(24 * 24, 12, 5)   # film 2D, lens 2D, time 1D
+    cells = (np.floor(dims[..., 0] * 4) + 4 * np.floor(dims[..., 1] * 3)).astype(int)
+    assert all(sorted(c) == list(range(12)) for c in cells)                     # 2D dimension 0: every stratum once
+    cells_l = (np.floor(dims[..., 2] * 4) + 4 * np.floor(dims[..., 3] * 3)).astype(int)
+    assert all(sorted(c) == list(range(12)) for c in cells_l)                   # 2D dimension 1
+    strata_t = np.floor(dims[..., 4] * 12).astype(int)
+    assert all(sorted(c) == list(range(12)) for c in strata_t)                  # 1D dimension 0
+    assert len({tuple(c) for c in cells}) > 500                                 # shuffled per pixel ...
+    assert (cells != cells_l).any(axis=1).mean() > 0.99                         # ... and per dimension
+    jit = dims[..., 0] * 4 - np.floor(dims[..., 0] * 4)
+    assert abs(jit.mean() - 0.5) < 0.01 and 0.07 < jit.var() < 0.10             # jitter ~ U[0, 1): var 1/12
+    cfg["Sampler"]["jitter"] = False
+    nj = O.camera_samples(Scene.loads(cfg, root), (0, 0, 24, 24), 0, 12)[0]
+    np.testing.assert_allclose(nj[:, 0] * 4 - np.floor(nj[:, 0] * 4), 0.5, atol=1e-12)
+    # dimension = 0: everything is "beyond": uniform on [-1, 1)
+    cfg["Sampler"]["dimension"] = 0
+    far = O.camera_samples(Scene.loads(cfg, root), (0, 0, 24, 24), 0, 12)[0]
+    assert far.min() < -0.99 and far.max() < 1.0 and abs(far.mean()) < 0.02 and abs(far.var() - 1.0 / 3.0) < 0.02
 
 
 # ---- closed forms for the BxDFs, light and filters added for SURVEY section 8(f) --------------------------------------
