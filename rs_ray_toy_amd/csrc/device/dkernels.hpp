@@ -780,8 +780,13 @@ RRT_DEV uint32_t sample_light_discrete(const SceneDev<R>& s, R u) {
 }
 
 // PathIntegrator::li loop body (path.rs:74-223) for one bounce of every active path.
+// occupancy target of the path shading kernel: asking for 4 waves per SIMD lets the register allocator use the full
+// 128-VGPR budget of that occupancy (measured: 8.9 ms against 9.9 ms without the hint; 5 or 6 waves spill: 10.6 / 13.2 ms)
+#ifndef RRT_SHADE_WAVES
+#define RRT_SHADE_WAVES 4
+#endif
 template <typename R, int NL>
-__global__ void __launch_bounds__(ShadeBlock<R>::n) k_shade_path(SceneDev<R> s, Pools<R> p) {
+__global__ void __launch_bounds__(ShadeBlock<R>::n) __attribute__((amdgpu_waves_per_eu(RRT_SHADE_WAVES, 8))) k_shade_path(SceneDev<R> s, Pools<R> p) {
   __shared__ uint32_t push_lds[ShadeBlock<R>::n / 64 + 1];
   const uint32_t n = p.counters[C_ACTIVE];
   using V4 = typename Vec4T<R>::type;
