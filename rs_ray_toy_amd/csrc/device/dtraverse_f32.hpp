@@ -248,8 +248,14 @@ __global__ void __launch_bounds__(kTravBlock) k_trace_pairs_f32(TravScene ts, Po
 // per loop iteration: NODE (one pair-node step), TRI (one triangle of the current leaf), IDLE.
 // Per ray the sequence of box tests, triangle tests, acceptances and t_max updates is unchanged.
 // ------------------------------------------------------------------------------------------------------------
-constexpr int kPtBlock = 256;
-constexpr int kPtStack = 12;
+#ifndef RRT_PT_BLOCK
+#define RRT_PT_BLOCK 256
+#endif
+#ifndef RRT_PT_STACK
+#define RRT_PT_STACK 10
+#endif
+constexpr int kPtBlock = RRT_PT_BLOCK;
+constexpr int kPtStack = RRT_PT_STACK;
 constexpr uint32_t kGrain = 256;
 
 template <bool ANY>
