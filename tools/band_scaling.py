@@ -18,4 +18,5 @@ for n in (1, 2, 4, 8):
     torch.cuda.synchronize()
     dt = (time.perf_counter() - t0) / 5 * 1e3
     st = r.render_bands_device(0, n, film.data_ptr(), stats=True)
-    print(f"N={n}: {dt:.2f} ms per rank-frame (ideal {81.2 / n:.2f}); raygen {st.ms_raygen:.2f} closest {st.ms_closest:.2f} any {st.ms_any:.2f} shade {st.ms_shade:.2f} film {st.ms_film:.2f}")
+    t1 = dt if n == 1 else t1
+    print(f"N={n}: {dt:.2f} ms per rank-frame (ideal {t1 / n:.2f}); raygen {st.ms_raygen:.2f} closest {st.ms_closest:.2f} any {st.ms_any:.2f} shade {st.ms_shade:.2f} film {st.ms_film:.2f}")
