@@ -6,7 +6,7 @@ rocprofv3 --kernel-trace --output-format csv -d gpurun_out/tp_$tag -- python3 to
 t=$(find gpurun_out/tp_$tag -name "*kernel_trace.csv" | head -1)
 python3 - "$t" <<'PY'
 import csv,sys
-rows=[r for r in csv.DictReader(open(sys.argv[1])) if ("k_closest<float, false, false>" in r["Kernel_Name"] or "k_trace_pairs_f32<false>" in r["Kernel_Name"] or "k_trace_pt_f32<false>" in r["Kernel_Name"])]
+rows=[r for r in csv.DictReader(open(sys.argv[1])) if ("k_closest<float, false, false>" in r["Kernel_Name"] or "k_trace_pairs_f32<false>" in r["Kernel_Name"] or "k_trace_pt_f32<false>" in r["Kernel_Name"] or "k_trace_pt_f32<false>" in r["Kernel_Name"])]
 d=[(int(r["End_Timestamp"])-int(r["Start_Timestamp"]))/1e3 for r in rows]
 # sequence: 6 benches x 23 launches
 labels=["primary","secondary","x0.05","x0.25","x1","x4"]
