@@ -59,7 +59,7 @@ enum {
 enum { RRT_PRIM_TRIANGLE = 0, RRT_PRIM_SPHERE = 1 };
 enum { /* material_type, renderprocess.rs:664-871 */
   RRT_MAT_MATTE = 0, RRT_MAT_PLASTIC = 1, RRT_MAT_METAL = 2, RRT_MAT_MIRROR = 3, RRT_MAT_DEBUG = 4,
-  RRT_MAT_GLASS = 5, RRT_MAT_TRANSLUCENT = 6   /* material/glass.rs, material/translucent.rs (Path integrator only) */
+  RRT_MAT_GLASS = 5, RRT_MAT_TRANSLUCENT = 6   /* material/glass.rs, material/translucent.rs */
 };
 enum { RRT_LIGHT_POINT = 0, RRT_LIGHT_DIFFUSE = 1, RRT_LIGHT_DISTANT = 2 };  /* renderprocess.rs:991-1031 */
 enum { RRT_SAMPLER_HALTON = 0, RRT_SAMPLER_STRATIFIED = 1 };    /* renderprocess.rs:1306-1325 */

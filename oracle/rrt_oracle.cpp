@@ -1189,7 +1189,6 @@ void compute_scattering(const Scene& sc, const SI& si, Bsdf* bsdf, bool allow_mu
       break;
     }
     case RRT_MAT_GLASS: {  // glass.rs:52-112 (allow_multiple_lobes as passed by the integrator, mode = Radiance)
-      if (sc.d->integrator.type != RRT_INT_PATH) throw OraclePanic{"transmissive materials are in scope for the Path integrator only (specular_transmit branches, integrator/mod.rs:199-301)"};
       double eta = m.index, ur = m.u_roughness, vr = m.v_roughness;
       Rgb r = rclamp0(Rgb(m.kr)), t = rclamp0(Rgb(m.kt));
       bsdf->eta = eta;
@@ -1215,7 +1214,6 @@ void compute_scattering(const Scene& sc, const SI& si, Bsdf* bsdf, bool allow_mu
       break;
     }
     case RRT_MAT_TRANSLUCENT: {  // translucent.rs:50-107
-      if (sc.d->integrator.type != RRT_INT_PATH) throw OraclePanic{"transmissive materials are in scope for the Path integrator only (specular_transmit branches, integrator/mod.rs:199-301)"};
       const double eta = 1.5;
       bsdf->eta = eta;
       Rgb r = rclamp0(Rgb(m.reflect)), t = rclamp0(Rgb(m.transmit));
@@ -1501,8 +1499,8 @@ struct Integ {
     return l;
   }
 
-  // specular_reflect integrator/mod.rs:150-198; specular_transmit :199-301 draws a 2D sample and, with no
-  // transmissive lobe in scope, returns 0.
+  // specular_reflect integrator/mod.rs:150-198, then specular_transmit :199-301: each draws a 2D sample and recurses;
+  // the reflect subtree consumes its sampler dimensions before the transmit draw (depth-first).
   template <typename F>
   Rgb specular_terms(const Ray& ray, const SI& isect, const Bsdf& bsdf, Sampler& smp, int depth, F&& li) {
     Rgb out;
@@ -1524,7 +1522,11 @@ struct Integ {
       uint8_t st = 0;
       smp.get_2d(&u0, &u1);
       Rgb f = bsdf.sample_f(wo, &wi, u0, u1, &pdf, BXDF_SPECULAR | BXDF_TRANSMISSION, &st);
-      if (pdf > 0.0 && !f.is_black()) throw OraclePanic{"specular transmission lobe reached: out of scope"};
+      V3 ns = isect.sn;
+      if (pdf > 0.0 && !f.is_black() && absdot(wi, ns) != 0.0) {   // specular_transmit integrator/mod.rs:199-301
+        Ray rd = ray_new(isect.p, wi, INF);
+        out = out + f * li(rd, depth + 1) * absdot(wi, ns) / pdf;
+      }
     }
     (void)ray;
     return out;
@@ -1538,7 +1540,7 @@ struct Integ {
       throw OraclePanic{"directlighting.rs:91 unbounded recursion: miss with an empty light list (Q20)"};
     }
     Bsdf bsdf;
-    compute_scattering(sc, isect, &bsdf);
+    compute_scattering(sc, isect, &bsdf, false);   // allow_multiple_lobes = false (directlighting.rs:91)
     Rgb l;  // isect.le() = 0 (Q18)
     if (sc.d->n_lights > 0) {
       if (in.light_strategy == RRT_STRATEGY_ALL) l = l + uniform_sample_all_lights(sc, isect, bsdf, smp, cnt);
@@ -1553,7 +1555,7 @@ struct Integ {
     if (!scene_intersect(sc, &ray, &isect, nullptr, cnt)) return Rgb();
     Rgb l(0.1, 0.1, 0.1);
     Bsdf bsdf;
-    compute_scattering(sc, isect, &bsdf);
+    compute_scattering(sc, isect, &bsdf, false);   // intersect_debug.rs:71
     Rgb s_l;
     if (sc.d->n_lights > 0) s_l = s_l + uniform_sample_all_lights(sc, isect, bsdf, smp, cnt);
     if ((depth + 1) < in.max_depth) s_l = s_l + specular_terms(ray, isect, bsdf, smp, depth, [&](Ray r, int d) { return li_debug(r, smp, d); });

@@ -646,12 +646,12 @@ RRT_DEV Surf<R> build_surface(const SceneDev<R>& s, int prim, V3<R> o, V3<R> d, 
 }
 
 template <typename R, int NL>
-RRT_DEV void build_bsdf(const SceneDev<R>& s, const Surf<R>& si, Bsdf<R, NL>* b) {  // Bsdf::new reflection.rs:215-226
+RRT_DEV void build_bsdf(const SceneDev<R>& s, const Surf<R>& si, Bsdf<R, NL>* b, bool allow_multiple_lobes = true) {  // Bsdf::new reflection.rs:215-226
   b->ns = si.sn;
   b->ss = vnormalize(si.sdpdu);
   b->ng = si.n;
   b->ts = cross(b->ns, b->ss);
-  build_lobes(s.materials[si.material], b);
+  build_lobes(s.materials[si.material], b, allow_multiple_lobes);
 }
 
 // Light::sample_li for PointLight (point.rs:55-77) and DiffuseAreaLight (diffuse.rs:63-79) over
@@ -915,7 +915,7 @@ __global__ void __launch_bounds__(ShadeBlock<R>::n) k_shade_nee(SceneDev<R> s, P
       if (!si.ok) atomicOr(&p.counters[C_ERROR], (uint32_t)ERR_SHADING_NORMAL);
       else {
         Bsdf<R> bsdf;
-        build_bsdf(s, si, &bsdf);
+        build_bsdf(s, si, &bsdf, false);   // allow_multiple_lobes = false (directlighting.rs:91)
         const uint32_t db = qe.db;
         uint32_t dim = db & 0xffffu;
         const V4 st_b = p.path[i];
@@ -997,7 +997,7 @@ __global__ void __launch_bounds__(ShadeBlock<R>::n) k_shade_specular(SceneDev<R>
         Surf<R> si = build_surface(s, prim, o, d, h.x, h.z, h.w);
         if (si.ok) {
           Bsdf<R> bsdf;
-          build_bsdf(s, si, &bsdf);
+          build_bsdf(s, si, &bsdf, false);
           double db0, db1;
           draw_2d(s, index, &dim, &db0, &db1);
           R u0 = to_real<R>(db0), u1 = to_real<R>(db1);
@@ -1021,6 +1021,103 @@ __global__ void __launch_bounds__(ShadeBlock<R>::n) k_shade_specular(SceneDev<R>
     p.npath[qn] = mk4<R>(nx_beta.r, nx_beta.g, nx_beta.b, R(1));
     store_ray<R>(p.nray_o, p.nray_d, qn, nx_o, o_lo, nx_d, Const<R>::inf, self_prim<R>(prim));
   }
+}
+
+// DirectLighting / Debug with transmissive materials. `l += specular_reflect(..) + specular_transmit(..)`
+// (directlighting.rs:126-129, integrator/mod.rs:150-301) makes li() a binary recursion, and the sampler dimensions are
+// consumed depth-first: the transmit draw of a vertex comes after everything its reflect subtree drew, which depends on
+// what that subtree hit. A breadth-first wavefront cannot know that count, so here one thread walks one camera
+// sample's whole tree with an explicit stack (traversal, shading and shadow tests inline; a vertex is re-intersected
+// when its reflect subtree returns instead of keeping its interaction on the stack). A correctness path, not a fast one.
+constexpr int kTreeMax = 16;
+template <typename R>
+__global__ void __launch_bounds__(kBlock) k_direct_tree(SceneDev<R> s, Pools<R> p, unsigned long long* totals) {
+  using V4 = typename Vec4T<R>::type;
+  const uint32_t i = blockIdx.x * blockDim.x + threadIdx.x;
+  if (i >= p.counters[C_ACTIVE]) return;
+  uint32_t n_closest = 0, n_any = 0;   // query counts for rrt_stats (totals[2], totals[3])
+  const QEnt qe = p.q_active[i];
+  const uint32_t index = qe.index;
+  uint32_t dim = qe.db & 0xffffu;
+  struct Frame { V3<R> o, d, lo; Rgb<R> beta; int skip, depth, phase; };
+  Frame st[kTreeMax];
+  int sp = 0;
+  {
+    const V4 ro = p.ray_o[i], rd = p.ray_d[i];
+    st[0].o = V3<R>(ro.x, ro.y, ro.z); st[0].d = V3<R>(rd.x, rd.y, rd.z); st[0].lo = V3<R>();
+    st[0].beta = Rgb<R>(R(1)); st[0].skip = -1; st[0].depth = 1; st[0].phase = 0;   // li(ray, .., depth = 1)
+    sp = 1;
+  }
+  Rgb<R> L;
+  const bool all_lights = s.integrator == 2 || s.light_strategy == 1 /* RRT_STRATEGY_ALL */;
+  while (sp > 0) {
+    Frame& f = st[sp - 1];
+    RayCtx<R> r = make_ctx(f.o, f.d, Const<R>::inf, f.lo);
+    R hu = 0, hv = 0;
+    uint32_t nn, np;
+    int hit;
+    { PrivStack stack; hit = traverse_closest(s, r, stack, f.skip, &hu, &hv, &nn, &np); }
+    if (f.phase == 0) n_closest++;   // the phase-1 re-intersection is bookkeeping, not a reference query
+    if (hit < 0) { sp--; continue; }   // `for light in lights { l += le; return l }`: le = 0
+    const Surf<R> si = build_surface(s, hit, f.o, f.d, r.tmax, hu, hv);
+    if (!si.ok) { atomicOr(&p.counters[C_ERROR], (uint32_t)ERR_SHADING_NORMAL); sp--; continue; }
+    Bsdf<R, 4> bsdf;
+    build_bsdf(s, si, &bsdf, false);   // allow_multiple_lobes = false (directlighting.rs:91, intersect_debug.rs:71)
+    const Rgb<R> beta = f.beta;
+    const int depth = f.depth;
+    uint32_t want = 0;   // lobe class of the continuation to try now
+    if (f.phase == 0) {
+      if (s.integrator == 2) L = L + beta * R(0.1);   // intersect_debug.rs:66-70
+      if (s.n_lights > 0) {
+        const uint32_t n_iter = all_lights ? s.n_lights : 1u;
+        for (uint32_t j = 0; j < n_iter; j++) {
+          uint32_t ln = j;
+          R pick_pdf = R(1);
+          if (!all_lights) {   // uniform_sample_one_light(.., None) integrator/mod.rs:377-386
+            const R v = to_real<R>(draw_1d(s, index, &dim)) * (R)s.n_lights;
+            const uint32_t vi = (v != v || v <= R(0)) ? 0u : (uint32_t)v;
+            ln = vi < s.n_lights - 1 ? vi : s.n_lights - 1;
+            pick_pdf = R(1) / (R)s.n_lights;
+          }
+          double du0, du1;
+          draw_2d(s, index, &dim, &du0, &du1);
+          skip_2d(s, &dim);   // u_scattering
+          V3<R> so, sd;
+          Rgb<R> ld;
+          if (estimate_direct_light(si, bsdf, s.lights[ln], to_real<R>(du0), to_real<R>(du1), &so, &sd, &ld)) {
+            RayCtx<R> sr = make_ctx(so, sd, R(1) - R(0.0001), si.p_lo);
+            PrivStack stack;
+            n_any++;
+            if (!traverse_any(s, sr, stack, self_prim<R>(hit), &nn, &np)) L = L + beta * (ld / pick_pdf);
+          }
+        }
+      }
+      if (depth + 1 < s.max_depth) { f.phase = 1; want = BXDF_SPECULAR | BXDF_REFLECTION; }
+      else sp--;
+    } else {
+      want = BXDF_SPECULAR | BXDF_TRANSMISSION;
+      sp--;   // this vertex is finished once its transmit child (if any) is pushed
+    }
+    if (want) {   // specular_reflect / specular_transmit: one 2D draw each, whether or not such a lobe exists
+      double db0, db1;
+      draw_2d(s, index, &dim, &db0, &db1);
+      V3<R> wi;
+      R pdf = R(0);
+      uint32_t sampled = 0;
+      const Rgb<R> fs = bsdf.sample_f(si.wo, &wi, to_real<R>(db0), to_real<R>(db1), &pdf, want, &sampled);
+      if (pdf > R(0) && !fs.is_black() && absdot(wi, si.sn) != R(0) && sp < kTreeMax) {
+        Frame& c = st[sp++];
+        c.o = si.p; c.lo = si.p_lo; c.d = vnormalize(wi);
+        c.beta = beta * (fs * absdot(wi, si.sn) / pdf);
+        c.skip = self_prim<R>(hit); c.depth = depth + 1; c.phase = 0;
+      }
+    }
+  }
+  V4 l = p.L[qe.slot];
+  l.x += L.r; l.y += L.g; l.z += L.b;
+  p.L[qe.slot] = l;
+  if (n_closest) atomicAdd(&totals[2], (unsigned long long)n_closest);
+  if (n_any) atomicAdd(&totals[3], (unsigned long long)n_any);
 }
 
 // queue rotation between bounces: active <- next, next <- 0, shadow <- 0 (single thread)

@@ -743,7 +743,7 @@ struct Bsdf {
 
 // Material::compute_scattering_functions (matte.rs:35-60, plastic.rs:42-73, metal.rs:48-89, mirror.rs:27-47,
 // debug_material.rs:37-48) with constant textures
-template <typename R, int NL> RRT_DEV void build_lobes(const Material<R>& m, Bsdf<R, NL>* b) {
+template <typename R, int NL> RRT_DEV void build_lobes(const Material<R>& m, Bsdf<R, NL>* b, bool allow_multiple_lobes = true) {
   b->n = 0;
   b->eta = R(1);
 #pragma unroll
@@ -795,15 +795,24 @@ template <typename R, int NL> RRT_DEV void build_lobes(const Material<R>& m, Bsd
       }
       break;
     }
-    case 5: {  // GlassMaterial glass.rs:52-112 (Path: allow_multiple_lobes = true, mode = Radiance)
+    case 5: {  // GlassMaterial glass.rs:52-112 (mode = Radiance; allow_multiple_lobes: Path true, DirectLighting / Debug false)
       const R eta = m.index;
       R ur = m.u_roughness, vr = m.v_roughness;
       const Rgb<R> r = rgb_clamp0(Rgb<R>(m.kr)), t = rgb_clamp0(Rgb<R>(m.kt));
       b->eta = eta;
       const bool is_specular = ur == R(0) && vr == R(0);
-      if (is_specular) {
+      if (is_specular && allow_multiple_lobes) {
         Lobe<R>& l = b->lobes[0]; b->n++;
         l.kind = LOBE_FRESNEL_SPEC; l.type = BXDF_SPECULAR | BXDF_ALL; l.r = r; l.k = t; l.a = R(1); l.b = eta; l.fr = FR_NOOP;
+      } else if (is_specular) {
+        if (!r.is_black()) {
+          Lobe<R>& l = b->lobes[0]; b->n++;
+          l.kind = LOBE_SPEC_REFL; l.type = BXDF_REFLECTION | BXDF_SPECULAR; l.r = r; l.fr = FR_DIELECTRIC; l.eta_i = Rgb<R>(R(1)); l.eta_t = Rgb<R>(eta);
+        }
+        if (!t.is_black()) {
+          Lobe<R>& l = b->lobes[1]; b->n++;
+          l.kind = LOBE_SPEC_TRANS; l.type = BXDF_SPECULAR | BXDF_TRANSMISSION; l.r = t; l.a = R(1); l.b = eta; l.fr = FR_NOOP;
+        }
       } else {
         if (m.remap_roughness) { ur = roughness_to_alpha(ur); vr = roughness_to_alpha(vr); }
         if (!r.is_black()) {

@@ -305,6 +305,11 @@ class Handle : public HandleBase {
             hipLaunchKernelGGL(k_rotate, dim3(1), dim3(1), 0, st_, counters_.p, 0);
           }
         } else if (integ == RRT_INT_DIRECT || integ == RRT_INT_DEBUG) {
+          if (has_transmissive_) {   // binary recursion with depth-first sampler dimensions: one thread per camera sample
+            size_t e2 = tick(3);
+            hipLaunchKernelGGL((k_direct_tree<R>), dim3(grid), dim3(kBlock), 0, st_, scene_, pool_, totals_.p);
+            tock(e2);
+          } else {
           const bool all = integ == RRT_INT_DEBUG || desc_.integrator.light_strategy == RRT_STRATEGY_ALL;
           // level k handles reference depth k+1; specular recursion while depth + 1 < max_depth
           for (int level = 0; level < std::max(1, max_depth - 1); level++) {
@@ -330,6 +335,7 @@ class Handle : public HandleBase {
             tock(e);
             swap_queues();
             hipLaunchKernelGGL(k_rotate, dim3(1), dim3(1), 0, st_, counters_.p, 0);
+          }
           }
         }
         e = tick(4);
@@ -445,8 +451,10 @@ class Handle : public HandleBase {
     }
   }
   void check_renderable() {
-    if (has_transmissive_ && desc_.integrator.type != RRT_INT_PATH)
-      throw UnsupportedError("Glass / Translucent materials are in scope for the Path integrator only: specular_transmit (integrator/mod.rs:199-301) makes DirectLighting a branching recursion");
+    if (has_transmissive_ && (desc_.integrator.type == RRT_INT_DIRECT || desc_.integrator.type == RRT_INT_DEBUG)) {
+      if (desc_.integrator.max_depth > kTreeMax) throw UnsupportedError("DirectLighting / Debug with transmissive materials: max_depth above 16");
+      if (deep_) throw UnsupportedError("DirectLighting / Debug with transmissive materials on a BVH deeper than 64");
+    }
     if (desc_.sampler.type == RRT_SAMPLER_STRATIFIED) {
       // index word = pixel << 10 | sample number; 8-bit 1D / 2D dimension counters (<= 3 of each per bounce)
       if (desc_.sampler.samples_per_pixel > 1024 || (uint64_t)desc_.film.xres * (uint64_t)desc_.film.yres > (1ull << 22))
