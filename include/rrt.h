@@ -32,7 +32,7 @@
 extern "C" {
 #endif
 
-#define RRT_ABI_VERSION 3
+#define RRT_ABI_VERSION 4
 
 /* ---- error codes ------------------------------------------------------- */
 enum {
@@ -103,7 +103,35 @@ typedef struct rrt_prim {
   uint32_t material;    /* index into materials                       */
 } rrt_prim;
 
-/* constant-texture material parameters, material/{matte,plastic,metal,mirror,debug_material}.rs */
+/* Texture graph (texture/ module, built by make_textures renderprocess.rs:298-515). Float and rgb textures share one
+ * array; a float texture carries its value in all three channels. Children are indices of textures created EARLIER
+ * (the reference captures the Arc at creation time, so a later texture of the same name does not rebind them), or -1
+ * with the fallback constant in `fallback[]`. ImageTexture (needs the `image` crate's decoders + MIPMap) is not part
+ * of the graph: a material that uses one is RRT_EUNSUP. */
+enum { RRT_TEX_CONSTANT = 0, RRT_TEX_MIX = 1, RRT_TEX_BILERP = 2, RRT_TEX_CHECKER2D = 3, RRT_TEX_CHECKER3D = 4,
+       RRT_TEX_SCALE = 5, RRT_TEX_WINDY = 6, RRT_TEX_WRINKLED = 7, RRT_TEX_UV = 8 };
+enum { RRT_MAP_UV = 0, RRT_MAP_SPHERICAL = 1, RRT_MAP_CYLINDRICAL = 2, RRT_MAP_PLANAR = 3, RRT_MAP_IDENTITY3D = 4 };
+typedef struct rrt_texture {
+  int32_t type;            /* RRT_TEX_*                                                              */
+  int32_t mapping;         /* RRT_MAP_* (texture/mod.rs:205-374)                                     */
+  int32_t child[3];        /* t1, t2, amount (Mix) -> textures[] index or -1                         */
+  int32_t aa_none;         /* Checkerboard2D: aamode == "none" (checkerboard.rs:13-16)               */
+  int32_t octaves, pad;    /* Wrinkled                                                               */
+  double fallback[3][3];   /* get_text_fallback's ConstantTexture per child (renderprocess.rs:282-296) */
+  double v[4][3];          /* CONSTANT: v[0]; BILERP: v00, v01, v10, v11                              */
+  double omega;            /* Wrinkled                                                               */
+  double map[4];           /* UV: su, sv, du, dv;  PLANAR: ds, dt                                    */
+  double vs[3], vt[3];     /* PLANAR                                                                 */
+  double world_to_texture[16];   /* SPHERICAL, CYLINDRICAL: inverse(to_world); IDENTITY3D: to_world itself
+                                    (renderprocess.rs:368,384,388 pass `to_world` as world_to_texture) */
+} rrt_texture;
+
+/* material parameter slots of rrt_material.tex[] */
+enum { RRT_P_KD = 0, RRT_P_KS, RRT_P_KR, RRT_P_ETA, RRT_P_K, RRT_P_SIGMA, RRT_P_ROUGHNESS, RRT_P_UROUGHNESS,
+       RRT_P_VROUGHNESS, RRT_P_KT, RRT_P_REFLECT, RRT_P_TRANSMIT, RRT_P_INDEX, RRT_P_COUNT };
+
+/* material parameters, material/{matte,plastic,metal,mirror,debug_material,glass,translucent}.rs: the constant
+ * value of each parameter, or (tex[slot] >= 0) the texture that replaces it at every hit */
 typedef struct rrt_material {
   int32_t type;         /* RRT_MAT_*                                  */
   int32_t remap_roughness;
@@ -113,6 +141,8 @@ typedef struct rrt_material {
   double kt[3];         /* glass */
   double reflect[3], transmit[3];   /* translucent */
   double index;         /* glass "eta" (a float texture there; `eta` above is MetalMaterial's spectrum) */
+  int32_t tex[RRT_P_COUNT];   /* index into rrt_scene_desc.textures per RRT_P_* slot, -1 = the constant above */
+  int32_t pad;
 } rrt_material;
 
 /* PointLight lights/point.rs:13-19, DiffuseAreaLight lights/diffuse.rs:13-22 */
@@ -196,6 +226,7 @@ typedef struct rrt_scene_desc {
   const rrt_xform* xforms;   size_t n_xforms;
   const rrt_prim* prims;     size_t n_prims;     /* aggregate input order, renderprocess.rs:1178-1304 */
   const rrt_material* materials; size_t n_materials;
+  const rrt_texture* textures;   size_t n_textures;    /* only the textures some material evaluates per hit */
   const rrt_light* lights;   size_t n_lights;    /* scene.lights; infinite_lights unsupported */
   /* BVHAccel, bvh.rs:116-121 */
   const rrt_bvh_node* bvh_nodes; size_t n_bvh_nodes;

@@ -93,6 +93,8 @@ inline Rgb rsqrt(Rgb a) { return {std::sqrt(a.c[0]), std::sqrt(a.c[1]), std::sqr
 inline Rgb rclamp0(Rgb a) { return {clampd(a.c[0], 0.0, INF), clampd(a.c[1], 0.0, INF), clampd(a.c[2], 0.0, INF)}; }
 
 struct Ray { V3 o, d; double t_max = INF; };
+// the differential half of RayDifferential (geometry.rs:80-92)
+struct RayDiff { bool has = false; V3 rxo, rxd, ryo, ryd; };
 inline Ray ray_new(V3 o, V3 d, double tmax) { Ray r; r.o = o; r.d = vnormalize(d); r.t_max = tmax; return r; }  // geometry.rs:1841
 inline V3 ray_at(const Ray& r, double t) { return r.o + r.d * t; }
 
@@ -140,22 +142,28 @@ struct SI {
   V3 p, n, wo;                 // BaseInteraction
   double u = 0, v = 0;         // uv
   V3 dpdu, dpdv;
+  V3 dndu, dndv;
   V3 sn, sdpdu, sdpdv;         // shading
+  V3 sdndu, sdndv;
+  V3 dpdx, dpdy;               // compute_differentials interaction.rs:223-284
+  double dudx = 0, dvdx = 0, dudy = 0, dvdy = 0;
   int prim = -1;               // index into prims (GeometricPrimitive)
   bool valid = false;
 };
 
 // SurfaceInteraction::new interaction.rs:131-181
-inline void si_new(SI* s, V3 p, double u, double v, V3 wo, V3 dpdu, V3 dpdv) {
+inline void si_new(SI* s, V3 p, double u, double v, V3 wo, V3 dpdu, V3 dpdv, V3 dndu = V3(), V3 dndv = V3()) {
   V3 n = vnormalize(cross(dpdu, dpdv));
   s->p = p; s->u = u; s->v = v; s->wo = wo; s->dpdu = dpdu; s->dpdv = dpdv;
   s->n = n; s->sn = n; s->sdpdu = dpdu; s->sdpdv = dpdv;
+  s->dndu = dndu; s->dndv = dndv; s->sdndu = dndu; s->sdndv = dndv;
+  s->dpdx = s->dpdy = V3(); s->dudx = s->dvdx = s->dudy = s->dvdy = 0.0;
 }
 // set_shading_geometry interaction.rs:183-202
-inline void si_set_shading(SI* s, V3 dpdus, V3 dpdvs, bool authoritative) {
+inline void si_set_shading(SI* s, V3 dpdus, V3 dpdvs, V3 dndus, V3 dndvs, bool authoritative) {
   V3 n = nnormalize(cross(dpdus, dpdvs));
   if (authoritative) n = faceforward(s->n, n); else n = faceforward(n, s->n);
-  s->sn = n; s->sdpdu = dpdus; s->sdpdv = dpdvs;
+  s->sn = n; s->sdpdu = dpdus; s->sdpdv = dpdvs; s->sdndu = dndus; s->sdndv = dndvs;
 }
 // Transformable for SurfaceInteraction transform.rs:628-655
 inline void si_transform(SI* s, const double* m, const double* minv) {
@@ -164,9 +172,13 @@ inline void si_transform(SI* s, const double* m, const double* minv) {
   s->n = xf_nrm(minv, s->n);                 // BaseInteraction::t_by: not re-normalised
   s->dpdu = xf_vec(m, s->dpdu);
   s->dpdv = xf_vec(m, s->dpdv);
+  s->dndu = xf_nrm(minv, s->dndu);
+  s->dndv = xf_nrm(minv, s->dndv);
   s->sn = nnormalize(xf_nrm(minv, s->sn));
   s->sdpdu = xf_vec(m, s->sdpdu);
   s->sdpdv = xf_vec(m, s->sdpdv);
+  s->sdndu = xf_nrm(minv, s->sdndu);
+  s->sdndv = xf_nrm(minv, s->sdndv);
   s->sn = faceforward(s->sn, s->n);
 }
 
@@ -262,7 +274,20 @@ bool tri_intersect(const Scene& sc, const rrt_tri& t, const Ray& r, double* thit
     V3 ts = cross(ss, ns);
     if (len2(ts) > 0.0) { ts = vnormalize(ts); ss = cross(ts, ns); }
     else coordinate_system(ns, &ss, &ts);
-    si_set_shading(ist, ss, ts, true);  // dndu/dndv only feed differentials (unused by constant textures)
+    // dndu / dndv of the shading geometry :351-386 (read by the specular ray differentials, integrator/mod.rs:188-196)
+    V3 dndu, dndv;
+    {
+      V3 dn1 = n0 - n2, dn2 = n1 - n2;
+      if (degenerate_uv) {
+        V3 dn = cross(n2 - n0, n1 - n0);
+        if (len2(dn) != 0.0) coordinate_system(dn, &dndu, &dndv);
+      } else {
+        double i_det = 1.0 / determinant;
+        dndu = (dn1 * duv12[1] - dn2 * duv02[1]) * i_det;
+        dndv = (dn1 * -duv12[0] + dn2 * duv02[0]) * i_det;
+      }
+    }
+    si_set_shading(ist, ss, ts, dndu, dndv, true);
   }
   *bu = u; *bv = v;
   return true;
@@ -336,7 +361,17 @@ bool sphere_intersect(const SphereRef& S, const Ray& r, double* thit, SI* ist) {
   double cos_phi = p_hit.x * inv_z_radius, sin_phi = p_hit.y * inv_z_radius;
   V3 dpdu(-s.phi_max * p_hit.y, s.phi_max * p_hit.x, 0.0);
   V3 dpdv = V3(p_hit.z * cos_phi, p_hit.z * sin_phi, -s.radius * std::sin(theta)) * (s.theta_max - s.theta_min);
-  si_new(ist, p_hit, u, v, -ray.d, dpdu, dpdv);  // dndu/dndv: differentials only
+  // sphere.rs:214-242: dndu / dndv from the fundamental forms
+  V3 d2pduu = V3(p_hit.x, p_hit.y, 0.0) * -s.phi_max * s.phi_max;
+  V3 d2pduv = V3(-sin_phi, cos_phi, 0.0) * (s.theta_max - s.theta_min) * p_hit.z * s.phi_max;
+  V3 d2pdvv = p_hit * -(s.theta_max - s.theta_min) * (s.theta_max - s.theta_min);
+  double E = dot(dpdu, dpdu), F = dot(dpdu, dpdv), G = dot(dpdv, dpdv);
+  V3 N = vnormalize(cross(dpdu, dpdv));
+  double e = dot(N, d2pduu), f = dot(N, d2pduv), g = dot(N, d2pdvv);
+  double inv_EFG2 = 1.0 / (E * G - F * F);
+  V3 dndu = dpdu * ((f * F - e * G) * inv_EFG2) + dpdv * ((e * F - f * E) * inv_EFG2);
+  V3 dndv = dpdu * ((g * F - f * G) * inv_EFG2) + dpdv * ((f * F - g * E) * inv_EFG2);
+  si_new(ist, p_hit, u, v, -ray.d, dpdu, dpdv, dndu, dndv);
   si_transform(ist, S.m, S.mi);                  // *ist = obj2world.t(ist)
   *thit = t_hit;
   return true;
@@ -520,6 +555,7 @@ struct Sampler {  // GlobalSampler<Halton>, samplers/mod.rs:266-447 with array_s
     dimension = 0; cur1d = cur2d = 0;
     if (h->type == RRT_SAMPLER_HALTON) interval_sample_index = get_index_for_sample(0);
   }
+  uint64_t samples_per_pixel() const { return h->samples_per_pixel; }   // samplers/mod.rs:245,439
   bool start_next_sample() {  // :378-386 + BaseSampler::start_next_sample :71-76 (Q1); PixelSampler :195-199
     dimension = 0; cur1d = cur2d = 0;
     if (h->type == RRT_SAMPLER_HALTON) interval_sample_index = get_index_for_sample(current_pixel_sample_index + 1);
@@ -638,19 +674,41 @@ struct Camera {
     double rz = c->elems[c->n_elems - 1].thickness;
     return (c->shutter_close - c->shutter_open) * (cos4 * area) / rz * rz;
   }
-  // generate_ray_differential :582-628 (only the success/failure of the auxiliary rays is observable)
-  double generate_ray_differential(double pfx, double pfy, double lx, double ly, Ray* ray) const {
+  // generate_ray_differential :582-628
+  double generate_ray_differential(double pfx, double pfy, double lx, double ly, Ray* ray, RayDiff* rd = nullptr) const {
     double wt = generate_ray(pfx, pfy, lx, ly, ray);
     if (wt == 0.0) return 0.0;
+    RayDiff d;
     double wtx = 0.0;
-    for (double eps : {0.05, -0.05}) { Ray rx; wtx = generate_ray(pfx + eps, pfy, lx, ly, &rx); if (wtx != 0.0) break; }
+    for (double eps : {0.05, -0.05}) {
+      Ray rx;
+      wtx = generate_ray(pfx + eps, pfy, lx, ly, &rx);
+      d.rxo = ray->o + (rx.o - ray->o) / eps;
+      d.rxd = ray->d + (rx.d - ray->d) / eps;
+      if (wtx != 0.0) break;
+    }
     if (wtx == 0.0) return 0.0;
     double wty = 0.0;
-    for (double eps : {0.05, -0.05}) { Ray ry; wty = generate_ray(pfx, pfy + eps, lx, ly, &ry); if (wty != 0.0) break; }
+    for (double eps : {0.05, -0.05}) {
+      Ray ry;
+      wty = generate_ray(pfx, pfy + eps, lx, ly, &ry);
+      d.ryo = ray->o + (ry.o - ray->o) / eps;
+      d.ryd = ray->d + (ry.d - ray->d) / eps;
+      if (wty != 0.0) break;
+    }
     if (wty == 0.0) return 0.0;
+    d.has = true;
+    if (rd) *rd = d;
     return wt;
   }
 };
+// RayDifferential::scale_differentials geometry.rs:1883-1888
+inline void scale_differentials(const Ray& r, RayDiff* d, double s) {
+  d->rxo = r.o + (d->rxo - r.o) * s;
+  d->ryo = r.o + (d->ryo - r.o) * s;
+  d->rxd = r.d + (d->rxd - r.d) * s;
+  d->ryd = r.d + (d->ryd - r.d) * s;
+}
 
 // ---- BVH traversal (bvh.rs:124-236) over primitives.rs wrappers ----------------------------------------
 struct Counters { uint64_t nodes = 0, prims = 0, closest = 0, any = 0; };
@@ -1135,10 +1193,225 @@ struct Bsdf {  // reflection.rs:205-405
   }
 };
 
-// Material::compute_scattering_functions for the in-scope materials (constant textures)
-void compute_scattering(const Scene& sc, const SI& si, Bsdf* bsdf, bool allow_multiple_lobes = true) {
+// ---- SurfaceInteraction::compute_differentials interaction.rs:223-284 --------------------------------------------
+// solve_linear_system_2x2 transform.rs:153-164
+inline bool solve_2x2(const double a[2][2], const double b[2], double* x0, double* x1) {
+  double det = a[0][0] * a[1][1] - a[0][1] * a[1][0];
+  if (std::fabs(det) < 1e-10) return false;
+  *x0 = (a[1][1] * b[0] - a[0][1] * b[1]) / det;
+  *x1 = (a[0][0] * b[1] - a[1][0] * b[0]) / det;
+  if (std::isnan(*x0) || std::isnan(*x1)) return false;
+  return true;
+}
+inline double v3_at(V3 v, int i) { return i == 0 ? v.x : (i == 1 ? v.y : v.z); }
+void compute_differentials(SI* si, const RayDiff& rd) {
+  si->dudx = si->dvdx = si->dudy = si->dvdy = 0.0;
+  si->dpdx = si->dpdy = V3();
+  if (!rd.has) return;
+  double d = dot(si->n, si->p);
+  double tx = -(dot(si->n, rd.rxo) - d) / dot(si->n, rd.rxd);
+  if (std::isinf(tx) || std::isnan(tx)) return;
+  V3 px = rd.rxo + rd.rxd * tx;
+  double ty = -(dot(si->n, rd.ryd) - d) / dot(si->n, rd.ryd);   // :234 reads ry_direction where pbrt reads ry_origin
+  if (std::isinf(ty) || std::isnan(ty)) return;
+  V3 py = rd.ryo + rd.ryd * ty;
+  si->dpdx = px - si->p;
+  si->dpdy = py - si->p;
+  int dim[2];
+  if (std::fabs(si->n.x) > std::fabs(si->n.y) && std::fabs(si->n.x) > std::fabs(si->n.z)) { dim[0] = 1; dim[1] = 2; }
+  else if (std::fabs(si->n.y) > std::fabs(si->n.z)) { dim[0] = 0; dim[1] = 2; }
+  else { dim[0] = 0; dim[1] = 1; }
+  double a[2][2] = {{v3_at(si->dpdu, dim[0]), v3_at(si->dpdv, dim[0])}, {v3_at(si->dpdu, dim[1]), v3_at(si->dpdv, dim[1])}};
+  double bx[2] = {v3_at(px, dim[0]) - v3_at(si->p, dim[0]), v3_at(px, dim[1]) - v3_at(si->p, dim[1])};
+  double by[2] = {v3_at(py, dim[0]) - v3_at(si->p, dim[0]), v3_at(py, dim[1]) - v3_at(si->p, dim[1])};
+  if (!solve_2x2(a, bx, &si->dudx, &si->dvdx)) { si->dudx = 0.0; si->dvdx = 0.0; }
+  if (!solve_2x2(a, by, &si->dudy, &si->dvdy)) { si->dudy = 0.0; si->dvdy = 0.0; }
+}
+
+// ---- textures (texture/*.rs) over the flat graph of rrt_scene_desc.textures ---------------------------------------
+// Perlin noise, texture/mod.rs:13-160 (NOISE_PERM is Ken Perlin's published reference permutation, doubled)
+static const uint8_t kNoisePerm[512] = {
+#define RRT_PERLIN_256 \
+  151, 160, 137, 91, 90, 15, 131, 13, 201, 95, 96, 53, 194, 233, 7, 225, 140, 36, 103, 30, 69, 142, 8, 99, 37, 240, 21, 10, 23, 190, 6, 148, \
+  247, 120, 234, 75, 0, 26, 197, 62, 94, 252, 219, 203, 117, 35, 11, 32, 57, 177, 33, 88, 237, 149, 56, 87, 174, 20, 125, 136, 171, 168, 68, 175, \
+  74, 165, 71, 134, 139, 48, 27, 166, 77, 146, 158, 231, 83, 111, 229, 122, 60, 211, 133, 230, 220, 105, 92, 41, 55, 46, 245, 40, 244, 102, 143, 54, \
+  65, 25, 63, 161, 1, 216, 80, 73, 209, 76, 132, 187, 208, 89, 18, 169, 200, 196, 135, 130, 116, 188, 159, 86, 164, 100, 109, 198, 173, 186, 3, 64, \
+  52, 217, 226, 250, 124, 123, 5, 202, 38, 147, 118, 126, 255, 82, 85, 212, 207, 206, 59, 227, 47, 16, 58, 17, 182, 189, 28, 42, 223, 183, 170, 213, \
+  119, 248, 152, 2, 44, 154, 163, 70, 221, 153, 101, 155, 167, 43, 172, 9, 129, 22, 39, 253, 19, 98, 108, 110, 79, 113, 224, 232, 178, 185, 112, 104, \
+  218, 246, 97, 228, 251, 34, 242, 193, 238, 210, 144, 12, 191, 179, 162, 241, 81, 51, 145, 235, 249, 14, 239, 107, 49, 192, 214, 31, 181, 199, 106, 157, \
+  184, 84, 204, 176, 115, 121, 50, 45, 127, 4, 150, 254, 138, 236, 205, 93, 222, 114, 67, 29, 24, 72, 243, 141, 128, 195, 78, 66, 215, 61, 156, 180
+  RRT_PERLIN_256, RRT_PERLIN_256
+#undef RRT_PERLIN_256
+};
+inline double noise_grad(int x, int y, int z, double dx, double dy, double dz) {   // grad :111-130
+  int h = kNoisePerm[kNoisePerm[kNoisePerm[x] + y] + z] & 15;
+  double u = (h < 8 || h == 12 || h == 13) ? dx : dy;
+  double v = (h < 4 || h == 12 || h == 13) ? dy : dz;
+  return ((h & 1) ? -u : u) + ((h & 2) ? -v : v);
+}
+inline double noise_weight(double t) { double t3 = t * t * t, t4 = t3 * t; return 6.0 * t4 * t - 15.0 * t4 + 10.0 * t3; }
+inline double lerp_r(double t, double a, double b) { return a * (1.0 - t) + b * t; }   // misc.rs:223-228
+inline int f2i_sat(double v) {   // Rust `as i32`: saturating, NaN -> 0
+  if (v != v) return 0;
+  if (v >= 2147483647.0) return 2147483647;
+  if (v <= -2147483648.0) return -2147483647 - 1;
+  return (int)v;
+}
+double noise_flt(double x, double y, double z) {   // :73-105
+  int ix = f2i_sat(std::floor(x)), iy = f2i_sat(std::floor(y)), iz = f2i_sat(std::floor(z));
+  double dx = x - (double)ix, dy = y - (double)iy, dz = z - (double)iz;
+  ix &= 255; iy &= 255; iz &= 255;
+  double w000 = noise_grad(ix, iy, iz, dx, dy, dz), w100 = noise_grad(ix + 1, iy, iz, dx - 1.0, dy, dz);
+  double w010 = noise_grad(ix, iy + 1, iz, dx, dy - 1.0, dz), w110 = noise_grad(ix + 1, iy + 1, iz, dx - 1.0, dy - 1.0, dz);
+  double w001 = noise_grad(ix, iy, iz + 1, dx, dy, dz - 1.0), w101 = noise_grad(ix + 1, iy, iz + 1, dx - 1.0, dy, dz - 1.0);
+  double w011 = noise_grad(ix, iy + 1, iz + 1, dx, dy - 1.0, dz - 1.0), w111 = noise_grad(ix + 1, iy + 1, iz + 1, dx - 1.0, dy - 1.0, dz - 1.0);
+  double wx = noise_weight(dx), wy = noise_weight(dy), wz = noise_weight(dz);
+  double x00 = lerp_r(wx, w000, w100), x10 = lerp_r(wx, w010, w110), x01 = lerp_r(wx, w001, w101), x11 = lerp_r(wx, w011, w111);
+  double y0 = lerp_r(wy, x00, x10), y1 = lerp_r(wy, x01, x11);
+  return lerp_r(wz, y0, y1);
+}
+inline double smooth_step(double mn, double mx, double v) { double t = clampd((v - mn) / (mx - mn), 0.0, 1.0); return t * t * (-2.0 * t + 3.0); }
+double tex_fbm(V3 p, V3 dpdx, V3 dpdy, double omega, int max_octaves) {   // fbm :138-153
+  double l2 = rmax(len2(dpdx), len2(dpdy));
+  double n = clampd(-1.0 - 0.5 * std::log2(l2), 0.0, (double)max_octaves);
+  int n_int = f2i_sat(std::floor(n));
+  double sum = 0.0, lambda = 1.0, o = 1.0;
+  for (int i = 0; i < n_int; i++) { V3 q = p * lambda; sum += o * noise_flt(q.x, q.y, q.z); lambda *= 1.99; o *= omega; }
+  double n_partial = n - (double)n_int;
+  V3 q = p * lambda;
+  sum += o * smooth_step(0.3, 0.7, n_partial) * noise_flt(q.x, q.y, q.z);
+  return sum;
+}
+double tex_turbulence(V3 p, V3 dpdx, V3 dpdy, double omega, int max_octaves) {   // turbulence :155-185
+  double l2 = rmax(len2(dpdx), len2(dpdy));
+  double n = clampd(-1.0 - 0.5 * std::log2(l2), 0.0, (double)max_octaves);
+  int n_int = f2i_sat(std::floor(n));
+  double sum = 0.0, lambda = 1.0, o = 1.0;
+  for (int i = 0; i < n_int; i++) { V3 q = p * lambda; sum += o * std::fabs(noise_flt(q.x, q.y, q.z)); lambda *= 1.99; o *= omega; }
+  double n_partial = n - (double)n_int;
+  V3 q = p * lambda;
+  sum += o * lerp_r(smooth_step(0.3, 0.7, n_partial), 0.2, std::fabs(noise_flt(q.x, q.y, q.z)));
+  for (int i = n_int; i < max_octaves; i++) { sum += o * 0.2; o *= omega; }
+  return sum;
+}
+
+// TextureMapping2D::map texture/mod.rs:205-352
+inline void map_sphere(const double* m, V3 p, double* s, double* t) {
+  V3 v = vnormalize(xf_pt(m, p) - V3());
+  double theta = std::acos(clampd(v.z, -1.0, 1.0));
+  double phi = std::atan2(v.y, v.x);
+  if (phi < 0.0) phi += 2.0 * PI;
+  *s = theta / PI; *t = phi / (PI * 2.0);
+}
+inline void map_cylinder(const double* m, V3 p, double* s, double* t) {
+  V3 v = vnormalize(xf_pt(m, p) - V3());
+  *s = (PI + std::atan2(v.y, v.x)) / (2.0 * PI); *t = v.z;
+}
+void tex_map_2d(const rrt_texture& t, const SI& si, double st[2], double dstdx[2], double dstdy[2]) {
+  switch (t.mapping) {
+    case RRT_MAP_UV:
+      dstdx[0] = t.map[0] * si.dudx; dstdx[1] = t.map[1] * si.dvdx;
+      dstdy[0] = t.map[0] * si.dudy; dstdy[1] = t.map[1] * si.dvdy;
+      st[0] = t.map[0] * si.u + t.map[2]; st[1] = t.map[1] * si.v + t.map[3];
+      return;
+    case RRT_MAP_SPHERICAL: case RRT_MAP_CYLINDRICAL: {
+      auto f = t.mapping == RRT_MAP_SPHERICAL ? map_sphere : map_cylinder;
+      const double delta = 0.1;
+      double sx[2], sy[2];
+      f(t.world_to_texture, si.p, &st[0], &st[1]);
+      f(t.world_to_texture, si.p + si.dpdx * delta, &sx[0], &sx[1]);
+      dstdx[0] = (sx[0] - st[0]) / delta; dstdx[1] = (sx[1] - st[1]) / delta;
+      f(t.world_to_texture, si.p + si.dpdy * delta, &sy[0], &sy[1]);
+      dstdy[0] = (sy[0] - st[0]) / delta; dstdy[1] = (sy[1] - st[1]) / delta;
+      if (dstdx[1] > 0.5) dstdx[1] = 1.0 - dstdx[1]; else if (dstdx[1] < -0.5) dstdx[1] = -(dstdx[1] + 1.0);
+      if (dstdy[1] > 0.5) dstdy[1] = 1.0 - dstdy[1]; else if (dstdy[1] < -0.5) dstdy[1] = -(dstdy[1] + 1.0);
+      return;
+    }
+    default: {   // RRT_MAP_PLANAR
+      V3 vs(t.vs[0], t.vs[1], t.vs[2]), vt(t.vt[0], t.vt[1], t.vt[2]);
+      dstdx[0] = dot(si.dpdx, vs); dstdx[1] = dot(si.dpdx, vt);
+      dstdy[0] = dot(si.dpdy, vs); dstdy[1] = dot(si.dpdy, vt);
+      st[0] = t.map[0] + dot(si.p, vs); st[1] = t.map[1] + dot(si.p, vt);
+      return;
+    }
+  }
+}
+inline double bump_int(double x) { return std::floor(x / 2.0) + 2.0 * rmax(x / 2.0 - std::floor(x / 2.0) - 0.5, 0.0); }   // checkerboard.rs:46-48
+
+Rgb tex_eval(const rrt_scene_desc* d, int id, const SI& si);
+inline Rgb tex_child(const rrt_scene_desc* d, const rrt_texture& t, int slot, const SI& si) {
+  return t.child[slot] >= 0 ? tex_eval(d, t.child[slot], si) : Rgb(t.fallback[slot]);
+}
+// Texture::evaluate of every in-scope texture; a float texture carries its value in all three channels
+Rgb tex_eval(const rrt_scene_desc* d, int id, const SI& si) {
+  const rrt_texture& t = d->textures[id];
+  switch (t.type) {
+    case RRT_TEX_CONSTANT: return Rgb(t.v[0]);
+    case RRT_TEX_MIX: {   // mix.rs:32-38
+      double amt = tex_child(d, t, 2, si).c[0];
+      return tex_child(d, t, 0, si) * (1.0 - amt) + tex_child(d, t, 1, si) * amt;
+    }
+    case RRT_TEX_SCALE: return tex_child(d, t, 0, si) * tex_child(d, t, 1, si);   // scale.rs:30-32
+    case RRT_TEX_BILERP: {   // bilerp.rs:33-43
+      double st[2], dx[2], dy[2];
+      tex_map_2d(t, si, st, dx, dy);
+      return Rgb(t.v[0]) * (1.0 - st[0]) * (1.0 - st[1]) + Rgb(t.v[1]) * (1.0 - st[0]) * st[1] + Rgb(t.v[2]) * st[0] * (1.0 - st[1]) + Rgb(t.v[3]) * st[0] * st[1];
+    }
+    case RRT_TEX_UV: {   // uv.rs:20-28
+      double st[2], dx[2], dy[2];
+      tex_map_2d(t, si, st, dx, dy);
+      return Rgb(st[0] - std::floor(st[0]), st[1] - std::floor(st[1]), 0.0);
+    }
+    case RRT_TEX_CHECKER2D: {   // checkerboard.rs:54-97
+      double st[2], dx[2], dy[2];
+      tex_map_2d(t, si, st, dx, dy);
+      bool first = (f2i_sat(std::floor(st[0])) + f2i_sat(std::floor(st[1]))) % 2 == 0;
+      if (t.aa_none) return tex_child(d, t, first ? 0 : 1, si);
+      double ds = rmax(std::fabs(dx[0]), std::fabs(dx[1])), dt = rmax(std::fabs(dy[0]), std::fabs(dy[1]));
+      double s0 = st[0] - ds, s1 = st[0] + ds, t0 = st[1] - dt, t1 = st[1] + dt;
+      if (std::floor(s0) == std::floor(s1) && std::floor(t0) == std::floor(t1)) return tex_child(d, t, first ? 0 : 1, si);
+      double sint = (bump_int(s1) - bump_int(s0)) / (2.0 * ds), tint = (bump_int(t1) - bump_int(t0)) / (2.0 * dt);
+      double area2 = sint + tint - 2.0 * sint * tint;
+      if (ds > 1.0 || dt > 1.0) area2 = 0.5;
+      return tex_child(d, t, 0, si) * (1.0 - area2) + tex_child(d, t, 1, si) * area2;
+    }
+    case RRT_TEX_CHECKER3D: {   // checkerboard.rs:121-131
+      V3 p = xf_pt(t.world_to_texture, si.p);
+      return tex_child(d, t, f2i_sat(std::floor(p.x) + std::floor(p.y) + std::floor(p.z)) % 2 == 0 ? 0 : 1, si);
+    }
+    case RRT_TEX_WINDY: {   // windy.rs:15-23
+      V3 p = xf_pt(t.world_to_texture, si.p), dpdx = xf_vec(t.world_to_texture, si.dpdx), dpdy = xf_vec(t.world_to_texture, si.dpdy);
+      double wind_strength = tex_fbm(p * 0.1, dpdx * 0.1, dpdy * 0.1, 0.5, 3);
+      double wave_height = tex_fbm(p, dpdx, dpdy, 0.5, 6);
+      return Rgb(std::fabs(wind_strength) * wave_height);
+    }
+    case RRT_TEX_WRINKLED: {   // wrinkled.rs:21-28
+      V3 p = xf_pt(t.world_to_texture, si.p), dpdx = xf_vec(t.world_to_texture, si.dpdx), dpdy = xf_vec(t.world_to_texture, si.dpdy);
+      return Rgb(tex_turbulence(p, dpdx, dpdy, t.omega, t.octaves));
+    }
+    default: throw OraclePanic{"texture type outside the oracle's scope"};
+  }
+}
+// a material with every textured parameter replaced by its value at this hit
+rrt_material resolve_material(const rrt_scene_desc* d, const rrt_material& m0, const SI& si) {
+  rrt_material m = m0;
+  double* dst3[RRT_P_COUNT] = {m.kd, m.ks, m.kr, m.eta, m.k, nullptr, nullptr, nullptr, nullptr, m.kt, m.reflect, m.transmit, nullptr};
+  double* dst1[RRT_P_COUNT] = {nullptr, nullptr, nullptr, nullptr, nullptr, &m.sigma, &m.roughness, &m.u_roughness, &m.v_roughness, nullptr, nullptr, nullptr, &m.index};
+  for (int k = 0; k < RRT_P_COUNT; k++) {
+    if (m.tex[k] < 0) continue;
+    Rgb v = tex_eval(d, m.tex[k], si);
+    if (dst3[k]) { dst3[k][0] = v.c[0]; dst3[k][1] = v.c[1]; dst3[k][2] = v.c[2]; } else *dst1[k] = v.c[0];
+  }
+  return m;
+}
+
+// SurfaceInteraction::compute_scattering_functions interaction.rs:203-214 (compute_differentials first) +
+// Material::compute_scattering_functions for the in-scope materials
+void compute_scattering(const Scene& sc, SI& si, const RayDiff& rd, Bsdf* bsdf, bool allow_multiple_lobes = true) {
+  compute_differentials(&si, rd);
+
   if (!(dot(si.n, si.sn) >= 0.0)) throw OraclePanic{"primitives.rs:100 assert!(dot3(&si.ist.n, &si.shading.n) >= 0.0)"};
-  const rrt_material& m = sc.d->materials[sc.d->prims[si.prim].material];
+  const rrt_material m = resolve_material(sc.d, sc.d->materials[sc.d->prims[si.prim].material], si);
   bsdf->init(si);
   switch (m.type) {
     case RRT_MAT_MATTE: {  // matte.rs:35-60
@@ -1455,7 +1728,7 @@ struct Integ {
   Counters* cnt;
 
   // PathIntegrator::li path.rs:51-226
-  Rgb li_path(Ray ray, Sampler& smp) {
+  Rgb li_path(Ray ray, RayDiff rdiff, Sampler& smp) {
     Rgb l, beta(1.0);
     bool specular_bounce = false;
     long bounces = 0;
@@ -1467,7 +1740,7 @@ struct Integ {
       (void)specular_bounce;
       if (!found || bounces >= (long)in.max_depth) break;
       Bsdf bsdf;
-      compute_scattering(sc, isect, &bsdf);
+      compute_scattering(sc, isect, rdiff, &bsdf);
       if (bsdf.num_components(BXDF_ALL & ~BXDF_SPECULAR) > 0) {
         Rgb ld = beta * uniform_sample_one_light(sc, isect, bsdf, smp, &distrib, cnt);
         l = l + ld;
@@ -1487,6 +1760,7 @@ struct Integ {
         eta_scale *= (dot(wo, isect.n) > 0.0) ? eta * eta : 1.0 / (eta * eta);
       }
       ray = ray_new(isect.p, wi, INF);  // spawn_ray: no origin offset (Q8)
+      rdiff = RayDiff();                // `.into()`: has_differentials = false (path.rs:163)
       Rgb rr_beta = beta * eta_scale;
       if (rr_beta.max_component() < in.rr_threshold && bounces > 3) {
         double q = rmax(1.0 - rr_beta.max_component(), 0.05);
@@ -1502,7 +1776,7 @@ struct Integ {
   // specular_reflect integrator/mod.rs:150-198, then specular_transmit :199-301: each draws a 2D sample and recurses;
   // the reflect subtree consumes its sampler dimensions before the transmit draw (depth-first).
   template <typename F>
-  Rgb specular_terms(const Ray& ray, const SI& isect, const Bsdf& bsdf, Sampler& smp, int depth, F&& li) {
+  Rgb specular_terms(const Ray& ray, const RayDiff& rdiff, const SI& isect, const Bsdf& bsdf, Sampler& smp, int depth, F&& li) {
     Rgb out;
     {
       V3 wo = isect.wo, wi;
@@ -1513,7 +1787,20 @@ struct Integ {
       V3 ns = isect.sn;
       if (pdf > 0.0 && !f.is_black() && absdot(wi, ns) != 0.0) {
         Ray rd = ray_new(isect.p, wi, INF);
-        out = out + f * li(rd, depth + 1) * absdot(wi, ns) / pdf;
+        RayDiff cd;
+        if (rdiff.has) {   // integrator/mod.rs:183-201
+          cd.has = true;
+          cd.rxo = isect.p + isect.dpdx;
+          cd.ryo = isect.p + isect.dpdy;
+          V3 dndx = isect.sdndu * isect.dudx + isect.sdndv * isect.dvdx;
+          V3 dndy = isect.sdndu * isect.dudy + isect.sdndv * isect.dvdy;
+          V3 dwodx = -rdiff.rxd - wo, dwody = -rdiff.ryd - wo;
+          double ddndx = dot(dwodx, ns) + dot(wo, dndx);
+          double ddndy = dot(dwody, ns) + dot(wo, dndy);
+          cd.rxd = wi - dwodx + (dndx * dot(wo, ns) + ns * ddndx) * 0.2;
+          cd.ryd = wi - dwody + (dndy * dot(wo, ns) + ns * ddndy) * 0.2;
+        }
+        out = out + f * li(rd, cd, depth + 1) * absdot(wi, ns) / pdf;
       }
     }
     {
@@ -1525,7 +1812,25 @@ struct Integ {
       V3 ns = isect.sn;
       if (pdf > 0.0 && !f.is_black() && absdot(wi, ns) != 0.0) {   // specular_transmit integrator/mod.rs:199-301
         Ray rd = ray_new(isect.p, wi, INF);
-        out = out + f * li(rd, depth + 1) * absdot(wi, ns) / pdf;
+        RayDiff cd;
+        if (rdiff.has) {   // :238-292
+          cd.has = true;
+          cd.rxo = isect.p + isect.dpdx;
+          cd.ryo = isect.p + isect.dpdy;
+          V3 dndx = isect.sdndu * isect.dudx + isect.sdndv * isect.dvdx;
+          V3 dndy = isect.sdndu * isect.dudy + isect.sdndv * isect.dvdy;
+          double eta = 1.0 / bsdf.eta;
+          if (dot(wo, ns) < 0.0) { eta = 1.0 / eta; ns = -ns; dndx = -dndx; dndy = -dndy; }
+          V3 dwodx = -rdiff.rxd - wo, dwody = -rdiff.ryd - wo;
+          double ddndx = dot(dwodx, ns) + dot(wo, dndx);
+          double ddndy = dot(dwody, ns) + dot(wo, dndy);
+          double mu = eta * dot(wo, ns) - absdot(wi, ns);
+          double dmudx = ddndx * (eta - (eta * eta * dot(wo, ns)) / absdot(wi, ns));
+          double dmudy = ddndy * (eta - (eta * eta * dot(wo, ns)) / absdot(wi, ns));
+          cd.rxd = wi - dwodx * eta + (dndx * mu + ns * dmudx);
+          cd.ryd = wi - dwody * eta + (dndy * mu + ns * dmudy);
+        }
+        out = out + f * li(rd, cd, depth + 1) * absdot(wi, ns) / pdf;   // `ns` is the flipped one here when it was flipped (:293)
       }
     }
     (void)ray;
@@ -1533,32 +1838,32 @@ struct Integ {
   }
 
   // DirectLightingIntegrator::li directlighting.rs:72-132
-  Rgb li_direct(Ray ray, Sampler& smp, int depth) {
+  Rgb li_direct(Ray ray, RayDiff rdiff, Sampler& smp, int depth) {
     SI isect;
     if (!scene_intersect(sc, &ray, &isect, nullptr, cnt)) {
       if (sc.d->n_lights > 0) return Rgb();  // `for light in lights { l += le; return l }` (le = 0)
       throw OraclePanic{"directlighting.rs:91 unbounded recursion: miss with an empty light list (Q20)"};
     }
     Bsdf bsdf;
-    compute_scattering(sc, isect, &bsdf, false);   // allow_multiple_lobes = false (directlighting.rs:91)
+    compute_scattering(sc, isect, rdiff, &bsdf, false);   // allow_multiple_lobes = false (directlighting.rs:91)
     Rgb l;  // isect.le() = 0 (Q18)
     if (sc.d->n_lights > 0) {
       if (in.light_strategy == RRT_STRATEGY_ALL) l = l + uniform_sample_all_lights(sc, isect, bsdf, smp, cnt);
       else l = l + uniform_sample_one_light(sc, isect, bsdf, smp, nullptr, cnt);
     }
-    if ((depth + 1) < in.max_depth) l = l + specular_terms(ray, isect, bsdf, smp, depth, [&](Ray r, int d) { return li_direct(r, smp, d); });
+    if ((depth + 1) < in.max_depth) l = l + specular_terms(ray, rdiff, isect, bsdf, smp, depth, [&](Ray r, RayDiff cd, int d) { return li_direct(r, cd, smp, d); });
     return l;
   }
   // IntersectDebugIntegrator::li intersect_debug.rs:56-89
-  Rgb li_debug(Ray ray, Sampler& smp, int depth) {
+  Rgb li_debug(Ray ray, RayDiff rdiff, Sampler& smp, int depth) {
     SI isect;
     if (!scene_intersect(sc, &ray, &isect, nullptr, cnt)) return Rgb();
     Rgb l(0.1, 0.1, 0.1);
     Bsdf bsdf;
-    compute_scattering(sc, isect, &bsdf, false);   // intersect_debug.rs:71
+    compute_scattering(sc, isect, rdiff, &bsdf, false);   // intersect_debug.rs:71
     Rgb s_l;
     if (sc.d->n_lights > 0) s_l = s_l + uniform_sample_all_lights(sc, isect, bsdf, smp, cnt);
-    if ((depth + 1) < in.max_depth) s_l = s_l + specular_terms(ray, isect, bsdf, smp, depth, [&](Ray r, int d) { return li_debug(r, smp, d); });
+    if ((depth + 1) < in.max_depth) s_l = s_l + specular_terms(ray, rdiff, isect, bsdf, smp, depth, [&](Ray r, RayDiff cd, int d) { return li_debug(r, cd, smp, d); });
     return l + s_l;
   }
   // AOIntegrator::li ao.rs:52-99: compute_scattering_functions is never called, so isect.bsdf is None and
@@ -1568,11 +1873,11 @@ struct Integ {
     scene_intersect(sc, &ray, &isect, nullptr, cnt);
     return Rgb();
   }
-  Rgb li(const Ray& ray, Sampler& smp) {
+  Rgb li(const Ray& ray, const RayDiff& rdiff, Sampler& smp) {
     switch (in.type) {
-      case RRT_INT_PATH: return li_path(ray, smp);
-      case RRT_INT_DIRECT: return li_direct(ray, smp, 1);
-      case RRT_INT_DEBUG: return li_debug(ray, smp, 1);
+      case RRT_INT_PATH: return li_path(ray, rdiff, smp);
+      case RRT_INT_DIRECT: return li_direct(ray, rdiff, smp, 1);
+      case RRT_INT_DEBUG: return li_debug(ray, rdiff, smp, 1);
       default: return li_ao(ray);
     }
   }
@@ -1703,7 +2008,7 @@ int oracle_bsdf_eval(const rrt_scene_desc* d, uint32_t material, int allow_multi
     si_new(&si, V3(), 0.0, 0.0, V3(wo_in[0], wo_in[1], wo_in[2]), V3(1.0, 0.0, 0.0), V3(0.0, 1.0, 0.0));
     si.prim = 0; si.valid = true;
     Bsdf b;
-    compute_scattering(sv, si, &b, allow_multiple_lobes != 0);
+    compute_scattering(sv, si, RayDiff(), &b, allow_multiple_lobes != 0);
     V3 wo(wo_in[0], wo_in[1], wo_in[2]), wi(wi_in[0], wi_in[1], wi_in[2]);
     Rgb f = b.f(wo, wi, BXDF_ALL);
     out16[0] = f.c[0]; out16[1] = f.c[1]; out16[2] = f.c[2];
@@ -1717,6 +2022,33 @@ int oracle_bsdf_eval(const rrt_scene_desc* d, uint32_t material, int allow_multi
     out16[10] = ps; out16[11] = (double)fl; out16[12] = b.eta; out16[13] = (double)b.n;
     out16[14] = (double)b.num_components(BXDF_ALL & ~BXDF_SPECULAR);
     out16[15] = 0.0;
+  });
+}
+
+// Texture::evaluate of textures[tex] at a hand-made interaction: si15 = {p.xyz, uv, dpdx.xyz, dpdy.xyz, dudx, dvdx, dudy, dvdy}
+int oracle_texture_eval(const rrt_scene_desc* d, int32_t tex, const double* si15, double* out3) {
+  return guarded([&]() {
+    if (tex < 0 || (size_t)tex >= d->n_textures) throw OraclePanic{"oracle_texture_eval: texture index out of range"};
+    SI si;
+    si.p = V3(si15[0], si15[1], si15[2]); si.u = si15[3]; si.v = si15[4];
+    si.dpdx = V3(si15[5], si15[6], si15[7]); si.dpdy = V3(si15[8], si15[9], si15[10]);
+    si.dudx = si15[11]; si.dvdx = si15[12]; si.dudy = si15[13]; si.dvdy = si15[14];
+    Rgb v = tex_eval(d, tex, si);
+    out3[0] = v.c[0]; out3[1] = v.c[1]; out3[2] = v.c[2];
+  });
+}
+// SurfaceInteraction::compute_differentials: in24 = {n, p, dpdu, dpdv, rx_origin, rx_direction, ry_origin, ry_direction},
+// out10 = {dpdx.xyz, dpdy.xyz, dudx, dvdx, dudy, dvdy}
+int oracle_surface_differentials(const double* in24, double* out10) {
+  return guarded([&]() {
+    auto v = [&](int k) { return V3(in24[3 * k], in24[3 * k + 1], in24[3 * k + 2]); };
+    SI si;
+    si.n = v(0); si.p = v(1); si.dpdu = v(2); si.dpdv = v(3);
+    RayDiff rd;
+    rd.has = true; rd.rxo = v(4); rd.rxd = v(5); rd.ryo = v(6); rd.ryd = v(7);
+    compute_differentials(&si, rd);
+    out10[0] = si.dpdx.x; out10[1] = si.dpdx.y; out10[2] = si.dpdx.z; out10[3] = si.dpdy.x; out10[4] = si.dpdy.y; out10[5] = si.dpdy.z;
+    out10[6] = si.dudx; out10[7] = si.dvdx; out10[8] = si.dudy; out10[9] = si.dvdy;
   });
 }
 
@@ -1863,10 +2195,13 @@ int oracle_render_rect(const rrt_scene_desc* d, const int32_t rect[4], double* f
                   smp.get_2d(&f0, &f1); smp.get_2d(&l0, &l1); (void)smp.get_1d();
                   double pfx = (double)x + f0, pfy = (double)y + f1;
                   Ray ray;
-                  double w = cam.generate_ray_differential(pfx, pfy, l0 + 0.5, l1 + 0.5, &ray);
+                  RayDiff rdiff;
+                  double w = cam.generate_ray_differential(pfx, pfy, l0 + 0.5, l1 + 0.5, &ray, &rdiff);
+                  // integrator/mod.rs:94-96 (scales the default-initialised differentials of a dead sample too; unobservable)
+                  if (rdiff.has) scale_differentials(ray, &rdiff, 1.0 / std::sqrt((double)smp.samples_per_pixel()));
                   my_samples++;
                   Rgb L;
-                  if (w > 0.0) { my_rays++; L = integ.li(ray, smp); }
+                  if (w > 0.0) { my_rays++; L = integ.li(ray, rdiff, smp); }
                   if (L.has_nan()) L = Rgb();
                   else if (L.y() < -1e-5) L = Rgb();
                   else if (std::isinf(L.y())) L = Rgb();

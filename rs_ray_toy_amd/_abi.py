@@ -47,7 +47,15 @@ class Material(C.Structure):
     _fields_ = [("type", C.c_int32), ("remap_roughness", C.c_int32), ("kd", C.c_double * 3), ("ks", C.c_double * 3),
                 ("kr", C.c_double * 3), ("eta", C.c_double * 3), ("k", C.c_double * 3), ("sigma", C.c_double),
                 ("roughness", C.c_double), ("u_roughness", C.c_double), ("v_roughness", C.c_double),
-                ("kt", C.c_double * 3), ("reflect", C.c_double * 3), ("transmit", C.c_double * 3), ("index", C.c_double)]
+                ("kt", C.c_double * 3), ("reflect", C.c_double * 3), ("transmit", C.c_double * 3), ("index", C.c_double),
+                ("tex", C.c_int32 * 13), ("pad", C.c_int32)]
+
+
+class Texture(C.Structure):
+    _fields_ = [("type", C.c_int32), ("mapping", C.c_int32), ("child", C.c_int32 * 3), ("aa_none", C.c_int32),
+                ("octaves", C.c_int32), ("pad", C.c_int32), ("fallback", (C.c_double * 3) * 3),
+                ("v", (C.c_double * 3) * 4), ("omega", C.c_double), ("map", C.c_double * 4),
+                ("vs", C.c_double * 3), ("vt", C.c_double * 3), ("world_to_texture", C.c_double * 16)]
 
 
 class Light(C.Structure):
@@ -102,6 +110,7 @@ class SceneDesc(C.Structure):
                 ("xforms", C.POINTER(Xform)), ("n_xforms", C.c_size_t),
                 ("prims", C.POINTER(Prim)), ("n_prims", C.c_size_t),
                 ("materials", C.POINTER(Material)), ("n_materials", C.c_size_t),
+                ("textures", C.POINTER(Texture)), ("n_textures", C.c_size_t),
                 ("lights", C.POINTER(Light)), ("n_lights", C.c_size_t),
                 ("bvh_nodes", C.POINTER(BvhNode)), ("n_bvh_nodes", C.c_size_t),
                 ("prim_order", C.POINTER(C.c_uint32)), ("n_prim_order", C.c_size_t),

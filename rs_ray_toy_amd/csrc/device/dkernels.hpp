@@ -3,6 +3,7 @@
 // slot; live paths are carried between kernels as index queues compacted with wave ballots and one atomic per block (block_push).
 #pragma once
 #include "dmath.hpp"
+#include "dtexture.hpp"
 
 namespace rrtd {
 
@@ -16,7 +17,7 @@ template <typename R> struct ShadeBlock { static constexpr int n = 256; };
 #define RRT_SHADE_BLOCK 256
 #endif
 template <> struct ShadeBlock<float> { static constexpr int n = RRT_SHADE_BLOCK; };
-enum { ERR_SHADING_NORMAL = 1, ERR_STACK = 2, ERR_BETA = 4 };
+enum { ERR_SHADING_NORMAL = 1, ERR_STACK = 2, ERR_BETA = 4, ERR_NULL_BSDF = 8 };
 
 // ------------------------------------------------------------------------------------------------------------
 // BVH traversal: BVHAccel::intersect / intersect_p (bvh.rs:124-236), same node order, same leaf order, every
@@ -183,6 +184,10 @@ template <typename R> RRT_DEV uint32_t skip_plane_of(const SceneDev<R>& s, int s
 // distribution (mean radiance within a few % of the oracle) though not pixel by pixel.
 template <typename R>
 struct SphereSI { V3<R> p, n, wo, sn, sdpdu; };
+// the parts of SurfaceInteraction only textured scenes read: uv, geometric dpdu / dpdv (compute_differentials),
+// shading dndu / dndv (specular ray differentials, integrator/mod.rs:188-196)
+template <typename R>
+struct SurfExt { R u, v; V3<R> dpdu, dpdv, sdndu, sdndv; };
 
 // The rays the sphere code works with: the ray handed to the sphere (instance space, Q16) and the object-space ray.
 template <typename R>
@@ -231,7 +236,7 @@ RRT_DEV bool sphere_prim_hit(const SphereDev<R>& S, V3<R> wo_, V3<R> wd_, R* t_o
 }
 // SurfaceInteraction of an accepted sphere hit (sphere.rs:192-259) from (t, branch)
 template <typename R>
-RRT_DEV void sphere_surface(const SphereDev<R>& S, V3<R> wo_, V3<R> wd_, R th, R branch, SphereSI<R>* si) {
+RRT_DEV void sphere_surface(const SphereDev<R>& S, V3<R> wo_, V3<R> wd_, R th, R branch, SphereSI<R>* si, SurfExt<R>* ext = nullptr) {
   V3<R> ro, rd, oo, od;
   sphere_rays(S, wo_, wd_, &ro, &rd, &oo, &od);
   V3<R> ph;
@@ -251,6 +256,22 @@ RRT_DEV void sphere_surface(const SphereDev<R>& S, V3<R> wo_, V3<R> wd_, R th, R
   si->n = aff_nrm(S.mi, n);
   si->sn = faceforward(nnormalize(aff_nrm(S.mi, n)), si->n);
   si->sdpdu = aff_vec(S.m, dpdu);
+  if (ext) {   // sphere.rs:198-242
+    R phi = atan2(ph.y, ph.x);
+    if (phi < R(0)) phi += R(2) * R(RRT_PI);
+    ext->u = phi / S.phi_max;
+    ext->v = (theta - S.theta_min) / (S.theta_max - S.theta_min);
+    const V3<R> d2pduu = V3<R>(ph.x, ph.y, R(0)) * -S.phi_max * S.phi_max;
+    const V3<R> d2pduv = V3<R>(-sphi, cphi, R(0)) * (S.theta_max - S.theta_min) * ph.z * S.phi_max;
+    const V3<R> d2pdvv = ph * -(S.theta_max - S.theta_min) * (S.theta_max - S.theta_min);
+    const R E = dot(dpdu, dpdu), F = dot(dpdu, dpdv), G = dot(dpdv, dpdv);
+    const R e = dot(n, d2pduu), f = dot(n, d2pduv), g = dot(n, d2pdvv);
+    const R inv_EFG2 = R(1) / (E * G - F * F);
+    const V3<R> dndu = dpdu * ((f * F - e * G) * inv_EFG2) + dpdv * ((e * F - f * E) * inv_EFG2);
+    const V3<R> dndv = dpdu * ((g * F - f * G) * inv_EFG2) + dpdv * ((f * F - g * E) * inv_EFG2);
+    ext->dpdu = aff_vec(S.m, dpdu); ext->dpdv = aff_vec(S.m, dpdv);
+    ext->sdndu = aff_nrm(S.mi, dndu); ext->sdndv = aff_nrm(S.mi, dndv);
+  }
   if (S.has_inst && !S.inst_identity) {   // TransformedPrimitive::intersect primitives.rs:131-136
     si->p = aff_pt(S.im, si->p);
     si->wo = aff_vec(S.im, si->wo);
@@ -258,6 +279,10 @@ RRT_DEV void sphere_surface(const SphereDev<R>& S, V3<R> wo_, V3<R> wd_, R th, R
     si->sn = faceforward(nnormalize(aff_nrm(S.imi, si->sn)), n2);
     si->n = n2;
     si->sdpdu = aff_vec(S.im, si->sdpdu);
+    if (ext) {
+      ext->dpdu = aff_vec(S.im, ext->dpdu); ext->dpdv = aff_vec(S.im, ext->dpdv);
+      ext->sdndu = aff_nrm(S.imi, ext->sdndu); ext->sdndv = aff_nrm(S.imi, ext->sdndv);
+    }
   }
 }
 
@@ -509,16 +534,28 @@ __global__ void __launch_bounds__(kBlock) k_raygen_aux(SceneDev<R> s, Pools<R> p
     slot = p.q_next[i].slot;
     const typename Vec4T<R>::type cs = p.samp[slot];
     const R pfx = cs.x, pfy = cs.y, lx = cs.z, ly = cs.w;
-    RayT<R> aux;
+    RayT<R> aux, auy;
+    R epsx = R(0.05), epsy = R(0.05);
     R wtx = generate_ray(s, pfx + R(0.05), pfy, lx, ly, &aux);
-    if (wtx == R(0)) wtx = generate_ray(s, pfx + R(-0.05), pfy, lx, ly, &aux);
+    if (wtx == R(0)) { epsx = R(-0.05); wtx = generate_ray(s, pfx + R(-0.05), pfy, lx, ly, &aux); }
     R wty = R(0);
     if (wtx != R(0)) {
-      wty = generate_ray(s, pfx, pfy + R(0.05), lx, ly, &aux);
-      if (wty == R(0)) wty = generate_ray(s, pfx, pfy + R(-0.05), lx, ly, &aux);
+      wty = generate_ray(s, pfx, pfy + R(0.05), lx, ly, &auy);
+      if (wty == R(0)) { epsy = R(-0.05); wty = generate_ray(s, pfx, pfy + R(-0.05), lx, ly, &auy); }
     }
     alive = wtx != R(0) && wty != R(0) && p.weight[slot] > R(0);   // `if ray_weight > 0.0` integrator/mod.rs:100
     if (!(wtx != R(0) && wty != R(0))) p.weight[slot] = R(0);
+    if (alive && p.rdx_o) {
+      // rx / ry of generate_ray_differential (camera.rs:597-598, 613-614), then scale_differentials (geometry.rs:1883-1888)
+      const typename Vec4T<R>::type mo = p.nray_o[slot], md = p.nray_d[slot];
+      const V3<R> o(mo.x, mo.y, mo.z), d(md.x, md.y, md.z);
+      V3<R> rxo = o + (aux.o - o) / epsx, rxd = d + (aux.d - d) / epsx;
+      V3<R> ryo = o + (auy.o - o) / epsy, ryd = d + (auy.d - d) / epsy;
+      rxo = o + (rxo - o) * s.diff_scale; ryo = o + (ryo - o) * s.diff_scale;
+      rxd = d + (rxd - d) * s.diff_scale; ryd = d + (ryd - d) * s.diff_scale;
+      p.rdx_o[slot] = mk4<R>(rxo.x, rxo.y, rxo.z, R(0)); p.rdx_d[slot] = mk4<R>(rxd.x, rxd.y, rxd.z, R(0));
+      p.rdy_o[slot] = mk4<R>(ryo.x, ryo.y, ryo.z, R(0)); p.rdy_d[slot] = mk4<R>(ryd.x, ryd.y, ryd.z, R(0));
+    }
   }
   __shared__ uint32_t push_lds[kBlock / 64 + 1];
   const bool enq = alive && enqueue;
@@ -584,12 +621,12 @@ RRT_DEV void spawn_point(V3<R> o, V3<R> d, R t, R u, R v, V3<R> p0, V3<R> p1, V3
 
 // Triangle::intersect's SurfaceInteraction (shape/triangle.rs:267-390) rebuilt from (triangle, t, u, v)
 template <typename R>
-RRT_DEV Surf<R> build_surface(const SceneDev<R>& s, int prim, V3<R> o, V3<R> d, R t, R u, R v) {
+RRT_DEV Surf<R> build_surface(const SceneDev<R>& s, int prim, V3<R> o, V3<R> d, R t, R u, R v, SurfExt<R>* ext = nullptr) {
   Surf<R> si;
   const Tri<R> tr = s.tris[prim];
   if (tr.plane == kSphereMark) {   // u = root branch recorded by the traversal (public API reports 0, 0 for spheres)
     SphereSI<R> ss;
-    sphere_surface(s.spheres[tr.shade], o, d, t, u, &ss);
+    sphere_surface(s.spheres[tr.shade], o, d, t, u, &ss, ext);
     si.ok = true;
     si.p = ss.p; si.p_lo = V3<R>(); si.n = ss.n; si.wo = ss.wo; si.sn = ss.sn; si.sdpdu = ss.sdpdu;
     si.material = tr.material;
@@ -627,6 +664,23 @@ RRT_DEV Surf<R> build_surface(const SceneDev<R>& s, int prim, V3<R> o, V3<R> d, 
   si.sdpdu = dpdu;
   si.material = tr.material;
   si.ok = true;
+  if (ext) {
+    ext->u = uv[0][0] * (R(1) - u - v) + uv[1][0] * u + uv[2][0] * v;
+    ext->v = uv[0][1] * (R(1) - u - v) + uv[1][1] * u + uv[2][1] * v;
+    ext->dpdu = dpdu; ext->dpdv = dpdv;
+    ext->sdndu = ext->sdndv = V3<R>();
+    if (has_n == 1) {   // triangle.rs:351-386
+      const V3<R> dn1 = vn0 - vn2, dn2 = vn1 - vn2;
+      if (degenerate_uv) {
+        const V3<R> dn = cross(vn2 - vn0, vn1 - vn0);
+        if (len2(dn) != R(0)) coordinate_system(dn, &ext->sdndu, &ext->sdndv);
+      } else {
+        const R i_det = R(1) / determinant;
+        ext->sdndu = (dn1 * duv12[1] - dn2 * duv02[1]) * i_det;
+        ext->sdndv = (dn1 * -duv12[0] + dn2 * duv02[0]) * i_det;
+      }
+    }
+  }
   if (has_n == 1) {
     V3<R> ns = vn0 * (R(1) - u - v) + vn1 * u + vn2 * v;
     if (len2(ns) > R(0)) ns = nnormalize(ns); else ns = si.n;
@@ -652,6 +706,24 @@ RRT_DEV void build_bsdf(const SceneDev<R>& s, const Surf<R>& si, Bsdf<R, NL>* b,
   b->ng = si.n;
   b->ts = cross(b->ns, b->ss);
   build_lobes(s.materials[si.material], b, allow_multiple_lobes);
+}
+// textured scenes: compute_differentials (interaction.rs:209), then the material's textures at this hit, then the lobes.
+// Returns false for a Glass / Translucent whose evaluated colours are all black: the reference leaves `bsdf` None there
+// and path.rs:103 underflows `bounces` (constant materials are checked on the host).
+template <typename R, int NL>
+RRT_DEV bool build_bsdf_tex(const SceneDev<R>& s, const Surf<R>& si, const SurfExt<R>& ext, const DiffRay<R>& rd, TexCtx<R>* c,
+                            Bsdf<R, NL>* b, bool allow_multiple_lobes = true) {
+  b->ns = si.sn;
+  b->ss = vnormalize(si.sdpdu);
+  b->ng = si.n;
+  b->ts = cross(b->ns, b->ss);
+  c->p = si.p; c->u = ext.u; c->v = ext.v;
+  compute_differentials(c, si.n, ext.dpdu, ext.dpdv, rd);
+  const Material<R> m = resolve_material(s, s.materials[si.material], *c);
+  build_lobes(m, b, allow_multiple_lobes);
+  if (m.type == 5 && rgb_clamp0(Rgb<R>(m.kr)).is_black() && rgb_clamp0(Rgb<R>(m.kt)).is_black()) return false;
+  if (m.type == 6 && rgb_clamp0(Rgb<R>(m.reflect)).is_black() && rgb_clamp0(Rgb<R>(m.transmit)).is_black()) return false;
+  return true;
 }
 
 // Light::sample_li for PointLight (point.rs:55-77) and DiffuseAreaLight (diffuse.rs:63-79) over
@@ -785,8 +857,10 @@ RRT_DEV uint32_t sample_light_discrete(const SceneDev<R>& s, R u) {
 #ifndef RRT_SHADE_WAVES
 #define RRT_SHADE_WAVES 4
 #endif
-template <typename R, int NL>
-__global__ void __launch_bounds__(ShadeBlock<R>::n) __attribute__((amdgpu_waves_per_eu(RRT_SHADE_WAVES, 8))) k_shade_path(SceneDev<R> s, Pools<R> p) {
+// TEX: the scene has materials that evaluate a texture per hit (SurfExt + ray differentials of the camera ray at bounce 0;
+// `ray = isect.spawn_ray(wi).into()` drops them afterwards, path.rs:163).
+template <typename R, int NL, bool TEX = false>
+__global__ void __launch_bounds__(ShadeBlock<R>::n) __attribute__((amdgpu_waves_per_eu(TEX ? 1 : RRT_SHADE_WAVES, 8))) k_shade_path(SceneDev<R> s, Pools<R> p) {
   __shared__ uint32_t push_lds[ShadeBlock<R>::n / 64 + 1];
   const uint32_t n = p.counters[C_ACTIVE];
   using V4 = typename Vec4T<R>::type;
@@ -812,11 +886,21 @@ __global__ void __launch_bounds__(ShadeBlock<R>::n) __attribute__((amdgpu_waves_
     if (prim >= 0 && (int)bounces < s.max_depth) {
       const V4 ro = p.ray_o[i], rd = p.ray_d[i];
       V3<R> o(ro.x, ro.y, ro.z), d(rd.x, rd.y, rd.z);
-      Surf<R> si = build_surface(s, prim, o, d, h.x, h.z, h.w);
+      SurfExt<R> ext;
+      Surf<R> si = build_surface(s, prim, o, d, h.x, h.z, h.w, TEX ? &ext : nullptr);
       if (!si.ok) { atomicOr(&p.counters[C_ERROR], (uint32_t)ERR_SHADING_NORMAL); }
       else {
         Bsdf<R, NL> bsdf;
-        build_bsdf(s, si, &bsdf);
+        if (TEX) {
+          DiffRay<R> dr;
+          if (bounces == 0) {
+            const V4 a = p.rdx_o[slot], b = p.rdx_d[slot], c = p.rdy_o[slot], e = p.rdy_d[slot];
+            dr.has = true;
+            dr.rxo = V3<R>(a.x, a.y, a.z); dr.rxd = V3<R>(b.x, b.y, b.z); dr.ryo = V3<R>(c.x, c.y, c.z); dr.ryd = V3<R>(e.x, e.y, e.z);
+          }
+          TexCtx<R> tc;
+          if (!build_bsdf_tex(s, si, ext, dr, &tc, &bsdf)) atomicOr(&p.counters[C_ERROR], (uint32_t)ERR_NULL_BSDF);
+        } else build_bsdf(s, si, &bsdf);
         const V4 st_b = p.path[i];
         index = qe.index;
         Rgb<R> beta(st_b.x, st_b.y, st_b.z);
@@ -1029,8 +1113,10 @@ __global__ void __launch_bounds__(ShadeBlock<R>::n) k_shade_specular(SceneDev<R>
 // what that subtree hit. A breadth-first wavefront cannot know that count, so here one thread walks one camera
 // sample's whole tree with an explicit stack (traversal, shading and shadow tests inline; a vertex is re-intersected
 // when its reflect subtree returns instead of keeping its interaction on the stack). A correctness path, not a fast one.
+// TEX: textured materials; every frame then carries its ray's differentials, which specular children inherit
+// (integrator/mod.rs:183-201, 238-292) - the reason textured scenes take this kernel even without transmissive materials.
 constexpr int kTreeMax = 16;
-template <typename R>
+template <typename R, bool TEX>
 __global__ void __launch_bounds__(kBlock) k_direct_tree(SceneDev<R> s, Pools<R> p, unsigned long long* totals) {
   using V4 = typename Vec4T<R>::type;
   const uint32_t i = blockIdx.x * blockDim.x + threadIdx.x;
@@ -1039,13 +1125,18 @@ __global__ void __launch_bounds__(kBlock) k_direct_tree(SceneDev<R> s, Pools<R> 
   const QEnt qe = p.q_active[i];
   const uint32_t index = qe.index;
   uint32_t dim = qe.db & 0xffffu;
-  struct Frame { V3<R> o, d, lo; Rgb<R> beta; int skip, depth, phase; };
+  struct Frame { V3<R> o, d, lo; Rgb<R> beta; int skip, depth, phase; DiffRay<R> dr; };
   Frame st[kTreeMax];
   int sp = 0;
   {
     const V4 ro = p.ray_o[i], rd = p.ray_d[i];
     st[0].o = V3<R>(ro.x, ro.y, ro.z); st[0].d = V3<R>(rd.x, rd.y, rd.z); st[0].lo = V3<R>();
     st[0].beta = Rgb<R>(R(1)); st[0].skip = -1; st[0].depth = 1; st[0].phase = 0;   // li(ray, .., depth = 1)
+    if (TEX) {
+      const V4 a = p.rdx_o[qe.slot], b = p.rdx_d[qe.slot], c = p.rdy_o[qe.slot], e = p.rdy_d[qe.slot];
+      st[0].dr.has = true;
+      st[0].dr.rxo = V3<R>(a.x, a.y, a.z); st[0].dr.rxd = V3<R>(b.x, b.y, b.z); st[0].dr.ryo = V3<R>(c.x, c.y, c.z); st[0].dr.ryd = V3<R>(e.x, e.y, e.z);
+    }
     sp = 1;
   }
   Rgb<R> L;
@@ -1059,10 +1150,15 @@ __global__ void __launch_bounds__(kBlock) k_direct_tree(SceneDev<R> s, Pools<R> 
     { PrivStack stack; hit = traverse_closest(s, r, stack, f.skip, &hu, &hv, &nn, &np); }
     if (f.phase == 0) n_closest++;   // the phase-1 re-intersection is bookkeeping, not a reference query
     if (hit < 0) { sp--; continue; }   // `for light in lights { l += le; return l }`: le = 0
-    const Surf<R> si = build_surface(s, hit, f.o, f.d, r.tmax, hu, hv);
+    SurfExt<R> ext;
+    const Surf<R> si = build_surface(s, hit, f.o, f.d, r.tmax, hu, hv, TEX ? &ext : nullptr);
     if (!si.ok) { atomicOr(&p.counters[C_ERROR], (uint32_t)ERR_SHADING_NORMAL); sp--; continue; }
     Bsdf<R, 4> bsdf;
-    build_bsdf(s, si, &bsdf, false);   // allow_multiple_lobes = false (directlighting.rs:91, intersect_debug.rs:71)
+    TexCtx<R> tc;
+    const DiffRay<R> fdr = f.dr;   // (a child frame may reuse this frame's stack entry below)
+    // allow_multiple_lobes = false (directlighting.rs:91, intersect_debug.rs:71)
+    if (TEX) { if (!build_bsdf_tex(s, si, ext, fdr, &tc, &bsdf, false)) atomicOr(&p.counters[C_ERROR], (uint32_t)ERR_NULL_BSDF); }
+    else build_bsdf(s, si, &bsdf, false);
     const Rgb<R> beta = f.beta;
     const int depth = f.depth;
     uint32_t want = 0;   // lobe class of the continuation to try now
@@ -1110,6 +1206,33 @@ __global__ void __launch_bounds__(kBlock) k_direct_tree(SceneDev<R> s, Pools<R> 
         c.o = si.p; c.lo = si.p_lo; c.d = vnormalize(wi);
         c.beta = beta * (fs * absdot(wi, si.sn) / pdf);
         c.skip = self_prim<R>(hit); c.depth = depth + 1; c.phase = 0;
+        c.dr = DiffRay<R>();
+        if (TEX && fdr.has) {
+          DiffRay<R> cd;
+          cd.has = true;
+          cd.rxo = si.p + tc.dpdx; cd.ryo = si.p + tc.dpdy;
+          V3<R> ns = si.sn;
+          V3<R> dndx = ext.sdndu * tc.dudx + ext.sdndv * tc.dvdx;
+          V3<R> dndy = ext.sdndu * tc.dudy + ext.sdndv * tc.dvdy;
+          const V3<R> wo = si.wo;
+          if (want & BXDF_REFLECTION) {   // integrator/mod.rs:183-201 (the factor is 0.2 there, not pbrt's 2)
+            const V3<R> dwodx = -fdr.rxd - wo, dwody = -fdr.ryd - wo;
+            const R ddndx = dot(dwodx, ns) + dot(wo, dndx), ddndy = dot(dwody, ns) + dot(wo, dndy);
+            cd.rxd = wi - dwodx + (dndx * dot(wo, ns) + ns * ddndx) * R(0.2);
+            cd.ryd = wi - dwody + (dndy * dot(wo, ns) + ns * ddndy) * R(0.2);
+          } else {                        // :238-292
+            R eta = R(1) / bsdf.eta;
+            if (dot(wo, ns) < R(0)) { eta = R(1) / eta; ns = -ns; dndx = -dndx; dndy = -dndy; }
+            const V3<R> dwodx = -fdr.rxd - wo, dwody = -fdr.ryd - wo;
+            const R ddndx = dot(dwodx, ns) + dot(wo, dndx), ddndy = dot(dwody, ns) + dot(wo, dndy);
+            const R mu = eta * dot(wo, ns) - absdot(wi, ns);
+            const R dmudx = ddndx * (eta - (eta * eta * dot(wo, ns)) / absdot(wi, ns));
+            const R dmudy = ddndy * (eta - (eta * eta * dot(wo, ns)) / absdot(wi, ns));
+            cd.rxd = wi - dwodx * eta + (dndx * mu + ns * dmudx);
+            cd.ryd = wi - dwody * eta + (dndy * mu + ns * dmudy);
+          }
+          c.dr = cd;
+        }
       }
     }
   }

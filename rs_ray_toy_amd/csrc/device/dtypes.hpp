@@ -56,6 +56,21 @@ struct Material {
   R kd[3], ks[3], kr[3], eta[3], k[3];
   R sigma, roughness, u_roughness, v_roughness;
   R kt[3], reflect[3], transmit[3], index;   // glass / translucent
+  int32_t tex[13];       // RRT_P_* slot -> SceneDev::textures index evaluated at every hit, -1 = the constant above
+  int32_t has_tex;       // any slot >= 0
+};
+
+// one node of the texture graph (rrt_texture, include/rrt.h): float textures carry their value in all three channels
+template <typename R>
+struct TexDev {
+  int32_t type, mapping, aa_none, octaves;
+  int32_t child[3], pad;
+  R fallback[3][3];
+  R v[4][3];
+  R omega;
+  R map[4];
+  R vs[3], vt[3];
+  R w2t[12];             // world_to_texture rows 0..2 (affine; the loader only composes T * R * S)
 };
 
 template <typename R>
@@ -90,6 +105,8 @@ struct SceneDev {
   const TriShade<R>* shades;
   const SphereDev<R>* spheres;
   const Material<R>* materials;
+  const TexDev<R>* textures;   // texture graph nodes (children before parents)
+  R diff_scale;                // scale_differentials factor 1 / sqrt(samples_per_pixel), integrator/mod.rs:94-96
   const Light<R>* lights;
   const R* light_cdf;          // Distribution1D([1; n]).cdf, n_lights + 1 entries
   uint32_t n_nodes, n_tris, n_lights;
@@ -163,6 +180,9 @@ struct Pools {
   R* weight;             // camera ray weight (0 = dead sample: its L is never read)
   V4* samp;              // camera sample {p_film.x, p_film.y, p_lens.x, p_lens.y}: one 128-bit gather per survivor
   uint32_t* hindex;      // Halton index (raygen -> first queue entry)
+  // camera ray differentials after scale_differentials (scenes with textured materials only, else null):
+  // {rx_origin, -}, {rx_direction, -}, {ry_origin, -}, {ry_direction, -} per slot
+  V4 *rdx_o, *rdx_d, *rdy_o, *rdy_d;
   uint32_t* counters;    // [0] active, [1] next, [2] shadow, [3] camera rays, [4..] stats
 };
 

@@ -122,7 +122,7 @@ class Handle : public HandleBase {
     // launches beat many small ones (whole 1024^2 x 256 spp frame in one pass: 268 M slots x 172 B = 46 GB).
     size_t free_b = 0, total_b = 0;
     HIP_CHECK(hipMemGetInfo(&free_b, &total_b));
-    const size_t per_slot = (12 * 4 + 1) * sizeof(R) + 9 * sizeof(uint32_t);
+    const size_t per_slot = ((tex_depth_ > 0 ? 16 : 12) * 4 + 1) * sizeof(R) + 9 * sizeof(uint32_t);
     max_paths_ = std::max<size_t>(1u << 16, std::min(max_paths_, (free_b / 2) / per_slot));
   }
   ~Handle() override {
@@ -294,7 +294,8 @@ class Handle : public HandleBase {
             launch_closest(nullptr, &counters_.p[C_ACTIVE], 0, count_traversal_, nullptr, nullptr, count_traversal_ ? totals_.p : nullptr, grid);
             tock(e); n_closest_launch++;
             e = tick(3);
-            if (has_translucent_) hipLaunchKernelGGL((k_shade_path<R, 4>), dim3(std::min((uint32_t)((nslots + 255) / 256), 16384u)), dim3(256), 0, st_, scene_, pool_);
+            if (tex_depth_ > 0) hipLaunchKernelGGL((k_shade_path<R, 4, true>), dim3(std::min((uint32_t)((nslots + 255) / 256), 16384u)), dim3(256), 0, st_, scene_, pool_);
+            else if (has_translucent_) hipLaunchKernelGGL((k_shade_path<R, 4>), dim3(std::min((uint32_t)((nslots + 255) / 256), 16384u)), dim3(256), 0, st_, scene_, pool_);
             else hipLaunchKernelGGL((k_shade_path<R, 2>), dim3(std::min(sgrid, 16384u)), dim3(ShadeBlock<R>::n), 0, st_, scene_, pool_);
             tock(e);
             hipLaunchKernelGGL(k_accumulate_shadow, dim3(1), dim3(1), 0, st_, counters_.p, totals_.p);
@@ -305,9 +306,10 @@ class Handle : public HandleBase {
             hipLaunchKernelGGL(k_rotate, dim3(1), dim3(1), 0, st_, counters_.p, 0);
           }
         } else if (integ == RRT_INT_DIRECT || integ == RRT_INT_DEBUG) {
-          if (has_transmissive_) {   // binary recursion with depth-first sampler dimensions: one thread per camera sample
+          if (has_transmissive_ || tex_depth_ > 0) {   // binary recursion with depth-first sampler dimensions / inherited ray differentials: one thread per camera sample
             size_t e2 = tick(3);
-            hipLaunchKernelGGL((k_direct_tree<R>), dim3(grid), dim3(kBlock), 0, st_, scene_, pool_, totals_.p);
+            if (tex_depth_ > 0) hipLaunchKernelGGL((k_direct_tree<R, true>), dim3(grid), dim3(kBlock), 0, st_, scene_, pool_, totals_.p);
+            else hipLaunchKernelGGL((k_direct_tree<R, false>), dim3(grid), dim3(kBlock), 0, st_, scene_, pool_, totals_.p);
             tock(e2);
           } else {
           const bool all = integ == RRT_INT_DEBUG || desc_.integrator.light_strategy == RRT_STRATEGY_ALL;
@@ -372,6 +374,7 @@ class Handle : public HandleBase {
     HIP_CHECK(hipMemcpy(hc, counters_.p, sizeof(hc), hipMemcpyDeviceToHost));
     HIP_CHECK(hipMemcpy(ht, totals_.p, sizeof(ht), hipMemcpyDeviceToHost));
     if (hc[C_ERROR] & ERR_SHADING_NORMAL) throw PanicError("primitives.rs:66 assert!(dot3(&si.ist.n, &si.shading.n) >= 0.0) (vertex normals oppose the winding, Q14)");
+    if (hc[C_ERROR] & ERR_NULL_BSDF) throw PanicError("glass.rs:70 / translucent.rs:66 null BSDF (textures evaluate to black): path.rs:103 `bounces -= 1` underflows");
     if (hc[C_ERROR] & ERR_BETA) throw PanicError("path.rs:146 assert!(beta.y() > 0.0 && beta.y().is_finite())");
     if (stats) {
       memset(stats, 0, sizeof(*stats));
@@ -422,6 +425,8 @@ class Handle : public HandleBase {
   DevBuf<TriShade<R>> shades_;
   DevBuf<SphereDev<R>> spheres_;
   DevBuf<Material<R>> materials_;
+  DevBuf<TexDev<R>> textures_;
+  int tex_depth_ = 0;          // deepest texture graph some primitive's material evaluates (0 = no textured material in use)
   DevBuf<Light<R>> lights_;
   DevBuf<R> light_cdf_;
   DevBuf<LensElem<R>> lens_;
@@ -451,6 +456,12 @@ class Handle : public HandleBase {
     }
   }
   void check_renderable() {
+    if (tex_depth_ > kTexDepth) throw UnsupportedError("texture graphs deeper than " + std::to_string(kTexDepth) + " levels");
+    if (tex_depth_ > 0 && (desc_.integrator.type == RRT_INT_DIRECT || desc_.integrator.type == RRT_INT_DEBUG)) {
+      // specular children inherit ray differentials (integrator/mod.rs:183-201, 238-292): the per-sample recursion kernel carries them
+      if (desc_.integrator.max_depth > kTreeMax) throw UnsupportedError("DirectLighting / Debug with textured materials: max_depth above 16");
+      if (deep_) throw UnsupportedError("DirectLighting / Debug with textured materials on a BVH deeper than 64");
+    }
     if (has_transmissive_ && (desc_.integrator.type == RRT_INT_DIRECT || desc_.integrator.type == RRT_INT_DEBUG)) {
       if (desc_.integrator.max_depth > kTreeMax) throw UnsupportedError("DirectLighting / Debug with transmissive materials: max_depth above 16");
       if (deep_) throw UnsupportedError("DirectLighting / Debug with transmissive materials on a BVH deeper than 64");
@@ -581,6 +592,40 @@ class Handle : public HandleBase {
       o.sigma = (R)m.sigma; o.roughness = (R)m.roughness; o.u_roughness = (R)m.u_roughness; o.v_roughness = (R)m.v_roughness;
       for (int k = 0; k < 3; k++) { o.kt[k] = (R)m.kt[k]; o.reflect[k] = (R)m.reflect[k]; o.transmit[k] = (R)m.transmit[k]; }
       o.index = (R)m.index;
+      o.has_tex = 0;
+      for (int k = 0; k < RRT_P_COUNT; k++) {
+        o.tex[k] = m.tex[k];
+        if (m.tex[k] >= 0) {
+          if ((size_t)m.tex[k] >= d->n_textures) throw std::invalid_argument("material texture index out of range");
+          o.has_tex = 1;
+        }
+      }
+    }
+    // texture graph: children precede parents (include/rrt.h); evaluation recurses at most kTexDepth levels
+    std::vector<TexDev<R>> texs(d->n_textures);
+    {
+      std::vector<int> depth(d->n_textures, 1);
+      for (size_t i = 0; i < d->n_textures; i++) {
+        const rrt_texture& t = d->textures[i];
+        TexDev<R>& o = texs[i];
+        memset(&o, 0, sizeof(o));
+        o.type = t.type; o.mapping = t.mapping; o.aa_none = t.aa_none; o.octaves = t.octaves;
+        for (int k = 0; k < 3; k++) {
+          o.child[k] = t.child[k];
+          if (t.child[k] >= (int32_t)i) throw std::invalid_argument("texture child index must precede its parent");
+          if (t.child[k] >= 0) depth[i] = std::max(depth[i], depth[t.child[k]] + 1);
+          for (int c = 0; c < 3; c++) o.fallback[k][c] = (R)t.fallback[k][c];
+        }
+        for (int k = 0; k < 4; k++) { for (int c = 0; c < 3; c++) o.v[k][c] = (R)t.v[k][c]; o.map[k] = (R)t.map[k]; }
+        o.omega = (R)t.omega;
+        for (int c = 0; c < 3; c++) { o.vs[c] = (R)t.vs[c]; o.vt[c] = (R)t.vt[c]; }
+        for (int k = 0; k < 12; k++) o.w2t[k] = (R)t.world_to_texture[k];
+      }
+      tex_depth_ = 0;
+      for (size_t i = 0; i < d->n_prims; i++) {
+        const rrt_material& m = d->materials[d->prims[i].material];
+        for (int k = 0; k < RRT_P_COUNT; k++) if (m.tex[k] >= 0) tex_depth_ = std::max(tex_depth_, depth[m.tex[k]]);
+      }
     }
     std::vector<Light<R>> lights(d->n_lights);
     for (size_t i = 0; i < d->n_lights; i++) {
@@ -637,13 +682,13 @@ class Handle : public HandleBase {
     if (d->sampler.type == RRT_SAMPLER_HALTON && d->sampler.perms) perms.assign(d->sampler.perms, d->sampler.perms + d->sampler.n_perms);
 
     nodes_.upload(nodes, st_); tris_.upload(tris, st_); build_pairs(nodes, tris.size()); shades_.upload(shades, st_); spheres_.upload(spheres, st_);
-    materials_.upload(mats, st_);
+    materials_.upload(mats, st_); textures_.upload(texs, st_);
     if (!spheres.empty()) pairs_ok_ = false;   // the fp32 pair-node kernels are triangle-only: sphere scenes use the generic kernels
     lights_.upload(lights, st_); light_cdf_.upload(cdf_r, st_); lens_.upload(lens, st_); hdims_.upload(hd, st_); perms_.upload(perms, st_);
     HIP_CHECK(hipStreamSynchronize(st_));  // host vectors go out of scope below
 
     SceneDev<R>& s = scene_;
-    s.nodes = nodes_.p; s.tris = tris_.p; s.shades = shades_.p; s.spheres = spheres_.p; s.materials = materials_.p; s.lights = lights_.p; s.light_cdf = light_cdf_.p;
+    s.nodes = nodes_.p; s.tris = tris_.p; s.shades = shades_.p; s.spheres = spheres_.p; s.materials = materials_.p; s.textures = textures_.p; s.lights = lights_.p; s.light_cdf = light_cdf_.p;
     s.n_nodes = (uint32_t)d->n_bvh_nodes; s.n_tris = (uint32_t)d->n_prim_order; s.n_lights = (uint32_t)nl;
     s.light_pick_pdf = (nl && func_int > 0.0) ? (R)(1.0 / (func_int * (double)nl)) : (R)0;
     s.stack_depth = d->bvh_depth + 1;
@@ -657,6 +702,7 @@ class Handle : public HandleBase {
     for (int k = 0; k < 4; k++) s.extent[k] = (R)d->film.physical_extent[k];
     s.max_sample_luminance = std::isinf(d->film.max_sample_luminance) ? Const<R>::inf : (R)d->film.max_sample_luminance;
     s.hdims = hdims_.p; s.perms = perms_.p;
+    s.diff_scale = (R)(1.0 / std::sqrt((double)d->sampler.samples_per_pixel));
     s.nsamp = (uint32_t)d->sampler.samples_per_pixel; s.sample_at_center = (uint32_t)d->sampler.sample_at_center;
     s.base_exp0 = (uint32_t)d->sampler.base_exponents[0]; s.base_exp1 = (uint32_t)d->sampler.base_exponents[1];
     s.base_scale0 = (uint32_t)d->sampler.base_scales[0]; s.base_scale1 = (uint32_t)d->sampler.base_scales[1];
@@ -697,7 +743,7 @@ class Handle : public HandleBase {
     HIP_CHECK(hipStreamSynchronize(st_));
     cap_ = n;
     using V4 = typename Vec4T<R>::type;
-    const size_t NV = 12, NR = 1, NU = 9;   // 4-word records, reals, u32 per slot
+    const size_t NV = tex_depth_ > 0 ? 16 : 12, NR = 1, NU = 9;   // 4-word records (+4: camera ray differentials), reals, u32 per slot
     vpool_.alloc(NV * cap_);
     rpool_.alloc(NR * cap_);
     upool_.alloc(NU * cap_);
@@ -706,6 +752,8 @@ class Handle : public HandleBase {
     auto nv = [&]() { V4* x = v; v += cap_; return x; };
     p.ray_o = nv(); p.ray_d = nv(); p.nray_o = nv(); p.nray_d = nv(); p.hit = nv();
     p.sray_o = nv(); p.sray_d = nv(); p.sld = nv(); p.samp = nv(); p.path = nv(); p.npath = nv(); p.L = nv();
+    p.rdx_o = p.rdx_d = p.rdy_o = p.rdy_d = nullptr;
+    if (tex_depth_ > 0) { p.rdx_o = nv(); p.rdx_d = nv(); p.rdy_o = nv(); p.rdy_d = nv(); }
     R* r = rpool_.p;
     auto nr = [&]() { R* x = r; r += cap_; return x; };
     p.weight = nr();
@@ -754,7 +802,7 @@ class Handle : public HandleBase {
   // camera ray generation: persistent-thread kernel in fp32, two-stage (main trace, compaction, auxiliary traces) in f64
   void launch_raygen(const PassDesc& pd, uint32_t grid, double* dims_out, int enqueue) {
     if constexpr (std::is_same<R, float>::value) {
-      if (raygen_pt_ && scene_.n_lens <= 32 && scene_.sampler_type == RRT_SAMPLER_HALTON) {
+      if (raygen_pt_ && scene_.n_lens <= 32 && scene_.sampler_type == RRT_SAMPLER_HALTON && tex_depth_ == 0) {   // textured scenes: the generic raygen keeps the auxiliary rays (differentials)
         if (rg_grid_ == 0) {
           int per_cu = 0, cus = 0;
           HIP_CHECK(hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, dev_));

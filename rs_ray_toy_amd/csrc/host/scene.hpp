@@ -15,6 +15,7 @@ struct SceneData {
   std::vector<rrt_xform> xforms;
   std::vector<rrt_prim> prims;
   std::vector<rrt_material> materials;
+  std::vector<rrt_texture> textures;
   std::vector<rrt_light> lights;
   std::vector<rrt_bvh_node> bvh_nodes;
   std::vector<uint32_t> prim_order;

@@ -25,6 +25,7 @@ void SceneData::finalize() {
   desc.xforms = xforms.data(); desc.n_xforms = xforms.size();
   desc.prims = prims.data(); desc.n_prims = prims.size();
   desc.materials = materials.data(); desc.n_materials = materials.size();
+  desc.textures = textures.data(); desc.n_textures = textures.size();
   desc.lights = lights.data(); desc.n_lights = lights.size();
   desc.bvh_nodes = bvh_nodes.data(); desc.n_bvh_nodes = bvh_nodes.size();
   desc.prim_order = prim_order.data(); desc.n_prim_order = prim_order.size();
@@ -101,10 +102,12 @@ Rgb make_spectrum(const Json& cfg, const char* key, double dflt) {
   return rgb1(dflt);
 }
 
-// Texture tables: only constant-valued textures are in scope. A declared texture is
-// recorded as {exists, constant?}; using a non-constant one from a material is RRT_EUNSUP.
-struct TexF { bool is_const = false; double v = 0; std::string type; };
-struct TexC { bool is_const = false; Rgb v{{0, 0, 0}}; std::string type; };
+// Texture tables (make_textures renderprocess.rs:298-515). Every declared texture becomes a node of the flat graph
+// in rrt_scene_desc.textures; `node` < 0 marks one that cannot be represented (ImageTexture, or a graph that
+// contains one): using it from a material is RRT_EUNSUP, declaring it is not. `is_const` textures (the value is the
+// same at every hit) are folded into the material's constant, as before.
+struct TexF { bool is_const = false; double v = 0; std::string type; int node = -1; };
+struct TexC { bool is_const = false; Rgb v{{0, 0, 0}}; std::string type; int node = -1; };
 
 struct Loader {
   SceneData& s;
@@ -113,6 +116,7 @@ struct Loader {
   uint64_t seed;
   std::map<std::string, TexF> float_tex;
   std::map<std::string, TexC> rgb_tex;
+  std::vector<bool> tex_ok;   // per s.textures entry: representable (no ImageTexture in its graph)
   struct MatEntry { int index = -1; std::string unsupported_type; };
   std::map<std::string, MatEntry> materials;
   struct MeshEntry { uint32_t first_tri = 0, n_tris = 0; };
@@ -127,92 +131,191 @@ struct Loader {
     return root_dir + "/" + t;
   }
 
-  // make_textures renderprocess.rs:298-560 (value model only)
+  // make_texture_mapping_2d renderprocess.rs:561-610 (defaults du = dv = 1.0 as read there)
+  void make_mapping_2d(const Json& tc, const Xf& to_world, rrt_texture* t) {
+    const Json* mc = tc.get("mapping");
+    t->mapping = RRT_MAP_UV;
+    t->map[0] = 1.0; t->map[1] = 1.0; t->map[2] = 0.0; t->map[3] = 0.0;   // UVMapping2D::new(1, 1, 0, 0) when "mapping" is absent :608
+    if (!mc) return;
+    std::string type = read_string(*mc, "mapping", "uv");
+    if (type == "uv") {
+      t->map[0] = read_f64(*mc, "su", 1.0); t->map[1] = read_f64(*mc, "sv", 1.0);
+      t->map[2] = read_f64(*mc, "du", 1.0); t->map[3] = read_f64(*mc, "dv", 1.0);
+    } else if (type == "spherical" || type == "cylindrical") {
+      t->mapping = type == "spherical" ? RRT_MAP_SPHERICAL : RRT_MAP_CYLINDRICAL;
+      Xf inv = xf_inverse(to_world);
+      for (int k = 0; k < 16; k++) t->world_to_texture[k] = inv.m.m[k / 4][k % 4];
+    } else if (type == "planar") {
+      t->mapping = RRT_MAP_PLANAR;
+      V3 v1 = fetch_v3(*mc, "v1", {1, 0, 0}), v2 = fetch_v3(*mc, "v2", {0, 1, 0});
+      t->vs[0] = v1.x; t->vs[1] = v1.y; t->vs[2] = v1.z; t->vt[0] = v2.x; t->vt[1] = v2.y; t->vt[2] = v2.z;
+      t->map[0] = read_f64(*mc, "udelta", 0.0); t->map[1] = read_f64(*mc, "vdelta", 0.0);
+    } else throw Panic("renderprocess.rs:601 Unsupported Mapping Type " + type);
+  }
+  void identity_mapping_3d(const Xf& to_world, rrt_texture* t) {   // IdentityMapping3D::new(to_world): not inverted
+    t->mapping = RRT_MAP_IDENTITY3D;
+    for (int k = 0; k < 16; k++) t->world_to_texture[k] = to_world.m.m[k / 4][k % 4];
+  }
+  int add_texture(const rrt_texture& t, bool representable) {
+    s.textures.push_back(t);
+    tex_ok.push_back(representable);
+    return (int)s.textures.size() - 1;
+  }
+
+  // make_textures renderprocess.rs:298-515
   void make_textures(const Json& cfg) {
     const Json* ft = cfg.get("float_texture");
     if (ft && ft->kind == Json::Arr) {
       for (auto& tc : ft->arr) {
+        Xf to_world = make_to_world(tc);
         std::string type = read_string(tc, "texture_type", ""), name = read_string(tc, "texture_name", "DefaultTextureName");
         TexF t; t.type = type;
-        auto fallback = [&](const std::string& n, double d) { auto it = float_tex.find(n); return it != float_tex.end() ? it->second : TexF{true, d, "Constant"}; };
+        rrt_texture n{};
+        n.child[0] = n.child[1] = n.child[2] = -1;
+        bool ok = true;
+        auto fallback = [&](int slot, const std::string& nm, double d) {
+          auto it = float_tex.find(nm);
+          TexF r = it != float_tex.end() ? it->second : TexF{true, d, "Constant", -1};
+          for (int k = 0; k < 3; k++) n.fallback[slot][k] = r.v;
+          if (it != float_tex.end()) { n.child[slot] = r.node; if (r.node < 0 || !tex_ok[r.node]) ok = false; }
+          return r;
+        };
         if (type == "MixTexture") {
-          TexF t1 = fallback(read_string(tc, "t1", "ErrorTextureName"), 0.0), t2 = fallback(read_string(tc, "t2", "ErrorTextureName"), 1.0);
-          TexF am = fallback(read_string(tc, "t2", "ErrorTextureName"), 0.5);  // reads "t2" for amount, :318
-          if (t1.is_const && t2.is_const && am.is_const) { t.is_const = true; t.v = (1.0 - am.v) * t1.v + am.v * t2.v; }
+          n.type = RRT_TEX_MIX;
+          TexF t1 = fallback(0, read_string(tc, "t1", "ErrorTextureName"), 0.0), t2 = fallback(1, read_string(tc, "t2", "ErrorTextureName"), 1.0);
+          TexF am = fallback(2, read_string(tc, "t2", "ErrorTextureName"), 0.5);  // reads "t2" for amount, :318
+          if (t1.is_const && t2.is_const && am.is_const) { t.is_const = true; t.v = t1.v * (1.0 - am.v) + t2.v * am.v; }
         } else if (type == "BilerpTexture") {
+          n.type = RRT_TEX_BILERP;
+          make_mapping_2d(tc, to_world, &n);
           double v00 = read_f64(tc, "v00", 0.0), v01 = read_f64(tc, "v01", 1.0), v10 = read_f64(tc, "v01", 0.0), v11 = read_f64(tc, "v01", 1.0);
+          for (int k = 0; k < 3; k++) { n.v[0][k] = v00; n.v[1][k] = v01; n.v[2][k] = v10; n.v[3][k] = v11; }
           if (v00 == v01 && v01 == v10 && v10 == v11) { t.is_const = true; t.v = v00; }
         } else if (type == "CheckerBoardTexture") {
           int64_t dim = read_i64(tc, "dimension", 2);
           if (dim != 2 && dim != 3) { warn(std::to_string(dim) + " dimensional checkerboard texture not supported"); continue; }
+          fallback(0, read_string(tc, "t1", "ErrorTextureName"), 1.0); fallback(1, read_string(tc, "t2", "ErrorTextureName"), 0.0);
+          if (dim == 2) {
+            n.type = RRT_TEX_CHECKER2D;
+            make_mapping_2d(tc, to_world, &n);
+            n.aa_none = read_string(tc, "aamode", "closedform") == "none";
+          } else { n.type = RRT_TEX_CHECKER3D; identity_mapping_3d(to_world, &n); }
         } else if (type == "ScaleTexture") {
-          TexF t1 = fallback(read_string(tc, "t1", "ErrorTextureName"), 1.0), t2 = fallback(read_string(tc, "t2", "ErrorTextureName"), 1.0);
+          n.type = RRT_TEX_SCALE;
+          TexF t1 = fallback(0, read_string(tc, "t1", "ErrorTextureName"), 1.0), t2 = fallback(1, read_string(tc, "t2", "ErrorTextureName"), 1.0);
           if (t1.is_const && t2.is_const) { t.is_const = true; t.v = t1.v * t2.v; }
-        } else if (type == "WindyTexture" || type == "WrinkledTexture") {
+        } else if (type == "WindyTexture") {
+          n.type = RRT_TEX_WINDY; identity_mapping_3d(to_world, &n);
+        } else if (type == "WrinkledTexture") {
+          n.type = RRT_TEX_WRINKLED; identity_mapping_3d(to_world, &n);
+          n.octaves = (int32_t)read_i64(tc, "octaves", 8); n.omega = read_f64(tc, "omega", 0.5);
         } else { warn("Unsupported Texture Type " + type); continue; }
+        t.node = add_texture(n, ok);
         float_tex[name] = t;
       }
     }
     const Json* rt = cfg.get("rgb_texture");
     if (rt && rt->kind == Json::Arr) {
       for (auto& tc : rt->arr) {
+        Xf to_world = make_to_world(tc);
         std::string type = read_string(tc, "texture_type", ""), name = read_string(tc, "texture_name", "DefaultTextureName");
         TexC t; t.type = type;
-        auto fallback = [&](const std::string& n, double d) { auto it = rgb_tex.find(n); return it != rgb_tex.end() ? it->second : TexC{true, rgb1(d), "Constant"}; };
+        rrt_texture n{};
+        n.child[0] = n.child[1] = n.child[2] = -1;
+        bool ok = true;
+        auto fallback = [&](int slot, const std::string& nm, double d) {
+          auto it = rgb_tex.find(nm);
+          TexC r = it != rgb_tex.end() ? it->second : TexC{true, rgb1(d), "Constant", -1};
+          for (int k = 0; k < 3; k++) n.fallback[slot][k] = r.v.c[k];
+          if (it != rgb_tex.end()) { n.child[slot] = r.node; if (r.node < 0 || !tex_ok[r.node]) ok = false; }
+          return r;
+        };
         if (type == "MixTexture") {
-          TexC t1 = fallback(read_string(tc, "t1", "ErrorTextureName"), 0.0), t2 = fallback(read_string(tc, "t2", "ErrorTextureName"), 1.0);
-          auto it = float_tex.find(read_string(tc, "t2", "ErrorTextureName"));
-          TexF am = it != float_tex.end() ? it->second : TexF{true, 0.5, "Constant"};
+          n.type = RRT_TEX_MIX;
+          TexC t1 = fallback(0, read_string(tc, "t1", "ErrorTextureName"), 0.0), t2 = fallback(1, read_string(tc, "t2", "ErrorTextureName"), 1.0);
+          auto it = float_tex.find(read_string(tc, "t2", "ErrorTextureName"));   // amount: a *float* texture named by "t2", :412-414
+          TexF am = it != float_tex.end() ? it->second : TexF{true, 0.5, "Constant", -1};
+          for (int k = 0; k < 3; k++) n.fallback[2][k] = am.v;
+          if (it != float_tex.end()) { n.child[2] = am.node; if (am.node < 0 || !tex_ok[am.node]) ok = false; }
           if (t1.is_const && t2.is_const && am.is_const) { t.is_const = true; for (int k = 0; k < 3; k++) t.v.c[k] = t1.v.c[k] * (1.0 - am.v) + t2.v.c[k] * am.v; }
+        } else if (type == "UVTexture") {
+          n.type = RRT_TEX_UV;
+          make_mapping_2d(tc, to_world, &n);
         } else if (type == "BilerpTexture") {
+          n.type = RRT_TEX_BILERP;
+          make_mapping_2d(tc, to_world, &n);
           Rgb v00 = make_spectrum(tc, "v00", 0.0), v01 = make_spectrum(tc, "v01", 1.0), v10 = make_spectrum(tc, "v01", 0.0), v11 = make_spectrum(tc, "v01", 1.0);
           bool same = true;
-          for (int k = 0; k < 3; k++) same = same && v00.c[k] == v01.c[k] && v01.c[k] == v10.c[k] && v10.c[k] == v11.c[k];
+          for (int k = 0; k < 3; k++) {
+            n.v[0][k] = v00.c[k]; n.v[1][k] = v01.c[k]; n.v[2][k] = v10.c[k]; n.v[3][k] = v11.c[k];
+            same = same && v00.c[k] == v01.c[k] && v01.c[k] == v10.c[k] && v10.c[k] == v11.c[k];
+          }
           if (same) { t.is_const = true; t.v = v00; }
         } else if (type == "ScaleTexture") {
-          TexC t1 = fallback(read_string(tc, "t1", "ErrorTextureName"), 1.0), t2 = fallback(read_string(tc, "t2", "ErrorTextureName"), 1.0);
+          n.type = RRT_TEX_SCALE;
+          TexC t1 = fallback(0, read_string(tc, "t1", "ErrorTextureName"), 1.0), t2 = fallback(1, read_string(tc, "t2", "ErrorTextureName"), 1.0);
           if (t1.is_const && t2.is_const) { t.is_const = true; for (int k = 0; k < 3; k++) t.v.c[k] = t1.v.c[k] * t2.v.c[k]; }
         } else if (type == "CheckerBoardTexture") {
           int64_t dim = read_i64(tc, "dimension", 2);
           if (dim != 2 && dim != 3) { warn(std::to_string(dim) + " dimensional checkerboard texture not supported"); continue; }
+          fallback(0, read_string(tc, "t1", "ErrorTextureName"), 1.0); fallback(1, read_string(tc, "t2", "ErrorTextureName"), 0.0);
+          if (dim == 2) {
+            n.type = RRT_TEX_CHECKER2D;
+            make_mapping_2d(tc, to_world, &n);
+            n.aa_none = read_string(tc, "aamode", "closedform") == "none";
+          } else { n.type = RRT_TEX_CHECKER3D; identity_mapping_3d(to_world, &n); }
         } else if (type == "ImageTexture") {
-          std::ifstream probe(asset_path(read_string(tc, "filename", "")));
+          std::ifstream probe(asset_path(read_string(tc, "filename", "DefaultTexture")));
           if (!probe) { warn("ImageTexture " + name + ": image not loadable, texture not registered"); continue; }  // load_image Err -> not inserted :428-436
-        } else if (type == "UVTexture" || type == "WindyTexture" || type == "WrinkledTexture") {
+          ok = false;   // would need the image crate's decoders + MIPMap (mipmap.rs): refused where a material uses it
+        } else if (type == "WindyTexture") {
+          n.type = RRT_TEX_WINDY; identity_mapping_3d(to_world, &n);
+        } else if (type == "WrinkledTexture") {
+          n.type = RRT_TEX_WRINKLED; identity_mapping_3d(to_world, &n);
+          n.octaves = (int32_t)read_i64(tc, "octaves", 8); n.omega = read_f64(tc, "omega", 0.5);
         } else { warn("Unsupported Texture Type " + type); continue; }
+        t.node = add_texture(n, ok);
         rgb_tex[name] = t;
       }
     }
   }
 
-  // fetch_rgb_texture renderprocess.rs:644-661
-  Rgb fetch_rgb(const Json& mc, const char* key, Rgb dflt, const std::string& mat) {
+  // fetch_rgb_texture renderprocess.rs:644-661. `slot` = RRT_P_*: a non-constant texture is recorded in cur->tex[slot]
+  // (the returned constant is then unused).
+  rrt_material* cur = nullptr;
+  void bind_texture(int node, const std::string& type, const std::string& tname, int slot, const char* key, const std::string& mat) {
+    if (node < 0 || !tex_ok[node])
+      throw Unsupported("material '" + mat + "' key '" + key + "' uses " + type + " '" + tname + "': ImageTexture (image decoders + MIPMap) is out of scope, SURVEY §8f rank 4");
+    cur->tex[slot] = node;
+  }
+  Rgb fetch_rgb(const Json& mc, const char* key, Rgb dflt, const std::string& mat, int slot) {
     const Json* v = mc.get(key);
     if (v && v->kind == Json::Str) {
       auto it = rgb_tex.find(v->str);
       if (it != rgb_tex.end()) {
-        if (!it->second.is_const)
-          throw Unsupported("material '" + mat + "' key '" + key + "' uses non-constant " + it->second.type + " '" + v->str + "' (textures other than constant-valued ones are out of scope, SURVEY §2 row 34)");
+        if (!it->second.is_const) bind_texture(it->second.node, it->second.type, v->str, slot, key, mat);
         return it->second.v;
       }
     }
     return dflt;
   }
   // fetch_float_texture :612-625 (HashMap index panics when the name is missing)
-  double fetch_float(const Json& mc, const char* key, double dflt, const std::string& mat) {
+  double fetch_float(const Json& mc, const char* key, double dflt, const std::string& mat, int slot) {
     const Json* v = mc.get(key);
     if (v && v->kind == Json::Str) {
       auto it = float_tex.find(v->str);
       if (it == float_tex.end()) throw Panic("renderprocess.rs:619 float_texture[\"" + v->str + "\"] missing (material " + mat + ")");
-      if (!it->second.is_const)
-        throw Unsupported("material '" + mat + "' key '" + key + "' uses non-constant " + it->second.type + " '" + v->str + "' (out of scope, SURVEY §2 row 34)");
+      if (!it->second.is_const) {
+        if (slot < 0) throw Unsupported("material '" + mat + "': bump_map is out of scope (Material::bump, material/mod.rs:22-62)");
+        bind_texture(it->second.node, it->second.type, v->str, slot, key, mat);
+      }
       return it->second.v;
     }
     return dflt;
   }
-  bool fetch_float_opt(const Json& mc, const char* key, double* out, const std::string& mat) {  // :627-642
+  bool fetch_float_opt(const Json& mc, const char* key, double* out, const std::string& mat, int slot) {  // :627-642
     const Json* v = mc.get(key);
-    if (v && v->kind == Json::Str) { *out = fetch_float(mc, key, 0.0, mat); return true; }
+    if (v && v->kind == Json::Str) { *out = fetch_float(mc, key, 0.0, mat, slot); return true; }
     return false;
   }
 
@@ -227,56 +330,60 @@ struct Loader {
     for (auto& mc : arr->arr) {
       std::string type = read_string(mc, "material_type", ""), name = read_string(mc, "material_name", "DefaultMaterialName");
       rrt_material m{};
+      for (int k = 0; k < RRT_P_COUNT; k++) m.tex[k] = -1;
+      cur = &m;
       double bump;
       auto no_bump = [&]() {
-        if (fetch_float_opt(mc, "bump_map", &bump, name)) throw Unsupported("material '" + name + "': bump_map is out of scope (Material::bump, material/mod.rs:22-62)");
+        if (fetch_float_opt(mc, "bump_map", &bump, name, -1)) throw Unsupported("material '" + name + "': bump_map is out of scope (Material::bump, material/mod.rs:22-62)");
       };
       auto put = [&](const Rgb& r, double* dst) { for (int k = 0; k < 3; k++) dst[k] = r.c[k]; };
       if (type == "MatteMaterial") {
         m.type = RRT_MAT_MATTE;
-        put(fetch_rgb(mc, "kd", rgb1(0.5), name), m.kd);
-        m.sigma = fetch_float(mc, "sigma", 0.0, name);
+        put(fetch_rgb(mc, "kd", rgb1(0.5), name, RRT_P_KD), m.kd);
+        m.sigma = fetch_float(mc, "sigma", 0.0, name, RRT_P_SIGMA);
         no_bump();
       } else if (type == "PlasticMaterial") {
         m.type = RRT_MAT_PLASTIC;
-        put(fetch_rgb(mc, "kd", rgb1(0.25), name), m.kd);
-        put(fetch_rgb(mc, "ks", rgb1(0.25), name), m.ks);
-        m.roughness = fetch_float(mc, "roughness", 0.1, name);
+        put(fetch_rgb(mc, "kd", rgb1(0.25), name, RRT_P_KD), m.kd);
+        put(fetch_rgb(mc, "ks", rgb1(0.25), name, RRT_P_KS), m.ks);
+        m.roughness = fetch_float(mc, "roughness", 0.1, name, RRT_P_ROUGHNESS);
         no_bump();
         m.remap_roughness = read_bool(mc, "remap_roughness", false);
       } else if (type == "MetalMaterial") {
         m.type = RRT_MAT_METAL;
-        put(fetch_rgb(mc, "eta", copper_n, name), m.eta);
-        put(fetch_rgb(mc, "k", copper_k, name), m.k);
-        m.roughness = fetch_float(mc, "roughness", 0.01, name);
+        put(fetch_rgb(mc, "eta", copper_n, name, RRT_P_ETA), m.eta);
+        put(fetch_rgb(mc, "k", copper_k, name, RRT_P_K), m.k);
+        m.roughness = fetch_float(mc, "roughness", 0.01, name, RRT_P_ROUGHNESS);
+        // metal.rs:60-71: u / v roughness evaluate their own texture when the key is present, else `roughness`
         m.u_roughness = m.roughness; m.v_roughness = m.roughness;
-        double r;
-        if (fetch_float_opt(mc, "u_roughness", &r, name)) m.u_roughness = r;
-        if (fetch_float_opt(mc, "v_roughness", &r, name)) m.v_roughness = r;
+        m.tex[RRT_P_UROUGHNESS] = m.tex[RRT_P_VROUGHNESS] = m.tex[RRT_P_ROUGHNESS];
+        double r = 0.0;
+        if (mc.get("u_roughness") && mc.get("u_roughness")->kind == Json::Str) { m.tex[RRT_P_UROUGHNESS] = -1; fetch_float_opt(mc, "u_roughness", &r, name, RRT_P_UROUGHNESS); m.u_roughness = r; }
+        if (mc.get("v_roughness") && mc.get("v_roughness")->kind == Json::Str) { m.tex[RRT_P_VROUGHNESS] = -1; fetch_float_opt(mc, "v_roughness", &r, name, RRT_P_VROUGHNESS); m.v_roughness = r; }
         no_bump();
         m.remap_roughness = read_bool(mc, "remap_roughness", false);
       } else if (type == "MirrorMaterial") {
         m.type = RRT_MAT_MIRROR;
-        put(fetch_rgb(mc, "kr", rgb1(0.9), name), m.kr);
+        put(fetch_rgb(mc, "kr", rgb1(0.9), name, RRT_P_KR), m.kr);
         no_bump();
       } else if (type == "Debug") {
         m.type = RRT_MAT_DEBUG;
       } else if (type == "GlassMaterial") {   // renderprocess.rs:772-798
         m.type = RRT_MAT_GLASS;
-        put(fetch_rgb(mc, "kr", rgb1(1.0), name), m.kr);
-        put(fetch_rgb(mc, "kt", rgb1(1.0), name), m.kt);
-        m.index = fetch_float(mc, "eta", 1.5, name);
-        m.u_roughness = fetch_float(mc, "u_roughness", 0.0, name);
-        m.v_roughness = fetch_float(mc, "v_roughness", 0.0, name);
+        put(fetch_rgb(mc, "kr", rgb1(1.0), name, RRT_P_KR), m.kr);
+        put(fetch_rgb(mc, "kt", rgb1(1.0), name, RRT_P_KT), m.kt);
+        m.index = fetch_float(mc, "eta", 1.5, name, RRT_P_INDEX);
+        m.u_roughness = fetch_float(mc, "u_roughness", 0.0, name, RRT_P_UROUGHNESS);
+        m.v_roughness = fetch_float(mc, "v_roughness", 0.0, name, RRT_P_VROUGHNESS);
         no_bump();
         m.remap_roughness = read_bool(mc, "remap_roughness", false);
       } else if (type == "TranslucentMaterial") {   // renderprocess.rs:695-720
         m.type = RRT_MAT_TRANSLUCENT;
-        put(fetch_rgb(mc, "kd", rgb1(0.25), name), m.kd);
-        put(fetch_rgb(mc, "ks", rgb1(0.25), name), m.ks);
-        m.roughness = fetch_float(mc, "roughness", 0.1, name);
-        put(fetch_rgb(mc, "reflect", rgb1(0.25), name), m.reflect);
-        put(fetch_rgb(mc, "transmit", rgb1(0.25), name), m.transmit);
+        put(fetch_rgb(mc, "kd", rgb1(0.25), name, RRT_P_KD), m.kd);
+        put(fetch_rgb(mc, "ks", rgb1(0.25), name, RRT_P_KS), m.ks);
+        m.roughness = fetch_float(mc, "roughness", 0.1, name, RRT_P_ROUGHNESS);
+        put(fetch_rgb(mc, "reflect", rgb1(0.25), name, RRT_P_REFLECT), m.reflect);
+        put(fetch_rgb(mc, "transmit", rgb1(0.25), name, RRT_P_TRANSMIT), m.transmit);
         no_bump();
         m.remap_roughness = read_bool(mc, "remap_roughness", false);
       } else if (type == "DisneyMaterial") {

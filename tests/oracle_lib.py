@@ -25,6 +25,8 @@ def lib():
         L.oracle_sphere_intersect_p.argtypes = [C.c_void_p, C.c_uint32, C.c_void_p, C.c_void_p]
         L.oracle_bsdf_eval.argtypes = [C.c_void_p, C.c_uint32, C.c_int, C.c_void_p, C.c_void_p, C.c_double, C.c_double, C.c_void_p]
         L.oracle_bsdf_eval.restype = C.c_int
+        L.oracle_texture_eval.argtypes = [C.c_void_p, C.c_int32, C.c_void_p, C.c_void_p]
+        L.oracle_surface_differentials.argtypes = [C.c_void_p, C.c_void_p]
         L.oracle_trace_closest.argtypes = [C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_size_t] + [C.c_void_p] * 8 + [C.c_int, C.c_void_p]
         L.oracle_trace_any.argtypes = [C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_size_t, C.c_void_p, C.c_void_p, C.c_void_p, C.c_int, C.c_void_p]
         L.oracle_camera_samples.argtypes = [C.c_void_p, C.c_void_p, C.c_uint64, C.c_uint64, C.c_void_p, C.c_void_p, C.c_void_p]
@@ -112,6 +114,22 @@ def random_rays(scene, n, seed=0):
     d = tgt - o
     d /= np.linalg.norm(d, axis=1, keepdims=True)
     return o, d, np.full(n, np.inf)
+
+
+def texture_eval(scene, tex, p=(0, 0, 0), uv=(0, 0), dpdx=(0, 0, 0), dpdy=(0, 0, 0), duv=(0, 0, 0, 0)):
+    """Texture::evaluate of scene.desc.textures[tex] at a hand-made interaction; duv = (dudx, dvdx, dudy, dvdy)."""
+    si = np.array(list(p) + list(uv) + list(dpdx) + list(dpdy) + list(duv), np.float64)
+    out = np.zeros(3)
+    _check(lib().oracle_texture_eval(_d(scene), tex, si.ctypes.data, out.ctypes.data))
+    return out
+
+
+def surface_differentials(n, p, dpdu, dpdv, rxo, rxd, ryo, ryd):
+    """compute_differentials (interaction.rs:223-284): dict(dpdx, dpdy, duv = (dudx, dvdx, dudy, dvdy))."""
+    a = np.ascontiguousarray(np.concatenate([n, p, dpdu, dpdv, rxo, rxd, ryo, ryd]), np.float64)
+    out = np.zeros(10)
+    _check(lib().oracle_surface_differentials(a.ctypes.data, out.ctypes.data))
+    return dict(dpdx=out[0:3].copy(), dpdy=out[3:6].copy(), duv=out[6:10].copy())
 
 
 def bsdf_eval(scene, material, wo, wi, u0=0.5, u1=0.5, allow_multiple_lobes=True):

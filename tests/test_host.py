@@ -173,8 +173,26 @@ def test_loader_error_behaviour(tmp_path):
                         {"texture_name": "uv", "texture_type": "UVTexture"}]
     t["materials"][2]["kd"] = "red"
     assert list(Scene.loads(t, root).desc.materials[2].kd) == [0.8, 0.1, 0.1]
+    # a non-constant one becomes a node of the texture graph, bound to the material's parameter slot
     t["materials"][2]["kd"] = "uv"
-    with pytest.raises(RrtUnsupported, match="non-constant"):
+    d = Scene.loads(t, root).desc
+    assert d.n_textures == 2 and d.materials[2].tex[0] == 1 and d.textures[1].type == 8 and list(d.materials[2].tex[1:]) == [-1] * 12
+    assert list(d.textures[1].map) == [1.0, 1.0, 0.0, 0.0]           # no "mapping" key: UVMapping2D::new(1, 1, 0, 0)
+    t["rgb_texture"][1]["mapping"] = {"mapping": "uv", "su": 4.0}
+    assert list(Scene.loads(t, root).desc.textures[1].map) == [4.0, 1.0, 1.0, 1.0]   # du / dv default to 1.0 there (renderprocess.rs:573-574)
+    t["rgb_texture"][1]["mapping"] = {"mapping": "conformal"}
+    with pytest.raises(RrtPanic, match="Unsupported Mapping Type"):
+        Scene.loads(t, root)
+    # ImageTexture: a missing file is skipped as in the reference; a present one is refused when a material uses it
+    t["rgb_texture"][1] = {"texture_name": "uv", "texture_type": "ImageTexture", "filename": "no_such.png"}
+    assert list(Scene.loads(t, root).desc.materials[2].kd) == [0.5, 0.5, 0.5]     # name not registered -> the key's default
+    t["rgb_texture"][1]["filename"] = t["objs"][0]["filename"]
+    with pytest.raises(RrtUnsupported, match="ImageTexture"):
+        Scene.loads(t, root)
+    # ... also through a texture that only contains one
+    t["rgb_texture"].append({"texture_name": "scaled", "texture_type": "ScaleTexture", "t1": "uv", "t2": "red"})
+    t["materials"][2]["kd"] = "scaled"
+    with pytest.raises(RrtUnsupported, match="ImageTexture"):
         Scene.loads(t, root)
 
 

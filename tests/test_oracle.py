@@ -363,3 +363,178 @@ def test_distant_light_and_wide_filters_closed_form(tmp_path):
             wacc[y, x0:x1] += fw
     np.testing.assert_allclose(fg[..., 3], 3.0 * wacc, rtol=1e-12)
     np.testing.assert_allclose(fg[..., :3], (m @ expect_rgb)[None, None, :] * acc[..., None], rtol=1e-11, atol=1e-14)
+
+
+# ---- textures: Texture::evaluate against closed forms, compute_differentials against numpy ------
+def _texture_scene(tmp, float_tex, rgb_tex):
+    cfg, root = scenes.cfg2(str(tmp), xres=16, yres=16, nsamp=2)
+    cfg["float_texture"], cfg["rgb_texture"] = float_tex, rgb_tex
+    sc = Scene.loads(cfg, root)
+    names = [t["texture_name"] for t in float_tex] + [t["texture_name"] for t in rgb_tex]
+    return sc, {n: i for i, n in enumerate(names)}     # later duplicates of a name own the later node, like the HashMap insert
+
+
+def test_texture_evaluate_closed_forms(tmp_path):
+    rot = {"rotation_axis": [0.0, 0.0, 1.0], "rotation_angle": 0.0}     # make_to_world normalises the axis: absent -> NaN matrix
+    ft = [{"texture_name": "lo", "texture_type": "BilerpTexture", "v00": 0.25, "v01": 0.25},
+          {"texture_name": "ramp", "texture_type": "BilerpTexture", "v00": 0.0, "v01": 2.0},
+          {"texture_name": "mixf", "texture_type": "MixTexture", "t1": "lo", "t2": "ramp"},
+          {"texture_name": "chk3", "texture_type": "CheckerBoardTexture", "dimension": 3, "t1": "lo", **rot, "scale": [2.0, 2.0, 2.0]},
+          {"texture_name": "wr", "texture_type": "WrinkledTexture", "octaves": 4, "omega": 0.5, **rot},
+          {"texture_name": "wind", "texture_type": "WindyTexture", **rot}]
+    rt = [{"texture_name": "a", "texture_type": "BilerpTexture", "v00": {"values": [0.9, 0.1, 0.2]}, "v01": {"values": [0.9, 0.1, 0.2]}},
+          {"texture_name": "b", "texture_type": "BilerpTexture", "v00": {"values": [0.0, 0.5, 1.0]}, "v01": {"values": [0.0, 0.5, 1.0]}},
+          {"texture_name": "uv", "texture_type": "UVTexture", "mapping": {"mapping": "uv", "su": 3.0, "sv": 2.0, "du": 0.25, "dv": -0.5}},
+          {"texture_name": "chk", "texture_type": "CheckerBoardTexture", "t1": "a", "t2": "b", "mapping": {"mapping": "uv", "su": 4.0, "sv": 4.0, "du": 0.0, "dv": 0.0}},
+          {"texture_name": "chk_none", "texture_type": "CheckerBoardTexture", "aamode": "none", "t1": "a", "t2": "b",
+           "mapping": {"mapping": "uv", "su": 4.0, "sv": 4.0, "du": 0.0, "dv": 0.0}},
+          {"texture_name": "chk_default", "texture_type": "CheckerBoardTexture", "t1": "nope", "t2": "nope2"},
+          {"texture_name": "scaled", "texture_type": "ScaleTexture", "t1": "a", "t2": "uv"},
+          {"texture_name": "mixc", "texture_type": "MixTexture", "t1": "a", "t2": "b"},
+          {"texture_name": "plane", "texture_type": "BilerpTexture", "v00": {"values": [1.0, 0.0, 0.0]}, "v01": {"values": [0.0, 1.0, 0.0]},
+           "mapping": {"mapping": "planar", "v1": [0.5, 0.0, 0.0], "v2": [0.0, 0.0, 0.25], "udelta": 0.1, "vdelta": 0.2}},
+          {"texture_name": "sph", "texture_type": "UVTexture", "mapping": {"mapping": "spherical"}, **rot, "world_pos": [1.0, 2.0, 3.0]},
+          {"texture_name": "cyl", "texture_type": "UVTexture", "mapping": {"mapping": "cylindrical"}, **rot, "world_pos": [1.0, 2.0, 3.0]}]
+    sc, ix = _texture_scene(tmp_path, ft, rt)
+    d = sc.desc
+    assert d.n_textures == len(ft) + len(rt)
+    ev = lambda name, **kw: O.texture_eval(sc, ix[name], **kw)
+    A, B = np.array([0.9, 0.1, 0.2]), np.array([0.0, 0.5, 1.0])
+    # children are evaluated, not folded: a constant spelled as a Bilerp goes through the bilerp expression (a few ulps)
+    same = lambda got, want: np.testing.assert_allclose(got, want, rtol=1e-15, atol=1e-16)
+    # Bilerp reads "v01" for v10 and v11 too (renderprocess.rs:329-330): (v00, v01, v01, v01)
+    s_, t_ = 0.3, 0.6
+    np.testing.assert_allclose(ev("ramp", uv=(s_, t_)), [0.0 * (1 - s_) * (1 - t_) + 2.0 * (1 - s_) * t_ + 2.0 * s_ * (1 - t_) + 2.0 * s_ * t_] * 3, rtol=1e-15)
+    # float Mix reads the "t2" *name* for the amount (:318): amount = ramp, so lo * (1 - ramp) + ramp * ramp
+    r = 2.0 * (1 - (1 - s_) * (1 - t_))
+    np.testing.assert_allclose(ev("mixf", uv=(s_, t_))[0], 0.25 * (1 - r) + r * r, rtol=1e-14)
+    # rgb Mix takes its amount from the *float* table under the "t2" name; "b" is not a float texture -> constant 0.5
+    np.testing.assert_allclose(ev("mixc"), A * 0.5 + B * 0.5, rtol=1e-15)
+    # UVTexture: fractional part of (su * u + du, sv * v + dv)
+    np.testing.assert_allclose(ev("uv", uv=(0.4, 0.9)), [(3 * 0.4 + 0.25) % 1.0, (2 * 0.9 - 0.5) % 1.0, 0.0], rtol=1e-14)
+    np.testing.assert_allclose(ev("scaled", uv=(0.4, 0.9)), A * [(3 * 0.4 + 0.25) % 1.0, (2 * 0.9 - 0.5) % 1.0, 0.0], rtol=1e-14)
+    # Checkerboard: point-sampled when the footprint stays inside one cell, for both aa modes; negative cells: Rust `%` keeps the sign,
+    # so floor(s) + floor(t) = -1 selects tex2
+    for name in ("chk", "chk_none"):
+        same(ev(name, uv=(0.1, 0.1)), A)
+        same(ev(name, uv=(0.3, 0.1)), B)
+        same(ev(name, uv=(-0.1, 0.1)), B)
+        same(ev(name, uv=(-0.1, -0.1)), A)
+    # missing children fall back to constants 1.0 / 0.0; default mapping without a "mapping" key is UVMapping2D(1, 1, 0, 0)
+    same(ev("chk_default", uv=(0.5, 0.5)), [1.0] * 3)
+    same(ev("chk_default", uv=(1.5, 0.5)), [0.0] * 3)
+    # closed-form box filter over [s - ds, s + ds] x [t - dt, t + dt], ds = max |dstdx| components, dt = max |dstdy| components
+    bump = lambda x: np.floor(x / 2) + 2 * max(x / 2 - np.floor(x / 2) - 0.5, 0.0)
+    u, v, duv = 0.255, 0.1, (0.01, 0.002, 0.001, 0.004)
+    s, t, ds, dt = 4 * u, 4 * v, 4 * max(duv[0], duv[1]), 4 * max(duv[2], duv[3])
+    sint = (bump(s + ds) - bump(s - ds)) / (2 * ds); tint = (bump(t + dt) - bump(t - dt)) / (2 * dt)
+    area2 = sint + tint - 2 * sint * tint
+    assert 0.0 < area2 < 1.0
+    np.testing.assert_allclose(ev("chk", uv=(u, v), duv=duv), A * (1 - area2) + B * area2, rtol=1e-13)
+    same(ev("chk_none", uv=(u, v), duv=duv), B)      # cell (1, 0)
+    np.testing.assert_allclose(ev("chk", uv=(u, v), duv=(0.3, 0, 0, 0.001)), A * 0.5 + B * 0.5, rtol=1e-15)      # ds > 1: area2 = 0.5
+    # 3D checkerboard: IdentityMapping3D receives to_world itself (scale 2), not its inverse
+    same(ev("chk3", p=(0.3, 0.3, 0.3)), [0.25] * 3)      # (0.6, 0.6, 0.6) -> cell sum 0 -> t1 = lo
+    same(ev("chk3", p=(0.6, 0.3, 0.3)), [0.0] * 3)       # (1.2, ..) -> cell sum 1 -> t2 fallback 0.0
+    # planar mapping: st = (ds + p . v1, dt + p . v2)
+    p = np.array([0.8, 5.0, 1.2]); ps, pt = 0.1 + 0.5 * p[0], 0.2 + 0.25 * p[2]
+    np.testing.assert_allclose(ev("plane", p=p), [(1 - ps) * (1 - pt), 1 - (1 - ps) * (1 - pt), 0.0], rtol=1e-14, atol=1e-16)
+    # spherical / cylindrical mapping of the point in texture space (world_to_texture = inverse(to_world) = translate(-pos))
+    q = p - [1.0, 2.0, 3.0]; qn = q / np.linalg.norm(q)
+    phi = np.arctan2(qn[1], qn[0]) % (2 * np.pi)
+    np.testing.assert_allclose(ev("sph", p=p), [(np.arccos(qn[2]) / np.pi) % 1.0, (phi / (2 * np.pi)) % 1.0, 0.0], rtol=1e-13)
+    np.testing.assert_allclose(ev("cyl", p=p), [((np.pi + np.arctan2(qn[1], qn[0])) / (2 * np.pi)) % 1.0, qn[2] % 1.0, 0.0], rtol=1e-13)
+    # Perlin noise vanishes on the integer lattice: with zero differentials every octave is kept (log2(0) = -inf -> n = max_octaves),
+    # fbm = 0 there and turbulence = o_n * lerp(smooth_step(0.3, 0.7, 0) = 0, 0.2, |noise|) = omega^4 * 0.2 at lattice points of every
+    # octave; lambda = 1.99^i is not an integer, so use p = 0
+    assert ev("wind", p=(0, 0, 0))[0] == 0.0
+    np.testing.assert_allclose(ev("wr", p=(0, 0, 0)), [0.5 ** 4 * 0.2] * 3, rtol=1e-15)
+    # ... and is smooth, bounded and non-trivial elsewhere; a large footprint removes octaves: n = clamp(-1 - log2(len2) / 2, 0, octaves)
+    vals = np.array([ev("wr", p=(0.37 * k, 1.1 + 0.21 * k, -0.4 * k))[0] for k in range(1, 40)])
+    assert vals.min() > 0.0 and vals.max() < 2.0 and vals.std() > 0.02
+    coarse = ev("wr", p=(0.37, 1.31, -0.4), dpdx=(0.5, 0, 0))[0]       # len2 = 0.25 -> n = 0: only the partial term and the 0.2 tails
+    noise1 = abs(_perlin(0.37, 1.31, -0.4))
+    np.testing.assert_allclose(coarse, 0.2 + sum(0.5 ** i * 0.2 for i in range(0, 4)), rtol=1e-14)   # lerp(0, 0.2, |n|) = 0.2 at n_partial = 0
+    fine = ev("wr", p=(0.37, 1.31, -0.4), dpdx=(0.25, 0, 0))[0]        # len2 = 1/16 -> n = 1: one full octave + tails from octave 1
+    q2 = np.array([0.37, 1.31, -0.4]) * 1.99
+    np.testing.assert_allclose(fine, noise1 + 0.5 * 0.2 + sum(0.5 ** i * 0.2 for i in range(1, 4)), rtol=1e-13)
+    assert abs(_perlin(*q2)) < 1.0
+
+
+def _perlin(x, y, z):
+    """Ken Perlin's improved noise as texture/mod.rs:73-130 spells it (numpy restatement for the test above)."""
+    perm = [151, 160, 137, 91, 90, 15, 131, 13, 201, 95, 96, 53, 194, 233, 7, 225, 140, 36, 103, 30, 69, 142, 8, 99, 37, 240, 21, 10, 23, 190, 6, 148,
+            247, 120, 234, 75, 0, 26, 197, 62, 94, 252, 219, 203, 117, 35, 11, 32, 57, 177, 33, 88, 237, 149, 56, 87, 174, 20, 125, 136, 171, 168, 68, 175,
+            74, 165, 71, 134, 139, 48, 27, 166, 77, 146, 158, 231, 83, 111, 229, 122, 60, 211, 133, 230, 220, 105, 92, 41, 55, 46, 245, 40, 244, 102, 143, 54,
+            65, 25, 63, 161, 1, 216, 80, 73, 209, 76, 132, 187, 208, 89, 18, 169, 200, 196, 135, 130, 116, 188, 159, 86, 164, 100, 109, 198, 173, 186, 3, 64,
+            52, 217, 226, 250, 124, 123, 5, 202, 38, 147, 118, 126, 255, 82, 85, 212, 207, 206, 59, 227, 47, 16, 58, 17, 182, 189, 28, 42, 223, 183, 170, 213,
+            119, 248, 152, 2, 44, 154, 163, 70, 221, 153, 101, 155, 167, 43, 172, 9, 129, 22, 39, 253, 19, 98, 108, 110, 79, 113, 224, 232, 178, 185, 112, 104,
+            218, 246, 97, 228, 251, 34, 242, 193, 238, 210, 144, 12, 191, 179, 162, 241, 81, 51, 145, 235, 249, 14, 239, 107, 49, 192, 214, 31, 181, 199, 106, 157,
+            184, 84, 204, 176, 115, 121, 50, 45, 127, 4, 150, 254, 138, 236, 205, 93, 222, 114, 67, 29, 24, 72, 243, 141, 128, 195, 78, 66, 215, 61, 156, 180] * 2
+
+    def grad(ix, iy, iz, dx, dy, dz):
+        h = perm[perm[perm[ix] + iy] + iz] & 15
+        u = dx if (h < 8 or h in (12, 13)) else dy
+        v = dy if (h < 4 or h in (12, 13)) else dz
+        return (-u if h & 1 else u) + (-v if h & 2 else v)
+
+    ix, iy, iz = int(np.floor(x)), int(np.floor(y)), int(np.floor(z))
+    dx, dy, dz = x - ix, y - iy, z - iz
+    ix &= 255; iy &= 255; iz &= 255
+    w = lambda t: 6 * t ** 5 - 15 * t ** 4 + 10 * t ** 3
+    lerp = lambda t, a, b: a * (1 - t) + b * t
+    c = [[[grad(ix + i, iy + j, iz + k, dx - i, dy - j, dz - k) for k in (0, 1)] for j in (0, 1)] for i in (0, 1)]
+    x00, x10 = lerp(w(dx), c[0][0][0], c[1][0][0]), lerp(w(dx), c[0][1][0], c[1][1][0])
+    x01, x11 = lerp(w(dx), c[0][0][1], c[1][0][1]), lerp(w(dx), c[0][1][1], c[1][1][1])
+    return lerp(w(dz), lerp(w(dy), x00, x10), lerp(w(dy), x01, x11))
+
+
+def test_compute_differentials_against_numpy():
+    """interaction.rs:223-284, including its `ty`, which reads ry_direction where the origin belongs (:234)."""
+    rng = np.random.default_rng(5)
+    for _ in range(50):
+        n = rng.normal(size=3); n /= np.linalg.norm(n)
+        p = rng.normal(size=3) * 3
+        t1 = np.cross(n, rng.normal(size=3)); t2 = np.cross(n, t1)
+        dpdu, dpdv = 0.7 * t1 + 0.1 * t2, -0.2 * t1 + 1.3 * t2
+        rxo, ryo = p + n * 5 + rng.normal(size=3) * 0.01, p + n * 5 + rng.normal(size=3) * 0.01
+        rxd, ryd = -n + rng.normal(size=3) * 0.05, -n + rng.normal(size=3) * 0.05
+        got = O.surface_differentials(n, p, dpdu, dpdv, rxo, rxd, ryo, ryd)
+        d = n @ p
+        tx = -((n @ rxo) - d) / (n @ rxd)
+        ty = -((n @ ryd) - d) / (n @ ryd)
+        px, py = rxo + rxd * tx, ryo + ryd * ty
+        np.testing.assert_allclose(got["dpdx"], px - p, rtol=1e-12, atol=1e-14)
+        np.testing.assert_allclose(got["dpdy"], py - p, rtol=1e-12, atol=1e-14)
+        an = np.abs(n)
+        dims = (1, 2) if (an[0] > an[1] and an[0] > an[2]) else ((0, 2) if an[1] > an[2] else (0, 1))
+        a = np.array([[dpdu[dims[0]], dpdv[dims[0]]], [dpdu[dims[1]], dpdv[dims[1]]]])
+        exp = []
+        for q in (px, py):
+            b = np.array([q[dims[0]] - p[dims[0]], q[dims[1]] - p[dims[1]]])
+            exp += list(np.linalg.solve(a, b)) if abs(np.linalg.det(a)) >= 1e-10 else [0.0, 0.0]
+        np.testing.assert_allclose(got["duv"], exp, rtol=1e-9, atol=1e-12)
+        assert abs((py - p) @ n) > 1e-3      # the :234 expression leaves py off the tangent plane (pbrt's would put it on)
+    # parallel auxiliary ray: tx infinite -> every differential zero
+    z = O.surface_differentials([0, 0, 1], [0, 0, 0], [1, 0, 0], [0, 1, 0], [0, 0, 1], [1, 0, 0], [0, 0, 1], [0, 0, -1])
+    assert not z["dpdx"].any() and not z["dpdy"].any() and not z["duv"].any()
+
+
+def test_textured_render_uses_camera_differentials(workdir):
+    """A checkerboard kd on cfg3's enclosure (no vt: uv = (0,0),(1,0),(1,1) per triangle): closed-form AA differs from point sampling
+    only through the camera ray differentials (scaled by 1 / sqrt(spp), integrator/mod.rs:94-96), only at cell borders, and stays
+    between the two child values; later bounces of the path integrator carry no differentials (path.rs:163)."""
+    cfg, root = scenes.cfg3(workdir, xres=48, yres=48, nsamp=3, max_depth=1)
+    imgs = {}
+    for aa in ("closedform", "none"):
+        c = json.loads(json.dumps(cfg))
+        c["rgb_texture"] = [{"texture_name": "w", "texture_type": "BilerpTexture", "v00": {"values": [0.8, 0.8, 0.8]}, "v01": {"values": [0.8, 0.8, 0.8]}},
+                            {"texture_name": "k", "texture_type": "BilerpTexture", "v00": {"values": [0.1, 0.1, 0.1]}, "v01": {"values": [0.1, 0.1, 0.1]}},
+                            {"texture_name": "chk", "texture_type": "CheckerBoardTexture", "aamode": aa, "t1": "w", "t2": "k",
+                             "mapping": {"mapping": "uv", "su": 6.0, "sv": 6.0, "du": 0.0, "dv": 0.0}}]
+        c["materials"] = c["materials"] + [{"material_type": "MatteMaterial", "material_name": "chk_m", "kd": "chk"}]
+        c["Aggregate"]["primitives"][0]["material_name"] = "chk_m"
+        imgs[aa] = O.render(Scene.loads(c, root))[..., :3]
+    assert imgs["none"].max() > 0
+    differ = np.abs(imgs["closedform"] - imgs["none"]).max(-1) > 1e-12 * imgs["none"].max()
+    assert 0.005 < differ.mean() < 0.6, differ.mean()
