@@ -9,7 +9,7 @@ namespace rrtd {
 
 constexpr int kBlock = 256;
 // device counters, one 128-byte line each (atomics on different queues must not share an L2 line)
-enum { C_ACTIVE = 0, C_NEXT = 32, C_SHADOW = 64, C_CAMERA_RAYS = 96, C_ERROR = 128, C_WORK_CLOSEST = 160, C_WORK_SHADOW = 192, C_WORK_AUX = 224, C_COUNT = 256 };
+enum { C_ACTIVE = 0, C_NEXT = 32, C_SHADOW = 64, C_CAMERA_RAYS = 96, C_ERROR = 128, C_WORK_CLOSEST = 160, C_WORK_SHADOW = 192, C_WORK_AUX = 224, C_SHADOW2 = 256, C_COUNT = 288 };
 // shading kernels push to their queues once per block (measured: 256 <= 512 <= 1024 threads by 5 %: smaller blocks retire
 // and refill a CU sooner, and one atomic per 256 paths no longer serialises)
 template <typename R> struct ShadeBlock { static constexpr int n = 256; };
@@ -958,7 +958,7 @@ __global__ void __launch_bounds__(ShadeBlock<R>::n) __attribute__((amdgpu_waves_
       }
     }
   }
-  const uint32_t qs = block_push(&p.counters[C_SHADOW], want_shadow, push_lds);
+  const uint32_t qs = block_push(p.shadow_count, want_shadow, push_lds);
   if (want_shadow) {
     store_ray<R>(p.sray_o, p.sray_d, qs, sh_o, o_lo, sh_d, R(1) - R(0.0001), self_prim<R>(prim));
     p.sld[qs] = mk4u<R>(sh_ld.r, sh_ld.g, sh_ld.b, slot);
@@ -1035,7 +1035,7 @@ __global__ void __launch_bounds__(ShadeBlock<R>::n) k_shade_nee(SceneDev<R> s, P
       }
     }
   }
-  const uint32_t qs = block_push(&p.counters[C_SHADOW], want_shadow, push_lds);
+  const uint32_t qs = block_push(p.shadow_count, want_shadow, push_lds);
   if (want_shadow) {
     store_ray<R>(p.sray_o, p.sray_d, qs, sh_o, o_lo, sh_d, R(1) - R(0.0001), self_prim<R>(prim));
     p.sld[qs] = mk4u<R>(sh_ld.r, sh_ld.g, sh_ld.b, slot);
@@ -1249,6 +1249,10 @@ static __global__ void k_rotate(uint32_t* c, int what) {
   else if (what == 1) { c[C_SHADOW] = 0; }
   else if (what == 3) { /* only the work counters */ }
   else if (what == 4) { c[C_NEXT] = 0; }
+  // 5 / 6: the two halves of `0` when the shadow launch runs on its own stream beside the next closest-hit launch
+  else if (what == 5) { c[C_ACTIVE] = c[C_NEXT]; c[C_NEXT] = 0; c[C_WORK_CLOSEST] = 0; c[C_WORK_AUX] = 0; return; }
+  else if (what == 6) { c[C_SHADOW] = 0; c[C_WORK_SHADOW] = 0; return; }
+  else if (what == 7) { c[C_SHADOW2] = 0; c[C_WORK_SHADOW] = 0; return; }
   else { c[C_ACTIVE] = 0; c[C_NEXT] = 0; c[C_SHADOW] = 0; }
   c[C_WORK_CLOSEST] = 0; c[C_WORK_SHADOW] = 0; c[C_WORK_AUX] = 0;
 }
@@ -1256,7 +1260,7 @@ static __global__ void k_accumulate_counts(uint32_t* c, unsigned long long* tota
   // totals[2] closest queries, totals[3] shadow queries, totals[4] camera rays
   totals[2] += c[C_ACTIVE];
 }
-static __global__ void k_accumulate_shadow(uint32_t* c, unsigned long long* totals) { totals[3] += c[C_SHADOW]; }
+static __global__ void k_accumulate_shadow(const uint32_t* shadow_count, unsigned long long* totals) { totals[3] += *shadow_count; }
 static __global__ void k_accumulate_camera(uint32_t* c, unsigned long long* totals) { totals[4] += c[C_CAMERA_RAYS]; c[C_CAMERA_RAYS] = 0; }
 
 // ------------------------------------------------------------------------------------------------------------

@@ -184,6 +184,7 @@ struct Pools {
   // {rx_origin, -}, {rx_direction, -}, {ry_origin, -}, {ry_direction, -} per slot
   V4 *rdx_o, *rdx_d, *rdy_o, *rdy_d;
   uint32_t* counters;    // [0] active, [1] next, [2] shadow, [3] camera rays, [4..] stats
+  uint32_t* shadow_count;  // the shadow queue's counter (the path integrator alternates two shadow queues, see render_impl)
 };
 
 }  // namespace rrtd

@@ -115,19 +115,29 @@ class Handle : public HandleBase {
  public:
   Handle(int device, const rrt_scene_desc* d) : dev_(device), desc_(*d) {
     HIP_CHECK(hipSetDevice(dev_));
-    HIP_CHECK(hipStreamCreate(&st_));
+    {   // the main stream carries the critical path (closest-hit -> shade); shadow rays fill what it leaves idle
+      int lo = 0, hi = 0;
+      HIP_CHECK(hipDeviceGetStreamPriorityRange(&lo, &hi));
+      HIP_CHECK(hipStreamCreateWithPriority(&st_, hipStreamDefault, hi));
+      HIP_CHECK(hipStreamCreateWithPriority(&st2_, hipStreamDefault, lo));
+    }
+    HIP_CHECK(hipEventCreateWithFlags(&ev_shade_, hipEventDisableTiming));
+    for (int k = 0; k < 2; k++) HIP_CHECK(hipEventCreateWithFlags(&ev_shadow_[k], hipEventDisableTiming));
     upload_scene(d);
     HIP_CHECK(hipStreamSynchronize(st_));
     // Large pools matter: a launch lasts at least as long as the latency chain of its longest ray, so few big
     // launches beat many small ones (whole 1024^2 x 256 spp frame in one pass: 268 M slots x 172 B = 46 GB).
     size_t free_b = 0, total_b = 0;
     HIP_CHECK(hipMemGetInfo(&free_b, &total_b));
-    const size_t per_slot = ((tex_depth_ > 0 ? 16 : 12) * 4 + 1) * sizeof(R) + 9 * sizeof(uint32_t);
+    const size_t per_slot = (n_vec_records() * 4 + 1) * sizeof(R) + 9 * sizeof(uint32_t);
     max_paths_ = std::max<size_t>(1u << 16, std::min(max_paths_, (free_b / 2) / per_slot));
   }
   ~Handle() override {
     (void)hipSetDevice(dev_);
     (void)hipStreamSynchronize(st_);
+    (void)hipStreamSynchronize(st2_);
+    (void)hipEventDestroy(ev_shade_); (void)hipEventDestroy(ev_shadow_[0]); (void)hipEventDestroy(ev_shadow_[1]);
+    (void)hipStreamDestroy(st2_);
     (void)hipStreamDestroy(st_);
   }
   int precision() const override { return sizeof(R) == 4 ? RRT_F32 : RRT_F64; }
@@ -140,6 +150,7 @@ class Handle : public HandleBase {
     else if (key == "raygen_pt") raygen_pt_ = v != 0;
     else if (key == "pt_split_closest") pt_split_closest_ = (uint32_t)v;
     else if (key == "pt_split_any") pt_split_any_ = (uint32_t)v;
+    else if (key == "overlap_shadow") overlap_shadow_ = v != 0;
     else throw std::invalid_argument("unknown option " + key);
   }
 
@@ -257,15 +268,15 @@ class Handle : public HandleBase {
     const uint64_t s_chunk = std::max<uint64_t>(1, cap_ / group);         // samples per pass
     const bool timing = stats != nullptr;
     std::vector<std::pair<int, std::pair<hipEvent_t, hipEvent_t>>> evs;
-    auto tick = [&](int cat) {
+    auto tick = [&](int cat, hipStream_t stream = nullptr) {
       if (!timing) return (size_t)0;
       hipEvent_t a, b;
       HIP_CHECK(hipEventCreate(&a)); HIP_CHECK(hipEventCreate(&b));
-      HIP_CHECK(hipEventRecord(a, st_));
+      HIP_CHECK(hipEventRecord(a, stream ? stream : st_));
       evs.push_back({cat, {a, b}});
       return evs.size() - 1;
     };
-    auto tock = [&](size_t id) { if (timing) HIP_CHECK(hipEventRecord(evs[id].second.second, st_)); };
+    auto tock = [&](size_t id, hipStream_t stream = nullptr) { if (timing) HIP_CHECK(hipEventRecord(evs[id].second.second, stream ? stream : st_)); };
     hipEvent_t ev_begin = nullptr, ev_end = nullptr;
     if (timing) { HIP_CHECK(hipEventCreate(&ev_begin)); HIP_CHECK(hipEventCreate(&ev_end)); HIP_CHECK(hipEventRecord(ev_begin, st_)); }
     uint64_t n_closest_launch = 0, n_any_launch = 0;
@@ -288,22 +299,48 @@ class Handle : public HandleBase {
         hipLaunchKernelGGL(k_accumulate_camera, dim3(1), dim3(1), 0, st_, counters_.p, totals_.p);
         if (integ == RRT_INT_PATH) {
           // bounce b: closest -> shade (NEE + BSDF sample + RR) -> shadow rays; paths live while bounces < max_depth
+          const bool overlap = two_shadow_queues() && shadow_buf_[1][0] && !count_traversal_ && max_depth > 1;
+          auto use_shadow_queue = [&](int k) {
+            pool_.sray_o = shadow_buf_[k][0]; pool_.sray_d = shadow_buf_[k][1]; pool_.sld = shadow_buf_[k][2];
+            pool_.shadow_count = counters_.p + (k ? C_SHADOW2 : C_SHADOW);
+          };
           for (int b = 0; b < max_depth; b++) {
             hipLaunchKernelGGL(k_accumulate_counts, dim3(1), dim3(1), 0, st_, counters_.p, totals_.p);
             e = tick(1);
             launch_closest(nullptr, &counters_.p[C_ACTIVE], 0, count_traversal_, nullptr, nullptr, count_traversal_ ? totals_.p : nullptr, grid);
             tock(e); n_closest_launch++;
+            if (overlap) {
+              use_shadow_queue(b & 1);
+              if (b > 1) HIP_CHECK(hipStreamWaitEvent(st_, ev_shadow_[b & 1], 0));   // shading refills the queue the shadow launch of bounce b - 2 read
+            }
             e = tick(3);
             if (tex_depth_ > 0) hipLaunchKernelGGL((k_shade_path<R, 4, true>), dim3(std::min((uint32_t)((nslots + 255) / 256), 16384u)), dim3(256), 0, st_, scene_, pool_);
             else if (has_translucent_) hipLaunchKernelGGL((k_shade_path<R, 4>), dim3(std::min((uint32_t)((nslots + 255) / 256), 16384u)), dim3(256), 0, st_, scene_, pool_);
             else hipLaunchKernelGGL((k_shade_path<R, 2>), dim3(std::min(sgrid, 16384u)), dim3(ShadeBlock<R>::n), 0, st_, scene_, pool_);
             tock(e);
-            hipLaunchKernelGGL(k_accumulate_shadow, dim3(1), dim3(1), 0, st_, counters_.p, totals_.p);
-            e = tick(2);
-            launch_shadow(grid);
-            tock(e); n_any_launch++;
-            swap_queues();
-            hipLaunchKernelGGL(k_rotate, dim3(1), dim3(1), 0, st_, counters_.p, 0);
+            if (overlap) {
+              HIP_CHECK(hipEventRecord(ev_shade_, st_));
+              HIP_CHECK(hipStreamWaitEvent(st2_, ev_shade_, 0));
+              hipLaunchKernelGGL(k_accumulate_shadow, dim3(1), dim3(1), 0, st2_, pool_.shadow_count, totals_.p);
+              e = tick(2, st2_);
+              launch_shadow(grid, st2_);
+              tock(e, st2_); n_any_launch++;
+              hipLaunchKernelGGL(k_rotate, dim3(1), dim3(1), 0, st2_, counters_.p, 6 + (b & 1));   // this shadow queue + the any-hit work counter
+              HIP_CHECK(hipEventRecord(ev_shadow_[b & 1], st2_));
+              swap_queues();
+              hipLaunchKernelGGL(k_rotate, dim3(1), dim3(1), 0, st_, counters_.p, 5);    // active <- next, closest work counter
+            } else {
+              hipLaunchKernelGGL(k_accumulate_shadow, dim3(1), dim3(1), 0, st_, pool_.shadow_count, totals_.p);
+              e = tick(2);
+              launch_shadow(grid);
+              tock(e); n_any_launch++;
+              swap_queues();
+              hipLaunchKernelGGL(k_rotate, dim3(1), dim3(1), 0, st_, counters_.p, 0);
+            }
+          }
+          if (overlap) {   // the film kernel reads L
+            HIP_CHECK(hipStreamWaitEvent(st_, ev_shadow_[(max_depth - 1) & 1], 0));
+            use_shadow_queue(0);
           }
         } else if (integ == RRT_INT_DIRECT || integ == RRT_INT_DEBUG) {
           if (has_transmissive_ || tex_depth_ > 0) {   // binary recursion with depth-first sampler dimensions / inherited ray differentials: one thread per camera sample
@@ -326,7 +363,7 @@ class Handle : public HandleBase {
                 e = tick(3);
                 hipLaunchKernelGGL((k_shade_nee<R>), dim3(sgrid), dim3(ShadeBlock<R>::n), 0, st_, scene_, pool_, all ? j : -1, j == 0 ? 1 : 0);
                 tock(e);
-                hipLaunchKernelGGL(k_accumulate_shadow, dim3(1), dim3(1), 0, st_, counters_.p, totals_.p);
+                hipLaunchKernelGGL(k_accumulate_shadow, dim3(1), dim3(1), 0, st_, pool_.shadow_count, totals_.p);
                 e = tick(2);
                 launch_shadow(grid);
                 tock(e); n_any_launch++;
@@ -405,6 +442,12 @@ class Handle : public HandleBase {
   int dev_;
   rrt_scene_desc desc_;   // shallow copy: scalar fields only are used after construction
   hipStream_t st_ = nullptr;
+  // Path integrator: the shadow rays of bounce k are traced on st2_ beside the closest-hit launch of bounce k + 1 (they only
+  // feed L[slot]); both launches end in a latency tail that leaves most of the chip idle, and the tails overlap this way.
+  hipStream_t st2_ = nullptr;
+  hipEvent_t ev_shade_ = nullptr, ev_shadow_[2] = {nullptr, nullptr};
+  typename Vec4T<R>::type* shadow_buf_[2][3] = {{nullptr, nullptr, nullptr}, {nullptr, nullptr, nullptr}};
+  bool overlap_shadow_ = true;
   SceneDev<R> scene_{};
   Pools<R> pool_{};
   size_t cap_ = 0;
@@ -415,11 +458,11 @@ class Handle : public HandleBase {
   bool raygen_pt_ = true;
   bool has_transmissive_ = false, has_translucent_ = false;
   int trav_mode_ = 3;   // 1 = LDS-treelet grid-stride kernel, 2 = persistent-thread kernel, 3 = by queue size
-  uint32_t pt_split_closest_ = 600000u, pt_split_any_ = 2500000u;
-  DevBuf<uint32_t> pt_overflow_;
+  uint32_t pt_split_closest_ = 100000u, pt_split_any_ = 100000u;   // re-tuned with the shadow launches overlapped (tools/band_scaling.py)
+  DevBuf<uint32_t> pt_overflow_, pt_overflow_any_;
   TravScene trav_{};
   DevBuf<PairNode> pairs_;
-  DevBuf<uint32_t> overflow_;
+  DevBuf<uint32_t> overflow_, overflow_any_;
   DevBuf<Node<R>> nodes_;
   DevBuf<Tri<R>> tris_;
   DevBuf<TriShade<R>> shades_;
@@ -738,12 +781,16 @@ class Handle : public HandleBase {
     HIP_CHECK(hipMemsetAsync(counters_.p, 0, C_COUNT * sizeof(uint32_t), st_));
   }
 
+  // The path integrator alternates two shadow queues, so that shading bounce k + 1 need not wait for the shadow rays of bounce k
+  bool two_shadow_queues() const { return overlap_shadow_ && desc_.integrator.type == RRT_INT_PATH && !deep_; }
+  // 12 four-word records per slot, +4 camera ray differentials on textured scenes, +3 for the second shadow queue
+  size_t n_vec_records() const { return 12 + (tex_depth_ > 0 ? 4 : 0) + (two_shadow_queues() ? 3 : 0); }
   void ensure_pools(size_t n) {
     if (n <= cap_) return;
     HIP_CHECK(hipStreamSynchronize(st_));
     cap_ = n;
     using V4 = typename Vec4T<R>::type;
-    const size_t NV = tex_depth_ > 0 ? 16 : 12, NR = 1, NU = 9;   // 4-word records (+4: camera ray differentials), reals, u32 per slot
+    const size_t NV = n_vec_records(), NR = 1, NU = 9;   // 4-word records, reals, u32 per slot
     vpool_.alloc(NV * cap_);
     rpool_.alloc(NR * cap_);
     upool_.alloc(NU * cap_);
@@ -761,6 +808,10 @@ class Handle : public HandleBase {
     auto nu = [&]() { uint32_t* x = u; u += cap_; return x; };
     p.q_active = (QEnt*)u; u += 4 * cap_; p.q_next = (QEnt*)u; u += 4 * cap_; p.hindex = nu();
     p.counters = counters_.p;
+    p.shadow_count = counters_.p + C_SHADOW;
+    shadow_buf_[0][0] = p.sray_o; shadow_buf_[0][1] = p.sray_d; shadow_buf_[0][2] = p.sld;
+    shadow_buf_[1][0] = shadow_buf_[1][1] = shadow_buf_[1][2] = nullptr;
+    if (two_shadow_queues()) { shadow_buf_[1][0] = nv(); shadow_buf_[1][1] = nv(); shadow_buf_[1][2] = nv(); }
     if (deep_) deep_stack_.alloc((size_t)scene_.stack_depth * cap_);
 
   }
@@ -828,17 +879,21 @@ class Handle : public HandleBase {
   }
   // fp32 production traversal (dtraverse_f32.hpp): 64 B pair nodes, LDS stack with global overflow
   bool use_persistent() const { return std::is_same<R, float>::value && persistent_ && pairs_ok_; }
-  void launch_persistent(bool any, const uint32_t* queue, const uint32_t* count, uint32_t n_fixed, uint32_t grid, uint8_t* occluded) {
+  void launch_persistent(bool any, const uint32_t* queue, const uint32_t* count, uint32_t n_fixed, uint32_t grid, uint8_t* occluded, hipStream_t stream = nullptr) {
     if constexpr (std::is_same<R, float>::value) {
+      if (!stream) stream = st_;
       const uint32_t grid_in = grid;
       if (trav_grid_ == 0) {
         int per_cu = 0, cus = 0;
         HIP_CHECK(hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, dev_));
         HIP_CHECK(hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu, k_trace_pairs_f32<false>, kTravBlock, 0));
         trav_grid_ = (uint32_t)(std::max(1, per_cu) * std::max(1, cus));
-        if (scene_.stack_depth > (uint32_t)kStackLds) overflow_.alloc((size_t)(scene_.stack_depth - kStackLds) * (size_t)trav_grid_ * kTravBlock * 2);
+        if (scene_.stack_depth > (uint32_t)kStackLds) {   // any-hit launches have their own columns: they may run beside a closest-hit launch
+          overflow_.alloc((size_t)(scene_.stack_depth - kStackLds) * (size_t)trav_grid_ * kTravBlock * 2);
+          overflow_any_.alloc((size_t)(scene_.stack_depth - kStackLds) * (size_t)trav_grid_ * kTravBlock * 2);
+        }
       }
-      trav_.overflow = overflow_.p;
+      trav_.overflow = any ? overflow_any_.p : overflow_.p;
       trav_.overflow_stride = trav_grid_ * kTravBlock;   // one column per resident thread of the persistent grid
       // persistent workgroups: grid-stride over the queue (slots / kBlock thread blocks were requested by the caller)
       const uint32_t need = (uint32_t)(((size_t)grid * kBlock + kTravBlock - 1) / kTravBlock);
@@ -856,19 +911,22 @@ class Handle : public HandleBase {
           HIP_CHECK(hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, dev_));
           HIP_CHECK(hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu, k_trace_pt_f32<false>, kPtBlock, 0));
           pt_grid_ = (uint32_t)(std::max(1, per_cu) * std::max(1, cus));
-          if (pairs_ok_ && scene_.stack_depth > (uint32_t)kPtStack) pt_overflow_.alloc((size_t)(scene_.stack_depth - kPtStack) * (size_t)pt_grid_ * kPtBlock * 2);
+          if (pairs_ok_ && scene_.stack_depth > (uint32_t)kPtStack) {
+            pt_overflow_.alloc((size_t)(scene_.stack_depth - kPtStack) * (size_t)pt_grid_ * kPtBlock * 2);
+            pt_overflow_any_.alloc((size_t)(scene_.stack_depth - kPtStack) * (size_t)pt_grid_ * kPtBlock * 2);
+          }
         }
         TravScene t2 = trav_;
-        t2.overflow = pt_overflow_.p;
+        t2.overflow = any ? pt_overflow_any_.p : pt_overflow_.p;
         t2.overflow_stride = pt_grid_ * kPtBlock;
         const uint32_t g2 = std::max(1u, std::min(grid_in, pt_grid_));
         uint32_t* work = &counters_.p[any ? C_WORK_SHADOW : C_WORK_CLOSEST];
-        if (any) hipLaunchKernelGGL((k_trace_pt_f32<true>), dim3(g2), dim3(kPtBlock), 0, st_, t2, pool_, queue, count, n_fixed, work, occluded, lo_pt, 0xffffffffu);
-        else hipLaunchKernelGGL((k_trace_pt_f32<false>), dim3(g2), dim3(kPtBlock), 0, st_, t2, pool_, queue, count, n_fixed, work, occluded, lo_pt, 0xffffffffu);
+        if (any) hipLaunchKernelGGL((k_trace_pt_f32<true>), dim3(g2), dim3(kPtBlock), 0, stream, t2, pool_, queue, count, n_fixed, work, occluded, lo_pt, 0xffffffffu);
+        else hipLaunchKernelGGL((k_trace_pt_f32<false>), dim3(g2), dim3(kPtBlock), 0, stream, t2, pool_, queue, count, n_fixed, work, occluded, lo_pt, 0xffffffffu);
       }
       if (trav_mode_ != 2) {
-        if (any) hipLaunchKernelGGL((k_trace_pairs_f32<true>), dim3(grid), dim3(kTravBlock), 0, st_, trav_, pool_, queue, count, n_fixed, occluded, 0u, hi_gs);
-        else hipLaunchKernelGGL((k_trace_pairs_f32<false>), dim3(grid), dim3(kTravBlock), 0, st_, trav_, pool_, queue, count, n_fixed, occluded, 0u, hi_gs);
+        if (any) hipLaunchKernelGGL((k_trace_pairs_f32<true>), dim3(grid), dim3(kTravBlock), 0, stream, trav_, pool_, queue, count, n_fixed, occluded, 0u, hi_gs);
+        else hipLaunchKernelGGL((k_trace_pairs_f32<false>), dim3(grid), dim3(kTravBlock), 0, stream, trav_, pool_, queue, count, n_fixed, occluded, 0u, hi_gs);
       }
       HIP_CHECK(hipGetLastError());
     }
@@ -937,17 +995,18 @@ class Handle : public HandleBase {
       pairs_ok_ = true;
     }
   }
-  void launch_shadow(uint32_t grid) {
-    if (!count_traversal_ && use_persistent()) { launch_persistent(true, nullptr, &counters_.p[C_SHADOW], 0, grid, nullptr); return; }
+  void launch_shadow(uint32_t grid, hipStream_t stream = nullptr) {
+    if (!stream) stream = st_;
+    if (!count_traversal_ && use_persistent()) { launch_persistent(true, nullptr, pool_.shadow_count, 0, grid, nullptr, stream); return; }
     uint32_t* ds = deep_ ? deep_stack_.p : nullptr;
     const uint32_t stride = deep_ ? (uint32_t)cap_ : 0u;
     unsigned long long* tot = count_traversal_ ? totals_.p + 5 : nullptr;
     if (deep_) {
-      if (count_traversal_) hipLaunchKernelGGL((k_shadow<R, true, true>), dim3(grid), dim3(kBlock), 0, st_, scene_, pool_, (const uint32_t*)nullptr, &counters_.p[C_SHADOW], ds, stride, tot);
-      else hipLaunchKernelGGL((k_shadow<R, true, false>), dim3(grid), dim3(kBlock), 0, st_, scene_, pool_, (const uint32_t*)nullptr, &counters_.p[C_SHADOW], ds, stride, tot);
+      if (count_traversal_) hipLaunchKernelGGL((k_shadow<R, true, true>), dim3(grid), dim3(kBlock), 0, stream, scene_, pool_, (const uint32_t*)nullptr, pool_.shadow_count, ds, stride, tot);
+      else hipLaunchKernelGGL((k_shadow<R, true, false>), dim3(grid), dim3(kBlock), 0, stream, scene_, pool_, (const uint32_t*)nullptr, pool_.shadow_count, ds, stride, tot);
     } else {
-      if (count_traversal_) hipLaunchKernelGGL((k_shadow<R, false, true>), dim3(grid), dim3(kBlock), 0, st_, scene_, pool_, (const uint32_t*)nullptr, &counters_.p[C_SHADOW], ds, stride, tot);
-      else hipLaunchKernelGGL((k_shadow<R, false, false>), dim3(grid), dim3(kBlock), 0, st_, scene_, pool_, (const uint32_t*)nullptr, &counters_.p[C_SHADOW], ds, stride, tot);
+      if (count_traversal_) hipLaunchKernelGGL((k_shadow<R, false, true>), dim3(grid), dim3(kBlock), 0, stream, scene_, pool_, (const uint32_t*)nullptr, pool_.shadow_count, ds, stride, tot);
+      else hipLaunchKernelGGL((k_shadow<R, false, false>), dim3(grid), dim3(kBlock), 0, stream, scene_, pool_, (const uint32_t*)nullptr, pool_.shadow_count, ds, stride, tot);
     }
     HIP_CHECK(hipGetLastError());
   }

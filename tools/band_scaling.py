@@ -7,6 +7,9 @@ wd = tempfile.mkdtemp()
 cfg, root = scenes.cfg4(wd)
 sc = Scene.loads(cfg, root, flags=RRT_FIXED_BVH)
 r = Renderer(sc, 0, RRT_F32)
+for kv in sys.argv[1:]:      # handle options, e.g. pt_split_closest=0
+    k, v = kv.split("=")
+    r.set_option(k, float(v))
 film = torch.zeros((1024, 1024, 4), dtype=torch.float32, device="cuda:0")
 for n in (1, 2, 4, 8):
     for _ in range(2):
