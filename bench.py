@@ -76,6 +76,9 @@ def main():
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--max-paths", type=int, default=0)
     ap.add_argument("--opt", action="append", default=[], help="handle option key=value (rrt_set_option), e.g. pt_split_any=1e9")
+    ap.add_argument("--frames-in-flight", type=int, default=2, choices=(1, 2),
+                    help="2: alternate two handles (rrt_render_bands_begin / _end): a frame's latency-bound last bounces drain "
+                         "while the next frame's camera rays fill the chip; 1: one synchronous frame at a time")
     args = ap.parse_args()
 
     import numpy as np
@@ -106,20 +109,46 @@ def main():
     scene = Scene.loads(cfg, root, flags=flags)
     t_build = time.time() - t0
     W, H = scene.resolution
-    r = Renderer(scene, local_rank, RRT_F32)
-    if args.max_paths:
-        r.set_option("max_paths", args.max_paths)
-    for kv in args.opt:
-        k, v = kv.split("=")
-        r.set_option(k, float(v))
-    film = torch.zeros((H, W, 4), dtype=torch.float32, device=f"cuda:{local_rank}")
+    nfl = args.frames_in_flight
+    handles = [Renderer(scene, local_rank, RRT_F32) for _ in range(nfl)]
+    for h in handles:
+        if args.max_paths:
+            h.set_option("max_paths", args.max_paths)
+        for kv in args.opt:
+            k, v = kv.split("=")
+            h.set_option(k, float(v))
+        if nfl > 1:
+            h.set_option("nonblocking_streams", 1)   # frames of the two handles may overlap; ordering with torch's stream is explicit below
+    r = handles[0]
+    films = [torch.zeros((H, W, 4), dtype=torch.float32, device=f"cuda:{local_rank}") for _ in range(nfl)]
+    film = films[0]
 
     def step(collect=False):
         film.zero_()
+        torch.cuda.current_stream().synchronize()
         st = r.render_bands_device(rank, world, film.data_ptr(), stats=collect)
         agg = {k: getattr(st, k) for k, _ in st._fields_} if collect else None
         reduce_film(film, world)  # disjoint bands: the sum reassembles the frame on rank 0 (RCCL over xGMI)
         return agg
+
+    def run_frames(n):
+        """n frames (steps), at most `nfl` in flight: frame i renders on handle i % nfl while frame i - 1 finishes on the other one;
+        each frame ends with its film reduced to rank 0, all inside the caller's timed region."""
+        if nfl == 1:
+            for _ in range(n):
+                step()
+            return
+        for i in range(n):
+            k = i % nfl
+            if i >= nfl:
+                handles[k].render_end()
+                reduce_film(films[k], world)
+            films[k].zero_()                              # (ordered after that film's previous reduce on torch's stream)
+            torch.cuda.current_stream().synchronize()     # the handle's streams do not wait for torch's stream
+            handles[k].render_bands_begin(rank, world, films[k].data_ptr())
+        for i in range(max(0, n - nfl), n):
+            handles[i % nfl].render_end()
+            reduce_film(films[i % nfl], world)
 
     def sync():
         torch.cuda.synchronize()
@@ -131,22 +160,26 @@ def main():
     r.set_option("count_traversal", 1)
     counted = step(collect=True)
     r.set_option("count_traversal", 0)
-    for _ in range(args.warmup):
-        step()
+    run_frames(max(args.warmup, nfl if nfl > 1 else 0))   # (at least one untimed frame per handle: pool allocation)
     sync()
     t0 = time.perf_counter()
-    for _ in range(args.steps):
-        step()
+    run_frames(args.steps)
     sync()
     elapsed = time.perf_counter() - t0
     # per-kernel durations with HIP events on the handle's stream (one extra frame, after the timed region)
     timed = step(collect=True)
     sync()
+    # the same frame with the shadow launches back on the main stream: the closest-hit kernel alone on the chip
+    r.set_option("overlap_shadow", 0)
+    step()
+    isolated = step(collect=True)
+    r.set_option("overlap_shadow", 1)
+    sync()
 
     tt = torch.tensor([elapsed], dtype=torch.float64, device=f"cuda:{local_rank}")
     keys = ["camera_samples", "camera_rays", "closest_queries", "any_queries", "closest_nodes", "closest_prims", "any_nodes", "any_prims", "closest_launches"]
     counted["closest_launches"] = timed["closest_launches"]
-    cnt = torch.tensor([float(counted[k]) for k in keys] + [timed["ms_closest"], timed["ms_any"], timed["ms_shade"], timed["ms_raygen"], timed["ms_film"], timed["ms_total"]],
+    cnt = torch.tensor([float(counted[k]) for k in keys] + [timed["ms_closest"], timed["ms_any"], timed["ms_shade"], timed["ms_raygen"], timed["ms_film"], timed["ms_total"], isolated["ms_closest"]],
                        dtype=torch.float64, device=f"cuda:{local_rank}")
     if world > 1:
         dist.all_reduce(tt, op=dist.ReduceOp.MAX)
@@ -156,7 +189,7 @@ def main():
     else:
         mx = cnt
     elapsed = float(tt.item())
-    names = keys + ["ms_closest", "ms_any", "ms_shade", "ms_raygen", "ms_film", "ms_total"]
+    names = keys + ["ms_closest", "ms_any", "ms_shade", "ms_raygen", "ms_film", "ms_total", "ms_closest_isolated"]
     tot = dict(zip(names, cnt.tolist()))
     mx_tot = dict(zip(names, mx.tolist()))
 
@@ -185,6 +218,11 @@ def main():
                     "frac": round(achieved / HBM_PEAK_GBS, 4), "traffic": traffic,
                     "algorithmic_bytes_per_launch": round(bytes_closest / n_launch, 1),
                     "avg_launch_ms": round(ms_closest * world / n_launch, 4), "launches": int(n_launch),
+                    # `achieved` is timed as the frame really runs: every closest-hit launch but the first shares the chip with the
+                    # previous bounce's shadow launch (second stream). `alone`: the same launches with that overlap switched off.
+                    "alone": {"achieved": round((bytes_closest / world) / (mx_tot["ms_closest_isolated"] * 1e-3) / 1e9, 2),
+                              "frac": round((bytes_closest / world) / (mx_tot["ms_closest_isolated"] * 1e-3) / 1e9 / HBM_PEAK_GBS, 4),
+                              "avg_launch_ms": round(mx_tot["ms_closest_isolated"] * world / n_launch, 4)},
                     "bytes_per_query": round(bytes_closest / max(1.0, tot["closest_queries"]), 1),
                     "nodes_per_query": round(tot["closest_nodes"] / max(1.0, tot["closest_queries"]), 2),
                     "tris_per_query": round(tot["closest_prims"] / max(1.0, tot["closest_queries"]), 2)}
@@ -196,8 +234,8 @@ def main():
             "value": round(value, 3), "unit": "Mrays/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
             "ms_per_step": round(ms_per_step, 3), "higher_is_better": True, "scaling": "strong", "vs_baseline": None,
             "dtype": "f32", "data": "synthetic",
-            "config": {"workload": "BASELINE cfg4: procedural heightfield %d triangles, %dx%d, %d spp, Path max_depth %d, HaltonSampler, RealisticCamera, box filter; %s BVH; film in interleaved 16-row bands, RCCL reduce to rank 0" % (
-                scene.desc.n_prims, W, H, args.spp, args.depth, "reference-exact (Q26/Q27)" if args.compat_bvh else "fixed-bvh"),
+            "config": {"workload": "BASELINE cfg4: procedural heightfield %d triangles, %dx%d, %d spp, Path max_depth %d, HaltonSampler, RealisticCamera, box filter; %s BVH; film in interleaved 16-row bands, RCCL reduce to rank 0; %d frame(s) in flight" % (
+                scene.desc.n_prims, W, H, args.spp, args.depth, "reference-exact (Q26/Q27)" if args.compat_bvh else "fixed-bvh", nfl),
                 "triangles": int(scene.desc.n_prims), "bvh_nodes": int(scene.desc.n_bvh_nodes), "bvh_depth": int(scene.desc.bvh_depth)},
             "roofline": roofline, "cpu_baseline": cpu,
             "camera_mrays_per_s": round(tot["camera_rays"] / (ms_per_step * 1e-3) / 1e6, 3),

@@ -325,6 +325,16 @@ int rrt_render_rect(rrt_handle*, const int32_t rect[4], void* film_xyzw, int fil
  * the ranks' films (one RCCL reduce) reassembles Film::pixels. */
 int rrt_render_bands(rrt_handle*, int rank, int world, void* film_xyzw, int film_mem, rrt_render_stats* stats);
 
+/* Frames in flight (no counterpart in the reference, whose si_render returns with the frame done): _begin enqueues
+ * rrt_render_bands on the handle's stream for a DEVICE film and returns; _end waits for that frame and reports what
+ * rrt_render_bands would have returned (RRT_EPANIC ...). One frame per handle; a second handle on the same GPU can
+ * render the next frame meanwhile, which hides the latency-bound last bounces of one frame behind the camera rays of
+ * the next. The film must stay untouched by the caller between the two calls. For the frames of two handles to overlap,
+ * both need rrt_set_option("nonblocking_streams", 1): the handle's streams then no longer synchronise with the legacy
+ * default stream, so work the caller issued there on the film (a memset ...) must be finished before _begin. */
+int rrt_render_bands_begin(rrt_handle*, int rank, int world, void* film_xyzw_device);
+int rrt_render_end(rrt_handle*);
+
 /* handle options: "max_paths" (wavefront pool slots; default 2^28 clamped to half of the free HBM), "count_traversal"
  * (exact node / triangle-test counters in rrt_render_stats, generic kernels), "persistent_traversal" (fp32: 0 generic
  * kernels, 1 grid-stride pair-node kernel, 2 persistent-thread kernel, 3 = default, by queue size), "pt_split_closest" /

@@ -159,6 +159,8 @@ PROTOTYPES = {
                                      C.c_void_p, C.c_void_p]),
     "rrt_render_rect": (C.c_int, [C.c_void_p, C.POINTER(C.c_int32), C.c_void_p, C.c_int, C.POINTER(RenderStats)]),
     "rrt_render_bands": (C.c_int, [C.c_void_p, C.c_int, C.c_int, C.c_void_p, C.c_int, C.POINTER(RenderStats)]),
+    "rrt_render_bands_begin": (C.c_int, [C.c_void_p, C.c_int, C.c_int, C.c_void_p]),
+    "rrt_render_end": (C.c_int, [C.c_void_p]),
     "rrt_set_option": (C.c_int, [C.c_void_p, C.c_char_p, C.c_double]),
     "rrt_last_error": (C.c_char_p, []),
     "rrt_version": (C.c_char_p, []),

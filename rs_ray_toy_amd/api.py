@@ -171,6 +171,13 @@ class Renderer:
         _check(A.lib().rrt_render_bands(self._h, rank, world, film_ptr, A.RRT_MEM_DEVICE, C.byref(st) if stats else None))
         return st
 
+    def render_bands_begin(self, rank, world, film_ptr):
+        """Enqueue render_bands_device and return (frames in flight, see rrt_render_bands_begin); pair with render_end()."""
+        _check(A.lib().rrt_render_bands_begin(self._h, rank, world, film_ptr))
+
+    def render_end(self):
+        _check(A.lib().rrt_render_end(self._h))
+
     def render_bands(self, rank, world, film=None):
         W, H = self.scene.resolution
         if film is None:

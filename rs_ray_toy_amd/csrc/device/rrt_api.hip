@@ -85,6 +85,16 @@ int rrt_render_bands(rrt_handle* h, int rank, int world, void* film_xyzw, int fi
   return guarded([&]() { h->impl->render_bands(rank, world, film_xyzw, film_mem, stats); });
 }
 
+int rrt_render_bands_begin(rrt_handle* h, int rank, int world, void* film_xyzw_device) {
+  if (!h || !film_xyzw_device) { rrt::set_last_error("rrt_render_bands_begin: null argument"); return RRT_EINVAL; }
+  return guarded([&]() { h->impl->render_bands_begin(rank, world, film_xyzw_device); });
+}
+
+int rrt_render_end(rrt_handle* h) {
+  if (!h) { rrt::set_last_error("rrt_render_end: null argument"); return RRT_EINVAL; }
+  return guarded([&]() { h->impl->render_end(); });
+}
+
 int rrt_set_option(rrt_handle* h, const char* key, double value) {
   if (!h || !key) { rrt::set_last_error("rrt_set_option: null argument"); return RRT_EINVAL; }
   return guarded([&]() { h->impl->set_option(key, value); });

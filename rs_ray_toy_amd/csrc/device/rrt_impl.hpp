@@ -38,6 +38,8 @@ struct HandleBase {
   virtual void camera_samples(const int32_t rect[4], uint64_t s0, uint64_t s1, double* dims5, double* ray_od6, double* weight) = 0;
   virtual void render_rect(const int32_t rect[4], void* film, int film_mem, rrt_render_stats* stats) = 0;
   virtual void render_bands(int rank, int world, void* film, int film_mem, rrt_render_stats* stats) = 0;
+  virtual void render_bands_begin(int rank, int world, void* film_device) = 0;
+  virtual void render_end() = 0;
   virtual void set_option(const std::string& key, double v) = 0;
 };
 
@@ -115,12 +117,7 @@ class Handle : public HandleBase {
  public:
   Handle(int device, const rrt_scene_desc* d) : dev_(device), desc_(*d) {
     HIP_CHECK(hipSetDevice(dev_));
-    {   // the main stream carries the critical path (closest-hit -> shade); shadow rays fill what it leaves idle
-      int lo = 0, hi = 0;
-      HIP_CHECK(hipDeviceGetStreamPriorityRange(&lo, &hi));
-      HIP_CHECK(hipStreamCreateWithPriority(&st_, hipStreamDefault, hi));
-      HIP_CHECK(hipStreamCreateWithPriority(&st2_, hipStreamDefault, lo));
-    }
+    create_streams(hipStreamDefault);
     HIP_CHECK(hipEventCreateWithFlags(&ev_shade_, hipEventDisableTiming));
     for (int k = 0; k < 2; k++) HIP_CHECK(hipEventCreateWithFlags(&ev_shadow_[k], hipEventDisableTiming));
     upload_scene(d);
@@ -151,6 +148,11 @@ class Handle : public HandleBase {
     else if (key == "pt_split_closest") pt_split_closest_ = (uint32_t)v;
     else if (key == "pt_split_any") pt_split_any_ = (uint32_t)v;
     else if (key == "overlap_shadow") overlap_shadow_ = v != 0;
+    else if (key == "nonblocking_streams") {   // see rrt.h: needed for two handles to overlap their frames
+      if (pending_) throw std::invalid_argument("nonblocking_streams: a frame is in flight");
+      HIP_CHECK(hipSetDevice(dev_));
+      create_streams(v != 0 ? hipStreamNonBlocking : hipStreamDefault);
+    }
     else throw std::invalid_argument("unknown option " + key);
   }
 
@@ -229,6 +231,37 @@ class Handle : public HandleBase {
     render_impl(rect, 1u << 30, 1, 0, film_user, film_mem, stats);
   }
   // rows of the interleaved 16-row bands b with b % world == rank (partition.py), as ONE pixel set
+  // the main stream carries the critical path (closest-hit -> shade); shadow rays fill what it leaves idle
+  void create_streams(unsigned flags) {
+    if (st_) { HIP_CHECK(hipStreamSynchronize(st_)); HIP_CHECK(hipStreamSynchronize(st2_)); (void)hipStreamDestroy(st2_); (void)hipStreamDestroy(st_); }
+    int lo = 0, hi = 0;
+    HIP_CHECK(hipDeviceGetStreamPriorityRange(&lo, &hi));
+    HIP_CHECK(hipStreamCreateWithPriority(&st_, flags, hi));
+    HIP_CHECK(hipStreamCreateWithPriority(&st2_, flags, lo));
+  }
+  // frames in flight: enqueue a frame and return; render_end() waits for it and reports its panics. A second handle can
+  // render the next frame meanwhile - its camera rays fill the chip while this frame's last, latency-bound bounces drain.
+  void render_bands_begin(int rank, int world, void* film_device) override {
+    if (pending_) throw std::invalid_argument("render_bands_begin: the previous frame was not ended");
+    defer_ = true;
+    try { render_bands(rank, world, film_device, RRT_MEM_DEVICE, nullptr); } catch (...) { defer_ = false; throw; }
+    defer_ = false;
+    pending_ = true;
+  }
+  void render_end() override {
+    if (!pending_) return;
+    pending_ = false;
+    HIP_CHECK(hipSetDevice(dev_));
+    HIP_CHECK(hipStreamSynchronize(st_));
+    check_device_errors();
+  }
+  void check_device_errors() {
+    uint32_t err = 0;
+    HIP_CHECK(hipMemcpy(&err, counters_.p + C_ERROR, sizeof(err), hipMemcpyDeviceToHost));
+    if (err & ERR_SHADING_NORMAL) throw PanicError("primitives.rs:66 assert!(dot3(&si.ist.n, &si.shading.n) >= 0.0) (vertex normals oppose the winding, Q14)");
+    if (err & ERR_NULL_BSDF) throw PanicError("glass.rs:70 / translucent.rs:66 null BSDF (textures evaluate to black): path.rs:103 `bounces -= 1` underflows");
+    if (err & ERR_BETA) throw PanicError("path.rs:146 assert!(beta.y() > 0.0 && beta.y().is_finite())");
+  }
   void render_bands(int rank, int world, void* film_user, int film_mem, rrt_render_stats* stats) override {
     if (world < 1 || rank < 0 || rank >= world) throw std::invalid_argument("render_bands: bad rank/world");
     const int32_t full[4] = {0, 0, desc_.film.xres, desc_.film.yres};
@@ -398,6 +431,7 @@ class Handle : public HandleBase {
     if (film_mem == RRT_MEM_DEVICE) {
       hipLaunchKernelGGL((k_film_add<R>), dim3((uint32_t)((nfilm + kBlock - 1) / kBlock)), dim3(kBlock), 0, st_, (const R*)film_.p, (R*)film_user, nfilm);
       HIP_CHECK(hipGetLastError());
+      if (defer_) return;   // render_end() synchronises and checks the error flags
       HIP_CHECK(hipStreamSynchronize(st_));
     } else {
       std::vector<R> tmp(nfilm);
@@ -410,9 +444,7 @@ class Handle : public HandleBase {
     unsigned long long ht[8];
     HIP_CHECK(hipMemcpy(hc, counters_.p, sizeof(hc), hipMemcpyDeviceToHost));
     HIP_CHECK(hipMemcpy(ht, totals_.p, sizeof(ht), hipMemcpyDeviceToHost));
-    if (hc[C_ERROR] & ERR_SHADING_NORMAL) throw PanicError("primitives.rs:66 assert!(dot3(&si.ist.n, &si.shading.n) >= 0.0) (vertex normals oppose the winding, Q14)");
-    if (hc[C_ERROR] & ERR_NULL_BSDF) throw PanicError("glass.rs:70 / translucent.rs:66 null BSDF (textures evaluate to black): path.rs:103 `bounces -= 1` underflows");
-    if (hc[C_ERROR] & ERR_BETA) throw PanicError("path.rs:146 assert!(beta.y() > 0.0 && beta.y().is_finite())");
+    check_device_errors();
     if (stats) {
       memset(stats, 0, sizeof(*stats));
       stats->camera_samples = (uint64_t)rpix * s_total;
@@ -448,6 +480,7 @@ class Handle : public HandleBase {
   hipEvent_t ev_shade_ = nullptr, ev_shadow_[2] = {nullptr, nullptr};
   typename Vec4T<R>::type* shadow_buf_[2][3] = {{nullptr, nullptr, nullptr}, {nullptr, nullptr, nullptr}};
   bool overlap_shadow_ = true;
+  bool defer_ = false, pending_ = false;   // render_bands_begin / render_end
   SceneDev<R> scene_{};
   Pools<R> pool_{};
   size_t cap_ = 0;

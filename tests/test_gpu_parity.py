@@ -238,6 +238,37 @@ def test_render_rect_and_passes_are_consistent(workdir):
     np.testing.assert_allclose(small, full, rtol=1e-12, atol=1e-15)
 
 
+def test_frames_in_flight_match_synchronous_frames(workdir):
+    """rrt_render_bands_begin / rrt_render_end: two handles with a frame each in flight (non-blocking streams) produce the
+    films of the synchronous call bit for bit; a second _begin on a busy handle is refused."""
+    import torch
+    from rs_ray_toy_amd import RrtError
+    cfg, root = scenes.cfg4(workdir, xres=96, yres=96, nsamp=9, max_depth=6, n=48)
+    sc = Scene.loads(cfg, root)
+    hs = [Renderer(sc, 0, RRT_F32) for _ in range(2)]
+    ref = [torch.zeros((96, 96, 4), dtype=torch.float32, device="cuda:0") for _ in range(2)]
+    for k in range(2):
+        hs[0].render_bands_device(k, 2, ref[k].data_ptr(), stats=False)
+    for h in hs:
+        h.set_option("nonblocking_streams", 1)
+    films = [torch.zeros((96, 96, 4), dtype=torch.float32, device="cuda:0") for _ in range(2)]
+    torch.cuda.synchronize()
+    for rep in range(3):                      # += into the same films: 3 x the frame
+        for k in range(2):
+            hs[k].render_end()
+            hs[k].render_bands_begin(k, 2, films[k].data_ptr())
+    with pytest.raises(RrtError):
+        hs[0].render_bands_begin(0, 2, films[0].data_ptr())
+    for h in hs:
+        h.render_end()
+    torch.cuda.synchronize()
+    for k in range(2):
+        assert torch.equal(films[k], ref[k] * 3.0)
+        assert ref[k].abs().sum() > 0
+    for h in hs:
+        h.close()
+
+
 def test_render_bands_partition_sums_to_the_frame(workdir):
     """rrt_render_bands: the ranks' interleaved 16-row bands are disjoint and sum to the full frame (world 1, 3)."""
     cfg, root = scenes.cfg2(workdir, xres=48, yres=72, nsamp=5, max_depth=3)

@@ -1,0 +1,27 @@
+"""One frame at a time against two frames in flight (two handles, rrt_render_bands_begin / _end) for rank 0 of N bands."""
+import sys, tempfile, time
+sys.path.insert(0, '.')
+import torch
+from rs_ray_toy_amd import Scene, scenes, Renderer, RRT_F32, RRT_FIXED_BVH
+wd = tempfile.mkdtemp()
+cfg, root = scenes.cfg4(wd)
+sc = Scene.loads(cfg, root, flags=RRT_FIXED_BVH)
+rs = [Renderer(sc, 0, RRT_F32) for _ in range(2)]
+for r in rs: r.set_option("nonblocking_streams", 1)
+films = [torch.zeros((1024, 1024, 4), dtype=torch.float32, device="cuda:0") for _ in range(2)]
+for n in ([int(a) for a in sys.argv[1:]] or [1, 2, 4, 8]):
+    for nh in (1, 2):
+        for i in range(4):
+            rs[i % nh].render_bands_device(0, n, films[i % nh].data_ptr(), stats=False)
+        torch.cuda.synchronize()
+        t0 = time.perf_counter()
+        K = 10
+        for i in range(K):
+            if nh == 1: rs[0].render_bands_device(0, n, films[0].data_ptr(), stats=False)
+            else:
+                rs[i % nh].render_end()
+                rs[i % nh].render_bands_begin(0, n, films[i % nh].data_ptr())
+        for r in rs: r.render_end()
+        torch.cuda.synchronize()
+        dt = (time.perf_counter() - t0) / K * 1e3
+        print(f"N={n} handles={nh}: {dt:.2f} ms per rank-frame")

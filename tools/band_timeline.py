@@ -5,7 +5,7 @@ rows.sort(key=lambda r: int(r["Start_Timestamp"]))
 name = lambda r: re.sub(r"\(.*", "", r["Kernel_Name"]).replace("void ", "").replace("rrtd::", "")
 # a frame starts at its k_sample_f32 / k_raygen launch
 starts = [i for i, r in enumerate(rows) if name(r).startswith("k_sample_f32") or name(r).startswith("k_raygen<")]
-rows = rows[starts[-1]:]
+rows = rows[starts[-int(sys.argv[2]) if len(sys.argv) > 2 else -1]:]
 t0 = int(rows[0]["Start_Timestamp"])
 end_prev = t0
 for r in rows:
