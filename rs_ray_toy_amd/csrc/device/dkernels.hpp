@@ -1276,11 +1276,10 @@ __global__ void __launch_bounds__(kBlock) k_film_box(SceneDev<R> s, Pools<R> p, 
   uint32_t px_, py_;
   pass_pixel(pd, pd.pix_begin + pl, &px_, &py_);
   const uint32_t pix = py_ * (uint32_t)s.xres + px_;
-  for (uint32_t sl = 0; sl < pd.ns; sl++) {
-    const uint32_t slot = sl * pd.npix + pl;
-    const R w = p.weight[slot];
+  constexpr uint32_t kBatch = 8;   // independent loads in flight per thread: a band of a frame has too few pixels to hide the latency otherwise
+  auto add = [&](R w, const typename Vec4T<R>::type& l) {
     Rgb<R> L;
-    if (w > R(0)) { const typename Vec4T<R>::type l = p.L[slot]; L = Rgb<R>(l.x, l.y, l.z); }   // dead samples: L = 0, w = 0 (Q2)
+    if (w > R(0)) L = Rgb<R>(l.x, l.y, l.z);   // dead samples: L = 0, w = 0 (Q2); their record is never initialised
     // integrator/mod.rs:105-122
     if (L.has_nan()) L = Rgb<R>();
     else if (L.y() < R(-1e-5)) L = Rgb<R>();
@@ -1288,6 +1287,24 @@ __global__ void __launch_bounds__(kBlock) k_film_box(SceneDev<R> s, Pools<R> p, 
     if (L.y() > s.max_sample_luminance) L = L * (s.max_sample_luminance / L.y());
     cr += (L.r * w) * R(1); cg += (L.g * w) * R(1); cb += (L.b * w) * R(1);  // box filter table weight 1
     wsum += R(1);
+  };
+  uint32_t sl = 0;
+  // few pixels (a band of a frame): latency-bound, batch the loads; many pixels: bandwidth-bound, and seven samples in ten are
+  // dead on the 100k-triangle config, so their L records are better left unread
+  if (pd.npix < (1u << 18))
+  for (; sl + kBatch <= pd.ns; sl += kBatch) {   // samples are added in sample order, as the tile loop does
+    R wb[kBatch];
+    typename Vec4T<R>::type lb[kBatch];
+#pragma unroll
+    for (uint32_t k = 0; k < kBatch; k++) { wb[k] = p.weight[(sl + k) * pd.npix + pl]; lb[k] = p.L[(sl + k) * pd.npix + pl]; }
+#pragma unroll
+    for (uint32_t k = 0; k < kBatch; k++) add(wb[k], lb[k]);
+  }
+  for (; sl < pd.ns; sl++) {
+    const R w = p.weight[sl * pd.npix + pl];
+    typename Vec4T<R>::type l = mk4<R>(R(0), R(0), R(0), R(0));
+    if (w > R(0)) l = p.L[sl * pd.npix + pl];
+    add(w, l);
   }
   // rgb_to_xyz spectrum.rs:2084-2090; filter_weight_sum is added three times per merged tile pixel (Q3)
   R* px = film + 4 * (size_t)pix;
