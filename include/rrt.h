@@ -32,7 +32,7 @@
 extern "C" {
 #endif
 
-#define RRT_ABI_VERSION 4
+#define RRT_ABI_VERSION 5
 
 /* ---- error codes ------------------------------------------------------- */
 enum {
@@ -106,17 +106,19 @@ typedef struct rrt_prim {
 /* Texture graph (texture/ module, built by make_textures renderprocess.rs:298-515). Float and rgb textures share one
  * array; a float texture carries its value in all three channels. Children are indices of textures created EARLIER
  * (the reference captures the Arc at creation time, so a later texture of the same name does not rebind them), or -1
- * with the fallback constant in `fallback[]`. ImageTexture (needs the `image` crate's decoders + MIPMap) is not part
- * of the graph: a material that uses one is RRT_EUNSUP. */
+ * with the fallback constant in `fallback[]`. ImageTexture: 8-bit non-interlaced PNG files (other formats / depths of
+ * the `image` crate are RRT_EUNSUP where a material uses the texture), as the MIPMap of mipmap.rs in `images[]`. */
 enum { RRT_TEX_CONSTANT = 0, RRT_TEX_MIX = 1, RRT_TEX_BILERP = 2, RRT_TEX_CHECKER2D = 3, RRT_TEX_CHECKER3D = 4,
-       RRT_TEX_SCALE = 5, RRT_TEX_WINDY = 6, RRT_TEX_WRINKLED = 7, RRT_TEX_UV = 8 };
+       RRT_TEX_SCALE = 5, RRT_TEX_WINDY = 6, RRT_TEX_WRINKLED = 7, RRT_TEX_UV = 8, RRT_TEX_IMAGE = 9 };
+enum { RRT_WRAP_REPEAT = 0, RRT_WRAP_BLACK = 1, RRT_WRAP_CLAMP = 2 };   /* ImageWrap mipmap.rs:50-55 */
 enum { RRT_MAP_UV = 0, RRT_MAP_SPHERICAL = 1, RRT_MAP_CYLINDRICAL = 2, RRT_MAP_PLANAR = 3, RRT_MAP_IDENTITY3D = 4 };
 typedef struct rrt_texture {
   int32_t type;            /* RRT_TEX_*                                                              */
   int32_t mapping;         /* RRT_MAP_* (texture/mod.rs:205-374)                                     */
   int32_t child[3];        /* t1, t2, amount (Mix) -> textures[] index or -1                         */
   int32_t aa_none;         /* Checkerboard2D: aamode == "none" (checkerboard.rs:13-16)               */
-  int32_t octaves, pad;    /* Wrinkled                                                               */
+  int32_t octaves;         /* Wrinkled                                                               */
+  int32_t image;           /* IMAGE: index into rrt_scene_desc.images                                */
   double fallback[3][3];   /* get_text_fallback's ConstantTexture per child (renderprocess.rs:282-296) */
   double v[4][3];          /* CONSTANT: v[0]; BILERP: v00, v01, v10, v11                              */
   double omega;            /* Wrinkled                                                               */
@@ -125,6 +127,19 @@ typedef struct rrt_texture {
   double world_to_texture[16];   /* SPHERICAL, CYLINDRICAL: inverse(to_world); IDENTITY3D: to_world itself
                                     (renderprocess.rs:368,384,388 pass `to_world` as world_to_texture) */
 } rrt_texture;
+
+/* MIPMap (mipmap.rs:70-96) as MIPMap::create (:270-382) leaves it. Each pyramid level is the BlockedArray's own
+ * `data` vector (memory.rs:24-98): texel (u, v) lives at
+ *     16 * (u_blocks * (v & 3) + (u & 3)) + 4 * (v >> 2) + (u >> 2)
+ * - the index expression of memory.rs:76-85, which swaps pbrt's block / offset roles, so texels alias each other and the
+ * level holds whatever was written last at each cell. Lookups go through the same expression. */
+typedef struct rrt_image_level { uint32_t u_res, v_res, u_blocks, pad; uint64_t offset, n; /* RGB triples in image_texels */ } rrt_image_level;
+typedef struct rrt_image {
+  int32_t do_trilinear, wrap;   /* RRT_WRAP_* */
+  double max_aniso;
+  int32_t n_levels, pad;
+  rrt_image_level levels[16];
+} rrt_image;
 
 /* material parameter slots of rrt_material.tex[] */
 enum { RRT_P_KD = 0, RRT_P_KS, RRT_P_KR, RRT_P_ETA, RRT_P_K, RRT_P_SIGMA, RRT_P_ROUGHNESS, RRT_P_UROUGHNESS,
@@ -226,7 +241,9 @@ typedef struct rrt_scene_desc {
   const rrt_xform* xforms;   size_t n_xforms;
   const rrt_prim* prims;     size_t n_prims;     /* aggregate input order, renderprocess.rs:1178-1304 */
   const rrt_material* materials; size_t n_materials;
-  const rrt_texture* textures;   size_t n_textures;    /* only the textures some material evaluates per hit */
+  const rrt_texture* textures;   size_t n_textures;    /* every declared texture, declaration order */
+  const rrt_image* images;       size_t n_images;
+  const double* image_texels;    size_t n_image_texels;   /* RGB triples of all pyramid levels */
   const rrt_light* lights;   size_t n_lights;    /* scene.lights; infinite_lights unsupported */
   /* BVHAccel, bvh.rs:116-121 */
   const rrt_bvh_node* bvh_nodes; size_t n_bvh_nodes;

@@ -318,3 +318,113 @@ def bound_exit_pupil(elems, x0, x1, n_samples=1024 * 1024):
     delta = 2.0 * math.sqrt(2.0 * (hi - lo) ** 2) / math.sqrt(n_samples)
     a, b = (mnx - delta, mny - delta), (mxx - delta, mxy - delta)
     return [min(a[0], b[0]), min(a[1], b[1]), max(a[0], b[0]), max(a[1], b[1])]
+
+
+# ---- ImageTexture on the host: load_image (renderprocess.rs:532-561) + MIPMap::create (mipmap.rs:270-382) over the
+# ---- BlockedArray of memory.rs:24-98, restated with numpy for tests/test_host.py ------------------------------------------
+def ba_index(u_blocks, u, v):
+    """BlockedArray's index expression memory.rs:76-85 (block and offset swapped relative to pbrt: texels alias)."""
+    return 16 * (u_blocks * (v & 3) + (u & 3)) + 4 * (v >> 2) + (u >> 2)
+
+
+class BlockedLevel:
+    def __init__(self, u_res, v_res):
+        self.u_res, self.v_res = u_res, v_res
+        self.u_blocks = ((u_res + 3) & ~3) >> 2
+        self.data = np.zeros((((u_res + 3) & ~3) * ((v_res + 3) & ~3), 3))
+
+    def set(self, u, v, rgb):
+        self.data[ba_index(self.u_blocks, u, v)] = rgb
+
+    def get(self, u, v):
+        return self.data[ba_index(self.u_blocks, u, v)]
+
+
+def _usize(v):
+    return 0 if not (v > 0.0) else int(v)
+
+
+def _lanczos(x, tau):
+    x = abs(x)
+    if x < 1e-5:
+        return 1.0
+    if x > 1.0:
+        return 0.0
+    x *= math.pi
+    return (math.sin(x * tau) / (x * tau)) * (math.sin(x) / x)
+
+
+def resample_weights(old_res, new_res):
+    out = []
+    for i in range(new_res):
+        center = (i + 0.5) * old_res / new_res
+        first = _usize(math.floor(center - 2.0 + 0.5))
+        w = [_lanczos(((first + j) + 0.5 - center) / 2.0, 2.0) for j in range(4)]
+        inv = 1.0 / (w[0] + w[1] + w[2] + w[3])
+        out.append((first, [x * inv for x in w]))
+    return out
+
+
+def mip_texel(level, wrap, s, t):
+    ts = tt = 0
+    if wrap == 0:
+        ts, tt = s % level.u_res, t % level.v_res
+    elif wrap == 1:
+        if s >= level.u_res or t >= level.v_res:
+            return np.zeros(3)
+    else:
+        ts, tt = min(s, level.u_res), min(t, level.v_res)
+    return level.get(ts, tt)
+
+
+def build_mipmap(rgb8, wrap=0):
+    """rgb8: (h, w, 3) uint8 as decoded (top row first). Returns the pyramid as a list of BlockedLevel."""
+    img = rgb8.astype(np.float64) / 255.0
+    h, w = img.shape[:2]
+    img = img.copy()
+    for y in range(h // 2):
+        tmp = img[y].copy(); img[y] = img[h - 1 - y]; img[h - 1 - y] = tmp
+    pow2 = lambda v: v != 0 and (v & (v - 1)) == 0
+    rup = lambda v: 1 << (v - 1).bit_length()
+    if not pow2(w) or not pow2(h):
+        pw, ph = rup(w), rup(h)
+        sw = resample_weights(w, pw)
+        res = np.zeros((ph, pw, 3))
+        for t in range(h):
+            for x in range(pw):
+                acc = np.zeros(3)
+                for j in range(4):
+                    o = sw[x][0] + j
+                    if wrap == 0: o = o % w
+                    elif wrap == 2: o = min(max(o, 0), w - 1)
+                    if o < w: acc = acc + img[t, o] * sw[x][1][j]
+                res[t, x] = acc
+        tw = resample_weights(h, ph)
+        for x in range(pw):
+            work = np.zeros((ph, 3))
+            for t in range(ph):
+                for j in range(4):
+                    o = tw[t][0] + j
+                    if wrap == 0: o = o % h
+                    elif wrap == 2: o = min(max(o, 0), h - 1)
+                    if o < h: work[t] = work[t] + res[o, x] * tw[t][1][j]
+            for t in range(ph):
+                res[t, x] = np.maximum(work[t], 0.0)
+        img, w, h = res, pw, ph
+    n_levels = 1 + int(math.log2(max(w, h)))
+    lv = BlockedLevel(w, h)
+    for u in range(w):
+        for v in range(h):
+            lv.set(u, v, img[v, u])
+    pyr = [lv]
+    for i in range(1, n_levels):
+        sr, tr = max(pyr[-1].u_res // 2, 1), max(pyr[-1].v_res // 2, 1)
+        if min(sr, tr) < 64:
+            break
+        nl = BlockedLevel(sr, tr)
+        p = pyr[-1]
+        for t in range(tr):
+            for s in range(sr):
+                nl.set(s, t, (((mip_texel(p, wrap, 2 * s, 2 * t) + mip_texel(p, wrap, 2 * s + 1, 2 * t)) + mip_texel(p, wrap, 2 * s, 2 * t + 1)) + mip_texel(p, wrap, 2 * s + 1, 2 * t + 1)) * 0.25)
+        pyr.append(nl)
+    return pyr

@@ -1338,6 +1338,101 @@ void tex_map_2d(const rrt_texture& t, const SI& si, double st[2], double dstdx[2
 }
 inline double bump_int(double x) { return std::floor(x / 2.0) + 2.0 * rmax(x / 2.0 - std::floor(x / 2.0) - 0.5, 0.0); }   // checkerboard.rs:46-48
 
+// ---- MIPMap lookups mipmap.rs:98-268 over the level storage the loader built (rrt_image, include/rrt.h) ----------------
+struct OracleMip {
+  const rrt_scene_desc* d;
+  const rrt_image& im;
+  size_t levels() const { return (size_t)im.n_levels; }
+  static size_t f2usize(double v) { return !(v > 0.0) ? 0 : (v >= 18446744073709551615.0 ? (size_t)-1 : (size_t)v); }   // Rust `as usize`
+  Rgb at(size_t level, size_t u, size_t v) const {   // BlockedArray::index memory.rs:76-85
+    const rrt_image_level& L = im.levels[level];
+    const size_t i = 16 * ((size_t)L.u_blocks * (v & 3) + (u & 3)) + 4 * (v >> 2) + (u >> 2);
+    if (i >= L.n) throw OraclePanic{"memory.rs:84 BlockedArray index out of bounds"};
+    return Rgb(d->image_texels + 3 * (L.offset + i));
+  }
+  Rgb texel(size_t level, size_t s, size_t t) const {   // :107-131
+    if (level >= levels()) throw OraclePanic{"mipmap.rs:108 assert!(level < self.pyramid.len())"};
+    const rrt_image_level& L = im.levels[level];
+    size_t ts = 0, tt = 0;
+    if (im.wrap == RRT_WRAP_REPEAT) { ts = s - (s / L.u_res) * L.u_res; tt = t - (t / L.v_res) * L.v_res; }
+    else if (im.wrap == RRT_WRAP_BLACK) { if (s >= L.u_res || t >= L.v_res) return Rgb(); }   // in range: texel (0, 0), as written there
+    else { ts = s > L.u_res ? L.u_res : s; tt = t > L.v_res ? L.v_res : t; }                 // clamp_t(s, 0, u_size): u_size itself passes
+    return at(level, ts, tt);
+  }
+  Rgb triangle(size_t level, const double st[2]) const {   // :193-205
+    level = level > levels() - 1 ? levels() - 1 : level;
+    const rrt_image_level& L = im.levels[level];
+    const double s = st[0] * (double)L.u_res - 0.5, t = st[1] * (double)L.v_res - 0.5;
+    const size_t s0 = f2usize(std::floor(s)), t0 = f2usize(std::floor(t));
+    const double ds = s - std::trunc(s), dt = t - std::trunc(t);   // f64::fract
+    return texel(level, s0, t0) * (1.0 - ds) * (1.0 - dt) + texel(level, s0, t0 + 1) * (1.0 - ds) * dt + texel(level, s0 + 1, t0) * ds * (1.0 - dt) +
+           texel(level, s0 + 1, t0 + 1) * ds * dt;
+  }
+  Rgb lookup_w(const double st[2], double width) const {   // :132-149
+    const double level = (double)levels() - 1.0 + std::log2(rmax(width, 1e-8));
+    if (level < 0.0) return triangle(0, st);
+    if (level >= (double)(levels() - 1)) return texel(levels() - 1, 0, 0);
+    const size_t il = f2usize(std::floor(level));
+    const double delta = level - std::trunc(level);
+    return triangle(il, st) * (1.0 - delta) + triangle(il + 1, st) * delta;
+  }
+  Rgb ewa(size_t level, const double st_in[2], const double dst0_in[2], const double dst1_in[2]) const {   // :206-268
+    if (level > levels()) return texel(levels() - 1, 0, 0);
+    if (level >= levels()) throw OraclePanic{"mipmap.rs:217 pyramid[level]: index out of bounds (ewa of the level past the last)"};
+    const rrt_image_level& L = im.levels[level];
+    const double st[2] = {st_in[0] * (double)L.u_res - 0.5, st_in[1] * (double)L.v_res - 0.5};
+    const double dst0[2] = {dst0_in[0] * (double)L.u_res, dst0_in[1] * (double)L.v_res};
+    const double dst1[2] = {dst1_in[0] * (double)L.u_res, dst1_in[1] * (double)L.v_res};
+    double a = dst0[1] * dst0[1] + dst1[1] * dst1[1] + 1.0;
+    double b = -2.0 * (dst0[0] * dst0[1] + dst1[0] * dst1[1]);
+    double c = dst0[0] * dst0[0] + dst1[0] * dst1[0] + 1.0;
+    const double inv_f = 1.0 / (a * c - b * b * 0.25);
+    a *= inv_f; b *= inv_f; c *= inv_f;
+    const double det = -b * b + 4.0 * a * c, inv_det = 1.0 / det;
+    const double u_sqrt = std::sqrt(det * c), v_sqrt = std::sqrt(det * a);
+    const size_t s0 = f2usize(std::ceil(st[0] - 2.0 * inv_det * u_sqrt)), s1 = f2usize(std::floor(st[0] + 2.0 * inv_det * u_sqrt));
+    const size_t t0 = f2usize(std::ceil(st[1] - 2.0 * inv_det * v_sqrt)), t1 = f2usize(std::floor(st[1] + 2.0 * inv_det * v_sqrt));
+    Rgb sum;
+    double sum_wts = 0.0;
+    for (size_t it = t0; it <= t1 && it >= t0; it++) {
+      const double tt = (double)it - st[0];   // (st[0], as written at :250)
+      for (size_t is = s0; is <= s1 && is >= s0; is++) {
+        const double ss = (double)is - st[0];
+        const double r2 = a * ss * ss + b * ss * tt + c * tt * tt;
+        if (r2 < 1.0) {
+          const size_t index = f2usize(std::fmin(r2 * 128.0, 127.0));
+          const double r2i = (double)index / 127.0;
+          const double weight = std::exp(-2.0 * r2i) - std::exp(-2.0);   // WEIGHT_LUT :13-23
+          sum = sum + texel(level, is, it) * weight;
+          sum_wts += weight;
+        }
+      }
+    }
+    return sum / sum_wts;
+  }
+  Rgb lookup_d(const double st[2], const double dstdx[2], const double dstdy[2]) const {   // :150-192
+    if (im.do_trilinear) {
+      const double width = rmax(rmax(std::fabs(dstdx[0]), std::fabs(dstdx[1])), rmax(std::fabs(dstdy[0]), std::fabs(dstdy[1])));
+      return lookup_w(st, width);
+    }
+    double dst0[2], dst1[2];
+    if (dstdx[0] * dstdx[0] + dstdx[1] * dstdx[1] < dstdy[0] * dstdy[0] + dstdy[1] * dstdy[1]) { dst0[0] = dstdy[0]; dst0[1] = dstdy[1]; dst1[0] = dstdx[0]; dst1[1] = dstdx[1]; }
+    else { dst0[0] = dstdx[0]; dst0[1] = dstdx[1]; dst1[0] = dstdy[0]; dst1[1] = dstdy[1]; }
+    const double major_length = std::sqrt(dst0[0] * dst0[0] + dst0[1] * dst0[1]);
+    double minor_length = std::sqrt(dst1[0] * dst1[0] + dst1[1] * dst1[1]);
+    if (minor_length * im.max_aniso < major_length && minor_length > 0.0) {
+      const double scale = major_length / (minor_length * im.max_aniso);
+      dst1[0] *= scale; dst1[1] *= scale;
+      minor_length *= scale;
+    }
+    if (minor_length == 0.0) return triangle(0, st);
+    const double lod = rmax((double)(levels() - 1) + std::log2(minor_length), 0.0);
+    const size_t i_lod = f2usize(std::floor(lod));
+    const double fr = lod - std::trunc(lod);
+    return ewa(i_lod, st, dst0, dst1) * (1.0 - fr) + ewa(i_lod + 1, st, dst0, dst1) * fr;   // lerp evaluates both
+  }
+};
+
 Rgb tex_eval(const rrt_scene_desc* d, int id, const SI& si);
 inline Rgb tex_child(const rrt_scene_desc* d, const rrt_texture& t, int slot, const SI& si) {
   return t.child[slot] >= 0 ? tex_eval(d, t.child[slot], si) : Rgb(t.fallback[slot]);
@@ -1388,6 +1483,12 @@ Rgb tex_eval(const rrt_scene_desc* d, int id, const SI& si) {
     case RRT_TEX_WRINKLED: {   // wrinkled.rs:21-28
       V3 p = xf_pt(t.world_to_texture, si.p), dpdx = xf_vec(t.world_to_texture, si.dpdx), dpdy = xf_vec(t.world_to_texture, si.dpdy);
       return Rgb(tex_turbulence(p, dpdx, dpdy, t.omega, t.octaves));
+    }
+    case RRT_TEX_IMAGE: {   // imagemap.rs:74-81
+      double st[2], dx[2], dy[2];
+      tex_map_2d(t, si, st, dx, dy);
+      if (t.image < 0 || (size_t)t.image >= d->n_images) throw OraclePanic{"image texture without a decoded image"};
+      return OracleMip{d, d->images[t.image]}.lookup_d(st, dx, dy);
     }
     default: throw OraclePanic{"texture type outside the oracle's scope"};
   }

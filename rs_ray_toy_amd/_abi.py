@@ -53,9 +53,19 @@ class Material(C.Structure):
 
 class Texture(C.Structure):
     _fields_ = [("type", C.c_int32), ("mapping", C.c_int32), ("child", C.c_int32 * 3), ("aa_none", C.c_int32),
-                ("octaves", C.c_int32), ("pad", C.c_int32), ("fallback", (C.c_double * 3) * 3),
+                ("octaves", C.c_int32), ("image", C.c_int32), ("fallback", (C.c_double * 3) * 3),
                 ("v", (C.c_double * 3) * 4), ("omega", C.c_double), ("map", C.c_double * 4),
                 ("vs", C.c_double * 3), ("vt", C.c_double * 3), ("world_to_texture", C.c_double * 16)]
+
+
+class ImageLevel(C.Structure):
+    _fields_ = [("u_res", C.c_uint32), ("v_res", C.c_uint32), ("u_blocks", C.c_uint32), ("pad", C.c_uint32),
+                ("offset", C.c_uint64), ("n", C.c_uint64)]
+
+
+class Image(C.Structure):
+    _fields_ = [("do_trilinear", C.c_int32), ("wrap", C.c_int32), ("max_aniso", C.c_double), ("n_levels", C.c_int32),
+                ("pad", C.c_int32), ("levels", ImageLevel * 16)]
 
 
 class Light(C.Structure):
@@ -111,6 +121,8 @@ class SceneDesc(C.Structure):
                 ("prims", C.POINTER(Prim)), ("n_prims", C.c_size_t),
                 ("materials", C.POINTER(Material)), ("n_materials", C.c_size_t),
                 ("textures", C.POINTER(Texture)), ("n_textures", C.c_size_t),
+                ("images", C.POINTER(Image)), ("n_images", C.c_size_t),
+                ("image_texels", C.POINTER(C.c_double)), ("n_image_texels", C.c_size_t),
                 ("lights", C.POINTER(Light)), ("n_lights", C.c_size_t),
                 ("bvh_nodes", C.POINTER(BvhNode)), ("n_bvh_nodes", C.c_size_t),
                 ("prim_order", C.POINTER(C.c_uint32)), ("n_prim_order", C.c_size_t),

@@ -17,7 +17,7 @@ template <typename R> struct ShadeBlock { static constexpr int n = 256; };
 #define RRT_SHADE_BLOCK 256
 #endif
 template <> struct ShadeBlock<float> { static constexpr int n = RRT_SHADE_BLOCK; };
-enum { ERR_SHADING_NORMAL = 1, ERR_STACK = 2, ERR_BETA = 4, ERR_NULL_BSDF = 8 };
+enum { ERR_SHADING_NORMAL = 1, ERR_STACK = 2, ERR_BETA = 4, ERR_NULL_BSDF = 8, ERR_MIPMAP = 16 };
 
 // ------------------------------------------------------------------------------------------------------------
 // BVH traversal: BVHAccel::intersect / intersect_p (bvh.rs:124-236), same node order, same leaf order, every
@@ -721,6 +721,7 @@ RRT_DEV bool build_bsdf_tex(const SceneDev<R>& s, const Surf<R>& si, const SurfE
   compute_differentials(c, si.n, ext.dpdu, ext.dpdv, rd);
   const Material<R> m = resolve_material(s, s.materials[si.material], *c);
   build_lobes(m, b, allow_multiple_lobes);
+  if (c->err) return false;
   if (m.type == 5 && rgb_clamp0(Rgb<R>(m.kr)).is_black() && rgb_clamp0(Rgb<R>(m.kt)).is_black()) return false;
   if (m.type == 6 && rgb_clamp0(Rgb<R>(m.reflect)).is_black() && rgb_clamp0(Rgb<R>(m.transmit)).is_black()) return false;
   return true;
@@ -899,7 +900,7 @@ __global__ void __launch_bounds__(ShadeBlock<R>::n) __attribute__((amdgpu_waves_
             dr.rxo = V3<R>(a.x, a.y, a.z); dr.rxd = V3<R>(b.x, b.y, b.z); dr.ryo = V3<R>(c.x, c.y, c.z); dr.ryd = V3<R>(e.x, e.y, e.z);
           }
           TexCtx<R> tc;
-          if (!build_bsdf_tex(s, si, ext, dr, &tc, &bsdf)) atomicOr(&p.counters[C_ERROR], (uint32_t)ERR_NULL_BSDF);
+          if (!build_bsdf_tex(s, si, ext, dr, &tc, &bsdf)) atomicOr(&p.counters[C_ERROR], (uint32_t)(tc.err ? ERR_MIPMAP : ERR_NULL_BSDF));
         } else build_bsdf(s, si, &bsdf);
         const V4 st_b = p.path[i];
         index = qe.index;
@@ -1157,7 +1158,7 @@ __global__ void __launch_bounds__(kBlock) k_direct_tree(SceneDev<R> s, Pools<R> 
     TexCtx<R> tc;
     const DiffRay<R> fdr = f.dr;   // (a child frame may reuse this frame's stack entry below)
     // allow_multiple_lobes = false (directlighting.rs:91, intersect_debug.rs:71)
-    if (TEX) { if (!build_bsdf_tex(s, si, ext, fdr, &tc, &bsdf, false)) atomicOr(&p.counters[C_ERROR], (uint32_t)ERR_NULL_BSDF); }
+    if (TEX) { if (!build_bsdf_tex(s, si, ext, fdr, &tc, &bsdf, false)) atomicOr(&p.counters[C_ERROR], (uint32_t)(tc.err ? ERR_MIPMAP : ERR_NULL_BSDF)); }
     else build_bsdf(s, si, &bsdf, false);
     const Rgb<R> beta = f.beta;
     const int depth = f.depth;

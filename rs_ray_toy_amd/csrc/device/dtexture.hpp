@@ -20,6 +20,7 @@ template <typename R>
 struct TexCtx {
   V3<R> p, dpdx, dpdy;
   R u = 0, v = 0, dudx = 0, dvdx = 0, dudy = 0, dvdy = 0;
+  uint32_t err = 0;   // set where the reference's MIPMap lookup would index out of bounds (-> RRT_EPANIC)
 };
 
 // solve_linear_system_2x2 transform.rs:153-164
@@ -161,14 +162,99 @@ RRT_DEV void tex_map_2d(const TexDev<R>& t, const TexCtx<R>& c, R st[2], R dx[2]
 }
 template <typename R> RRT_DEV R bump_int(R x) { return floor(x / R(2)) + R(2) * rmax(x / R(2) - floor(x / R(2)) - R(0.5), R(0)); }   // checkerboard.rs:46-48
 
+// ---- MIPMap lookups mipmap.rs:98-268 (level storage: rrt_image in include/rrt.h) ---------------------------------------
+template <typename R> RRT_DEV uint32_t f2u_sat(R v) { return !(v > R(0)) ? 0u : (v >= R(4294967295.0) ? 0xffffffffu : (uint32_t)v); }   // `as usize` (32 bits suffice: res <= 2^16)
+template <typename R>
+RRT_DEV Rgb<R> mip_texel(const SceneDev<R>& s, const ImageDev<R>& im, uint32_t level, uint32_t su, uint32_t tu, uint32_t* err) {   // :107-131
+  const ImageLevelDev L = im.levels[level];
+  uint32_t ts = 0, tt = 0;
+  if (im.wrap == 0) { ts = su % L.u_res; tt = tu % L.v_res; }
+  else if (im.wrap == 1) { if (su >= L.u_res || tu >= L.v_res) return Rgb<R>(); }   // in range: texel (0, 0), as written there
+  else { ts = su > L.u_res ? L.u_res : su; tt = tu > L.v_res ? L.v_res : tu; }
+  const uint32_t i = 16u * (L.u_blocks * (tt & 3u) + (ts & 3u)) + 4u * (tt >> 2) + (ts >> 2);   // memory.rs:76-85
+  if (i >= L.n) { *err = 1; return Rgb<R>(); }
+  return Rgb<R>(s.image_texels + 3 * (size_t)(L.offset + i));
+}
+template <typename R>
+RRT_DEV Rgb<R> mip_triangle(const SceneDev<R>& s, const ImageDev<R>& im, uint32_t level, const R st[2], uint32_t* err) {   // :193-205
+  level = level > (uint32_t)im.n_levels - 1u ? (uint32_t)im.n_levels - 1u : level;
+  const ImageLevelDev L = im.levels[level];
+  const R sx = st[0] * (R)L.u_res - R(0.5), tx = st[1] * (R)L.v_res - R(0.5);
+  const uint32_t s0 = f2u_sat(floor(sx)), t0 = f2u_sat(floor(tx));
+  const R ds = sx - trunc(sx), dt = tx - trunc(tx);
+  return mip_texel(s, im, level, s0, t0, err) * (R(1) - ds) * (R(1) - dt) + mip_texel(s, im, level, s0, t0 + 1u, err) * (R(1) - ds) * dt +
+         mip_texel(s, im, level, s0 + 1u, t0, err) * ds * (R(1) - dt) + mip_texel(s, im, level, s0 + 1u, t0 + 1u, err) * ds * dt;
+}
+template <typename R>
+RRT_DEV Rgb<R> mip_ewa(const SceneDev<R>& s, const ImageDev<R>& im, uint32_t level, const R st_in[2], const R d0[2], const R d1[2], uint32_t* err) {   // :206-268
+  if (level >= (uint32_t)im.n_levels) { *err = 1; return Rgb<R>(); }   // level == levels: pyramid[level] out of bounds (level > levels cannot occur: i_lod <= levels - 1)
+  const ImageLevelDev L = im.levels[level];
+  const R st[2] = {st_in[0] * (R)L.u_res - R(0.5), st_in[1] * (R)L.v_res - R(0.5)};
+  const R dst0[2] = {d0[0] * (R)L.u_res, d0[1] * (R)L.v_res}, dst1[2] = {d1[0] * (R)L.u_res, d1[1] * (R)L.v_res};
+  R a = dst0[1] * dst0[1] + dst1[1] * dst1[1] + R(1);
+  R b = R(-2) * (dst0[0] * dst0[1] + dst1[0] * dst1[1]);
+  R c = dst0[0] * dst0[0] + dst1[0] * dst1[0] + R(1);
+  const R inv_f = R(1) / (a * c - b * b * R(0.25));
+  a *= inv_f; b *= inv_f; c *= inv_f;
+  const R det = -b * b + R(4) * a * c, inv_det = R(1) / det;
+  const R u_sqrt = sqrt(det * c), v_sqrt = sqrt(det * a);
+  const uint32_t s0 = f2u_sat(ceil(st[0] - R(2) * inv_det * u_sqrt)), s1 = f2u_sat(floor(st[0] + R(2) * inv_det * u_sqrt));
+  const uint32_t t0 = f2u_sat(ceil(st[1] - R(2) * inv_det * v_sqrt)), t1 = f2u_sat(floor(st[1] + R(2) * inv_det * v_sqrt));
+  Rgb<R> sum;
+  R sum_wts = R(0);
+  for (uint32_t it = t0; it <= t1 && it >= t0; it++) {
+    const R tt = (R)it - st[0];   // (st[0], as written at :250)
+    for (uint32_t is = s0; is <= s1 && is >= s0; is++) {
+      const R ss = (R)is - st[0];
+      const R r2 = a * ss * ss + b * ss * tt + c * tt * tt;
+      if (r2 < R(1)) {
+        const uint32_t index = f2u_sat(rmin(r2 * R(128), R(127)));
+        const R weight = (R)(exp(-2.0 * ((double)index / 127.0)) - exp(-2.0));   // WEIGHT_LUT :13-23 (f64 table)
+        sum = sum + mip_texel(s, im, level, is, it, err) * weight;
+        sum_wts += weight;
+      }
+    }
+  }
+  return sum / sum_wts;
+}
+template <typename R>
+RRT_DEV Rgb<R> mip_lookup_d(const SceneDev<R>& s, const ImageDev<R>& im, const R st[2], const R dstdx[2], const R dstdy[2], uint32_t* err) {   // :150-192
+  const uint32_t levels = (uint32_t)im.n_levels;
+  if (im.do_trilinear) {   // lookup_w :132-149
+    const R width = rmax(rmax(rabs(dstdx[0]), rabs(dstdx[1])), rmax(rabs(dstdy[0]), rabs(dstdy[1])));
+    const R level = (R)levels - R(1) + (R)log2(rmax(width, R(1e-8)));
+    if (level < R(0)) return mip_triangle(s, im, 0u, st, err);
+    if (level >= (R)(levels - 1u)) return mip_texel(s, im, levels - 1u, 0u, 0u, err);
+    const uint32_t il = f2u_sat(floor(level));
+    const R delta = level - trunc(level);
+    return mip_triangle(s, im, il, st, err) * (R(1) - delta) + mip_triangle(s, im, il + 1u, st, err) * delta;
+  }
+  R dst0[2], dst1[2];
+  if (dstdx[0] * dstdx[0] + dstdx[1] * dstdx[1] < dstdy[0] * dstdy[0] + dstdy[1] * dstdy[1]) { dst0[0] = dstdy[0]; dst0[1] = dstdy[1]; dst1[0] = dstdx[0]; dst1[1] = dstdx[1]; }
+  else { dst0[0] = dstdx[0]; dst0[1] = dstdx[1]; dst1[0] = dstdy[0]; dst1[1] = dstdy[1]; }
+  const R major_length = sqrt(dst0[0] * dst0[0] + dst0[1] * dst0[1]);
+  R minor_length = sqrt(dst1[0] * dst1[0] + dst1[1] * dst1[1]);
+  if (minor_length * im.max_aniso < major_length && minor_length > R(0)) {
+    const R scale = major_length / (minor_length * im.max_aniso);
+    dst1[0] *= scale; dst1[1] *= scale;
+    minor_length *= scale;
+  }
+  if (minor_length == R(0)) return mip_triangle(s, im, 0u, st, err);
+  const R lod = rmax((R)(levels - 1u) + (R)log2(minor_length), R(0));
+  const uint32_t i_lod = f2u_sat(floor(lod));
+  const R fr = lod - trunc(lod);
+  return mip_ewa(s, im, i_lod, st, dst0, dst1, err) * (R(1) - fr) + mip_ewa(s, im, i_lod + 1u, st, dst0, dst1, err) * fr;
+}
+
 // Texture::evaluate. LEVEL bounds the recursion at compile time (kTexDepth levels, each its own function: children are
 // real calls, not inlined copies); level 0 is never reached for graphs the host accepted.
 template <typename R, int LEVEL>
 struct TexEval {
-  static __device__ __noinline__ Rgb<R> eval(const TexDev<R>* texs, int id, const TexCtx<R>& c) {
+  static __device__ __noinline__ Rgb<R> eval(const SceneDev<R>& s, int id, TexCtx<R>& c) {
+    const TexDev<R>* texs = s.textures;
     const TexDev<R>& t = texs[id];
     auto child = [&](int slot) -> Rgb<R> {
-      return t.child[slot] >= 0 ? TexEval<R, LEVEL - 1>::eval(texs, t.child[slot], c) : Rgb<R>(t.fallback[slot]);
+      return t.child[slot] >= 0 ? TexEval<R, LEVEL - 1>::eval(s, t.child[slot], c) : Rgb<R>(t.fallback[slot]);
     };
     switch (t.type) {
       case 0: return Rgb<R>(t.v[0]);
@@ -204,6 +290,11 @@ struct TexEval {
         const V3<R> p = aff_pt(t.w2t, c.p);
         return child(f2i_sat(floor(p.x) + floor(p.y) + floor(p.z)) % 2 == 0 ? 0 : 1);
       }
+      case 9: {   // ImageTexture imagemap.rs:74-81
+        R st[2], dx[2], dy[2];
+        tex_map_2d(t, c, st, dx, dy);
+        return mip_lookup_d(s, s.images[t.image], st, dx, dy, &c.err);
+      }
       case 6: {   // WindyTexture windy.rs:15-23
         const V3<R> p = aff_pt(t.w2t, c.p), dpdx = aff_vec(t.w2t, c.dpdx), dpdy = aff_vec(t.w2t, c.dpdy);
         const R wind_strength = noise_sum(p * R(0.1), dpdx * R(0.1), dpdy * R(0.1), R(0.5), 3, false);
@@ -219,16 +310,16 @@ struct TexEval {
 };
 template <typename R>
 struct TexEval<R, 0> {
-  static __device__ Rgb<R> eval(const TexDev<R>*, int, const TexCtx<R>&) { return Rgb<R>(); }
+  static __device__ Rgb<R> eval(const SceneDev<R>&, int, TexCtx<R>&) { return Rgb<R>(); }
 };
 
 // the material with every textured parameter replaced by its value at this hit (materials evaluate their textures at
 // the top of compute_scattering_functions, e.g. matte.rs:47-49)
 template <typename R>
-RRT_DEV Material<R> resolve_material(const SceneDev<R>& s, const Material<R>& m0, const TexCtx<R>& c) {
+RRT_DEV Material<R> resolve_material(const SceneDev<R>& s, const Material<R>& m0, TexCtx<R>& c) {
   Material<R> m = m0;
   if (!m.has_tex) return m;
-  auto ev = [&](int slot) -> Rgb<R> { return TexEval<R, kTexDepth>::eval(s.textures, m0.tex[slot], c); };
+  auto ev = [&](int slot) -> Rgb<R> { return TexEval<R, kTexDepth>::eval(s, m0.tex[slot], c); };
   auto put3 = [&](int slot, R* dst) { if (m0.tex[slot] >= 0) { const Rgb<R> v = ev(slot); dst[0] = v.r; dst[1] = v.g; dst[2] = v.b; } };
   auto put1 = [&](int slot, R* dst) { if (m0.tex[slot] >= 0) *dst = ev(slot).r; };
   put3(0, m.kd); put3(1, m.ks); put3(2, m.kr); put3(3, m.eta); put3(4, m.k);

@@ -64,13 +64,22 @@ struct Material {
 template <typename R>
 struct TexDev {
   int32_t type, mapping, aa_none, octaves;
-  int32_t child[3], pad;
+  int32_t child[3], image;   // image: index into SceneDev::images (ImageTexture)
   R fallback[3][3];
   R v[4][3];
   R omega;
   R map[4];
   R vs[3], vt[3];
   R w2t[12];             // world_to_texture rows 0..2 (affine; the loader only composes T * R * S)
+};
+
+// MIPMap (rrt_image, include/rrt.h): per level the BlockedArray's data vector as the reference's index expression fills it
+struct ImageLevelDev { uint32_t u_res, v_res, u_blocks, n; uint32_t offset, pad[3]; };   // offset / n in texels of SceneDev::image_texels
+template <typename R>
+struct ImageDev {
+  int32_t do_trilinear, wrap, n_levels, pad;
+  R max_aniso, pad2;
+  ImageLevelDev levels[16];
 };
 
 template <typename R>
@@ -106,6 +115,8 @@ struct SceneDev {
   const SphereDev<R>* spheres;
   const Material<R>* materials;
   const TexDev<R>* textures;   // texture graph nodes (children before parents)
+  const ImageDev<R>* images;
+  const R* image_texels;       // RGB triples
   R diff_scale;                // scale_differentials factor 1 / sqrt(samples_per_pixel), integrator/mod.rs:94-96
   const Light<R>* lights;
   const R* light_cdf;          // Distribution1D([1; n]).cdf, n_lights + 1 entries

@@ -259,6 +259,7 @@ class Handle : public HandleBase {
     uint32_t err = 0;
     HIP_CHECK(hipMemcpy(&err, counters_.p + C_ERROR, sizeof(err), hipMemcpyDeviceToHost));
     if (err & ERR_SHADING_NORMAL) throw PanicError("primitives.rs:66 assert!(dot3(&si.ist.n, &si.shading.n) >= 0.0) (vertex normals oppose the winding, Q14)");
+    if (err & ERR_MIPMAP) throw PanicError("mipmap.rs:217 / memory.rs:84 index out of bounds in an ImageTexture lookup (EWA of the level past the last one: images with fewer than two pyramid levels, or a footprint >= the whole texture)");
     if (err & ERR_NULL_BSDF) throw PanicError("glass.rs:70 / translucent.rs:66 null BSDF (textures evaluate to black): path.rs:103 `bounces -= 1` underflows");
     if (err & ERR_BETA) throw PanicError("path.rs:146 assert!(beta.y() > 0.0 && beta.y().is_finite())");
   }
@@ -502,6 +503,8 @@ class Handle : public HandleBase {
   DevBuf<SphereDev<R>> spheres_;
   DevBuf<Material<R>> materials_;
   DevBuf<TexDev<R>> textures_;
+  DevBuf<ImageDev<R>> images_;
+  DevBuf<R> image_texels_;
   int tex_depth_ = 0;          // deepest texture graph some primitive's material evaluates (0 = no textured material in use)
   DevBuf<Light<R>> lights_;
   DevBuf<R> light_cdf_;
@@ -685,7 +688,8 @@ class Handle : public HandleBase {
         const rrt_texture& t = d->textures[i];
         TexDev<R>& o = texs[i];
         memset(&o, 0, sizeof(o));
-        o.type = t.type; o.mapping = t.mapping; o.aa_none = t.aa_none; o.octaves = t.octaves;
+        o.type = t.type; o.mapping = t.mapping; o.aa_none = t.aa_none; o.octaves = t.octaves; o.image = t.image;
+        if (t.type == RRT_TEX_IMAGE && t.image >= 0 && (size_t)t.image >= d->n_images) throw std::invalid_argument("texture image index out of range");
         for (int k = 0; k < 3; k++) {
           o.child[k] = t.child[k];
           if (t.child[k] >= (int32_t)i) throw std::invalid_argument("texture child index must precede its parent");
@@ -701,6 +705,21 @@ class Handle : public HandleBase {
       for (size_t i = 0; i < d->n_prims; i++) {
         const rrt_material& m = d->materials[d->prims[i].material];
         for (int k = 0; k < RRT_P_COUNT; k++) if (m.tex[k] >= 0) tex_depth_ = std::max(tex_depth_, depth[m.tex[k]]);
+      }
+    }
+    std::vector<ImageDev<R>> imgs(d->n_images);
+    std::vector<R> texels(3 * d->n_image_texels);
+    for (size_t i = 0; i < texels.size(); i++) texels[i] = (R)d->image_texels[i];
+    for (size_t i = 0; i < d->n_images; i++) {
+      const rrt_image& im = d->images[i];
+      ImageDev<R>& o = imgs[i];
+      memset(&o, 0, sizeof(o));
+      o.do_trilinear = im.do_trilinear; o.wrap = im.wrap; o.n_levels = im.n_levels; o.max_aniso = (R)im.max_aniso;
+      if (im.n_levels < 1 || im.n_levels > 16) throw std::invalid_argument("image pyramid levels out of range");
+      for (int l = 0; l < im.n_levels; l++) {
+        const rrt_image_level& L = im.levels[l];
+        if (L.offset + L.n > d->n_image_texels || L.offset + L.n >= (1ull << 32)) throw std::invalid_argument("image level outside the texel pool");
+        o.levels[l].u_res = L.u_res; o.levels[l].v_res = L.v_res; o.levels[l].u_blocks = L.u_blocks; o.levels[l].n = (uint32_t)L.n; o.levels[l].offset = (uint32_t)L.offset;
       }
     }
     std::vector<Light<R>> lights(d->n_lights);
@@ -758,13 +777,13 @@ class Handle : public HandleBase {
     if (d->sampler.type == RRT_SAMPLER_HALTON && d->sampler.perms) perms.assign(d->sampler.perms, d->sampler.perms + d->sampler.n_perms);
 
     nodes_.upload(nodes, st_); tris_.upload(tris, st_); build_pairs(nodes, tris.size()); shades_.upload(shades, st_); spheres_.upload(spheres, st_);
-    materials_.upload(mats, st_); textures_.upload(texs, st_);
+    materials_.upload(mats, st_); textures_.upload(texs, st_); images_.upload(imgs, st_); image_texels_.upload(texels, st_);
     if (!spheres.empty()) pairs_ok_ = false;   // the fp32 pair-node kernels are triangle-only: sphere scenes use the generic kernels
     lights_.upload(lights, st_); light_cdf_.upload(cdf_r, st_); lens_.upload(lens, st_); hdims_.upload(hd, st_); perms_.upload(perms, st_);
     HIP_CHECK(hipStreamSynchronize(st_));  // host vectors go out of scope below
 
     SceneDev<R>& s = scene_;
-    s.nodes = nodes_.p; s.tris = tris_.p; s.shades = shades_.p; s.spheres = spheres_.p; s.materials = materials_.p; s.textures = textures_.p; s.lights = lights_.p; s.light_cdf = light_cdf_.p;
+    s.nodes = nodes_.p; s.tris = tris_.p; s.shades = shades_.p; s.spheres = spheres_.p; s.materials = materials_.p; s.textures = textures_.p; s.images = images_.p; s.image_texels = image_texels_.p; s.lights = lights_.p; s.light_cdf = light_cdf_.p;
     s.n_nodes = (uint32_t)d->n_bvh_nodes; s.n_tris = (uint32_t)d->n_prim_order; s.n_lights = (uint32_t)nl;
     s.light_pick_pdf = (nl && func_int > 0.0) ? (R)(1.0 / (func_int * (double)nl)) : (R)0;
     s.stack_depth = d->bvh_depth + 1;

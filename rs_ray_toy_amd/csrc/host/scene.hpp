@@ -16,6 +16,8 @@ struct SceneData {
   std::vector<rrt_prim> prims;
   std::vector<rrt_material> materials;
   std::vector<rrt_texture> textures;
+  std::vector<rrt_image> images;
+  std::vector<double> image_texels;
   std::vector<rrt_light> lights;
   std::vector<rrt_bvh_node> bvh_nodes;
   std::vector<uint32_t> prim_order;
@@ -25,6 +27,11 @@ struct SceneData {
   std::vector<std::string> warnings;  // the reference's non-fatal eprintln! diagnostics
   void finalize();                    // point desc at the vectors
 };
+
+// ImageTexture support (imagemap.cpp): PNG -> rgb8 as `image::open(..).decode().into_rgb8()` gives it (0 ok, 1 not
+// decodable = the reference skips the texture, 2 decodable there but not restated here), and MIPMap::create.
+int decode_png_rgb8(const std::string& path, uint32_t* w, uint32_t* h, std::vector<uint8_t>* rgb, std::string* why);
+int build_mipmap(SceneData& s, uint32_t w, uint32_t h, const std::vector<uint8_t>& rgb8, bool do_trilinear, double max_aniso, int wrap);
 
 // BVHAccel::new bvh.rs:307-363 (HLBVH); fills bvh_nodes, prim_order, bvh_depth, world_bound.
 void build_bvh(SceneData& s, uint32_t max_prims_in_node, uint32_t flags);

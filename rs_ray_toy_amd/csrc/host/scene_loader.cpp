@@ -26,6 +26,8 @@ void SceneData::finalize() {
   desc.prims = prims.data(); desc.n_prims = prims.size();
   desc.materials = materials.data(); desc.n_materials = materials.size();
   desc.textures = textures.data(); desc.n_textures = textures.size();
+  desc.images = images.data(); desc.n_images = images.size();
+  desc.image_texels = image_texels.data(); desc.n_image_texels = image_texels.size() / 3;
   desc.lights = lights.data(); desc.n_lights = lights.size();
   desc.bvh_nodes = bvh_nodes.data(); desc.n_bvh_nodes = bvh_nodes.size();
   desc.prim_order = prim_order.data(); desc.n_prim_order = prim_order.size();
@@ -116,7 +118,9 @@ struct Loader {
   uint64_t seed;
   std::map<std::string, TexF> float_tex;
   std::map<std::string, TexC> rgb_tex;
-  std::vector<bool> tex_ok;   // per s.textures entry: representable (no ImageTexture in its graph)
+  std::vector<bool> tex_ok;   // per s.textures entry: representable (every image in its graph decodable here)
+  std::map<int, std::string> tex_why;
+  std::map<std::string, int> image_cache;   // `images: HashMap<TexInfo, Arc<MIPMap>>` renderprocess.rs:305
   struct MatEntry { int index = -1; std::string unsupported_type; };
   std::map<std::string, MatEntry> materials;
   struct MeshEntry { uint32_t first_tri = 0, n_tris = 0; };
@@ -264,10 +268,27 @@ struct Loader {
             make_mapping_2d(tc, to_world, &n);
             n.aa_none = read_string(tc, "aamode", "closedform") == "none";
           } else { n.type = RRT_TEX_CHECKER3D; identity_mapping_3d(to_world, &n); }
-        } else if (type == "ImageTexture") {
-          std::ifstream probe(asset_path(read_string(tc, "filename", "DefaultTexture")));
-          if (!probe) { warn("ImageTexture " + name + ": image not loadable, texture not registered"); continue; }  // load_image Err -> not inserted :428-436
-          ok = false;   // would need the image crate's decoders + MIPMap (mipmap.rs): refused where a material uses it
+        } else if (type == "ImageTexture") {   // :421-437, make_tex_info :517-530, load_image :532-561
+          n.type = RRT_TEX_IMAGE;
+          make_mapping_2d(tc, to_world, &n);
+          const std::string filename = asset_path(read_string(tc, "filename", "DefaultTexture"));
+          const bool do_trilinear = read_bool(tc, "do_trilinear", false);
+          const double max_aniso = read_f64(tc, "max_aniso", 8.0);
+          const std::string wrap_s = read_string(tc, "wrap", "repeat");
+          const int wrap = wrap_s == "black" ? RRT_WRAP_BLACK : (wrap_s == "clamp" ? RRT_WRAP_CLAMP : RRT_WRAP_REPEAT);
+          // ("scale" and "gamma" are read into TexInfo and never applied)
+          const std::string key = filename + "|" + (do_trilinear ? "1" : "0") + "|" + std::to_string(max_aniso) + "|" + std::to_string(wrap);
+          auto it = image_cache.find(key);
+          if (it != image_cache.end()) n.image = it->second;
+          else {
+            uint32_t w = 0, h = 0;
+            std::vector<uint8_t> rgb;
+            std::string why;
+            const int rc = decode_png_rgb8(filename, &w, &h, &rgb, &why);
+            if (rc == 1) { warn("ImageTexture " + name + ": image not loadable (" + why + "), texture not registered"); continue; }  // load_image Err -> not inserted
+            if (rc == 2) { ok = false; tex_why[(int)s.textures.size()] = why; n.image = -1; }
+            else { n.image = build_mipmap(s, w, h, rgb, do_trilinear, max_aniso, wrap); image_cache[key] = n.image; }
+          }
         } else if (type == "WindyTexture") {
           n.type = RRT_TEX_WINDY; identity_mapping_3d(to_world, &n);
         } else if (type == "WrinkledTexture") {
@@ -284,8 +305,11 @@ struct Loader {
   // (the returned constant is then unused).
   rrt_material* cur = nullptr;
   void bind_texture(int node, const std::string& type, const std::string& tname, int slot, const char* key, const std::string& mat) {
-    if (node < 0 || !tex_ok[node])
-      throw Unsupported("material '" + mat + "' key '" + key + "' uses " + type + " '" + tname + "': ImageTexture (image decoders + MIPMap) is out of scope, SURVEY §8f rank 4");
+    if (node < 0 || !tex_ok[node]) {
+      std::string why = "an image format the restated decoder does not cover";
+      for (auto& kv : tex_why) if (kv.first <= node) why = kv.second;
+      throw Unsupported("material '" + mat + "' key '" + key + "' uses " + type + " '" + tname + "' whose graph holds an ImageTexture that cannot be decoded here: " + why);
+    }
     cur->tex[slot] = node;
   }
   Rgb fetch_rgb(const Json& mc, const char* key, Rgb dflt, const std::string& mat, int slot) {

@@ -49,11 +49,12 @@ def test_no_gpu_means_device_error_not_fallback():
         Renderer(sc, 0)
 
 
-STRUCTS = {"rrt_xform": A.Xform, "rrt_tri": A.Tri, "rrt_sphere": A.Sphere, "rrt_prim": A.Prim, "rrt_material": A.Material,
+STRUCTS = {"rrt_xform": A.Xform, "rrt_tri": A.Tri, "rrt_sphere": A.Sphere, "rrt_prim": A.Prim, "rrt_material": A.Material, "rrt_texture": A.Texture, "rrt_image": A.Image, "rrt_image_level": A.ImageLevel,
            "rrt_light": A.Light, "rrt_bvh_node": A.BvhNode, "rrt_lens_elem": A.LensElem, "rrt_camera": A.Camera,
            "rrt_film": A.Film, "rrt_sampler": A.Sampler, "rrt_integrator": A.Integrator, "rrt_scene_desc": A.SceneDesc,
            "rrt_rays": A.Rays, "rrt_hits": A.Hits, "rrt_render_stats": A.RenderStats}
-FIELDS = {"rrt_scene_desc": ["flags", "tris", "n_prims", "bvh_nodes", "prim_order", "bvh_depth", "world_bound", "camera", "film", "sampler", "integrator"],
+FIELDS = {"rrt_texture": ["image", "fallback", "world_to_texture"], "rrt_material": ["tex"], "rrt_image": ["levels"],
+          "rrt_scene_desc": ["flags", "tris", "n_prims", "textures", "image_texels", "bvh_nodes", "prim_order", "bvh_depth", "world_bound", "camera", "film", "sampler", "integrator"],
           "rrt_camera": ["elems", "exit_pupil_bounds", "exit_pupil_valid"], "rrt_film": ["filter_table", "max_sample_luminance"],
           "rrt_sampler": ["perms", "perm_seed", "jitter"], "rrt_render_stats": ["ms_total", "any_prims"], "rrt_rays": ["skip_prim"]}
 

@@ -732,6 +732,27 @@ def _tex_case(which, wd):
         cube["material_name"], box["material_name"] = "m_cube", "m_box"
         cfg["Aggregate"]["primitives"].append({"primitive_type": "triangle", "material_name": "m_patch", "obj_name": "patch_01",
                                                "instances": [{"world_pos": [33.0, -2.5, 0.0], "rotation_axis": [0.2, 1.0, 0.1], "rotation_angle": 20}]})
+    elif which in ("direct_image_ewa", "path_image_trilinear"):
+        from test_host import write_png_fixture as write_png
+        rng = np.random.default_rng(4)
+        yy, xx = np.mgrid[0:256, 0:256]
+        img = np.stack([(xx ^ yy) & 255, (xx * 3 + yy) & 255, rng.integers(0, 256, size=(256, 256))], -1).astype(np.uint8)
+        write_png(os.path.join(wd, "tex.png"), img, filters=[4])
+        tri = which.endswith("trilinear")
+        cfg["rgb_texture"] = [{"texture_name": "img", "texture_type": "ImageTexture", "filename": "tex.png", "do_trilinear": tri, "wrap": "clamp" if tri else "repeat",
+                               "mapping": {"mapping": "uv", "su": 3.0, "sv": 2.0, "du": 0.25, "dv": 0.5} if tri else
+                                          {"mapping": "uv", "su": 0.002, "sv": 0.002, "du": 0.3, "dv": 0.3}},
+                              _const_rgb("half", [0.5, 0.5, 0.5]), {"texture_name": "img_half", "texture_type": "ScaleTexture", "t1": "img", "t2": "half"}]
+        cfg["materials"] = cfg["materials"] + [{"material_type": "MatteMaterial", "material_name": "m_box", "kd": "img"},
+                                               {"material_type": "PlasticMaterial", "material_name": "m_cube", "kd": "img_half", "ks": "img"}]
+        cube["material_name"], box["material_name"] = "m_cube", "m_box"
+        # EWA (the default) as the reference has it: compute_differentials' `ty` (interaction.rs:234) makes dpdy - hence dstdy - as large as
+        # the scene, so at unit texture scale lod lands past the last level and ewa() indexes out of bounds
+        # (test_image_texture_ewa_panics_like_the_reference); and the ellipse's t offset is taken from st[0] (mipmap.rs:250), so off the
+        # diagonal s = t no texel passes r2 < 1 and the lookup is 0 / 0. The case therefore shrinks the mapping (footprint < 1) and keeps
+        # s = t; DirectLighting drops NaN samples at the film (integrator/mod.rs:105) where the path integrator would assert on beta.
+        if not tri:
+            cfg["Integrator"] = {"integrator_type": "DirectLighting", "light_strategy": "all", "max_depth": 3}
     elif which == "direct_spheres":
         cfg, root = scenes.cfg1(wd, xres=64, yres=64, nsamp=5)
         cfg["rgb_texture"] = [_const_rgb("w", [0.9, 0.9, 0.9]), _const_rgb("k", [0.2, 0.1, 0.1]),
@@ -745,7 +766,8 @@ def _tex_case(which, wd):
     return cfg, root
 
 
-@pytest.mark.parametrize("which", ["path_checker_uv", "path_noise", "direct_mirror_patch", "debug_glass_patch", "direct_spheres"])
+@pytest.mark.parametrize("which", ["path_checker_uv", "path_noise", "direct_mirror_patch", "debug_glass_patch", "direct_spheres", "direct_image_ewa",
+                                   "path_image_trilinear"])
 def test_textured_materials(which, workdir):
     """Texture graph evaluated per hit (texture/*.rs), with the camera ray differentials (camera.rs:582-628, scaled by 1 / sqrt(spp)),
     compute_differentials incl. its `ty` quirk (interaction.rs:234), and - DirectLighting / Debug - the differentials specular
@@ -776,3 +798,29 @@ def test_textured_materials(which, workdir):
     if which != "direct_spheres":     # fp32 spheres: parity in the mean only
         assert (d32 < 1e-4).mean() > 0.97 and np.median(d32) < 1e-5, ((d32 < 1e-4).mean(), d32.max())
     assert abs(f32[..., :3].mean() / ref[..., :3].mean() - 1) < (0.15 if which == "direct_spheres" else 0.02)
+
+
+def test_image_texture_ewa_panics_like_the_reference(workdir):
+    """A 64 x 64 image has one pyramid level (mipmap.rs:361 stops below 64), so every EWA lookup with a non-degenerate footprint asks
+    for ewa(1) = pyramid[1]: index out of bounds in the reference; the trilinear path of the same texture renders."""
+    from test_host import write_png_fixture as write_png
+    rng = np.random.default_rng(9)
+    write_png(os.path.join(workdir, "small.png"), rng.integers(0, 256, size=(64, 64, 3), dtype=np.uint8))
+    for tri in (False, True):
+        cfg, root = _cfg3_tilted(workdir)
+        cfg["rgb_texture"] = [{"texture_name": "img", "texture_type": "ImageTexture", "filename": "small.png", "do_trilinear": tri}]
+        cfg["materials"] = cfg["materials"] + [{"material_type": "MatteMaterial", "material_name": "m_box", "kd": "img"}]
+        cfg["Aggregate"]["primitives"][1]["material_name"] = "m_box"
+        sc = Scene.loads(cfg, root)
+        for prec in (RRT_F64, RRT_F32):
+            r = Renderer(sc, 0, prec)
+            if tri:
+                film = r.render()
+                assert film[..., :3].max() > 0
+            else:
+                with pytest.raises(RrtPanic, match="index out of bounds"):
+                    r.render()
+            r.close()
+        if not tri:
+            with pytest.raises(O.OracleError, match="out of bounds"):
+                O.render(sc)

@@ -186,7 +186,11 @@ def test_loader_error_behaviour(tmp_path):
     # ImageTexture: a missing file is skipped as in the reference; a present one is refused when a material uses it
     t["rgb_texture"][1] = {"texture_name": "uv", "texture_type": "ImageTexture", "filename": "no_such.png"}
     assert list(Scene.loads(t, root).desc.materials[2].kd) == [0.5, 0.5, 0.5]     # name not registered -> the key's default
-    t["rgb_texture"][1]["filename"] = t["objs"][0]["filename"]
+    t["rgb_texture"][1]["filename"] = t["objs"][0]["filename"]      # no image format for ".obj": skipped as well
+    assert list(Scene.loads(t, root).desc.materials[2].kd) == [0.5, 0.5, 0.5]
+    with open(os.path.join(root, "photo.jpg"), "wb") as f:        # a format the image crate decodes and this build does not
+        f.write(b"\xff\xd8\xff\xe0")
+    t["rgb_texture"][1]["filename"] = "photo.jpg"
     with pytest.raises(RrtUnsupported, match="ImageTexture"):
         Scene.loads(t, root)
     # ... also through a texture that only contains one
@@ -256,3 +260,155 @@ def test_distant_light_construction(tmp_path):
     np.testing.assert_allclose(list(L.w_light), w, atol=1e-15)
     wb = np.array(list(d.world_bound))
     assert L.world_radius == pytest.approx(np.linalg.norm(wb[3:] - (wb[:3] + wb[3:]) / 2), rel=1e-15)
+
+
+# ---- ImageTexture: PNG decode as `image::open(..).decode().into_rgb8()` + MIPMap::create ---------------------------------------
+def write_png_fixture(path, arr, ctype=2, depth=8, palette=None, filters=None):
+    """Minimal PNG writer for fixtures (zlib from the standard library): arr = (h, w[, channels]) sample values."""
+    import struct, zlib
+    arr = np.asarray(arr)
+    h, w = arr.shape[:2]
+    ch = {0: 1, 2: 3, 3: 1, 4: 2, 6: 4}[ctype]
+    a = arr.reshape(h, w * ch)
+    if depth == 8:
+        rows = [bytes(a[y].astype(np.uint8)) for y in range(h)]
+    else:
+        rows = []
+        for y in range(h):
+            bits = "".join(format(int(v), f"0{depth}b") for v in a[y])
+            bits += "0" * (-len(bits) % 8)
+            rows.append(bytes(int(bits[i:i + 8], 2) for i in range(0, len(bits), 8)))
+    bpp = max(1, ch * depth // 8)
+    raw = b""
+    prev = bytes(len(rows[0]))
+    for y, row in enumerate(rows):
+        ft = (filters[y % len(filters)] if filters else 0)
+        out = bytearray(len(row))
+        for i, v in enumerate(row):
+            l = row[i - bpp] if i >= bpp else 0
+            u = prev[i]
+            ul = prev[i - bpp] if i >= bpp else 0
+            if ft == 0: p = 0
+            elif ft == 1: p = l
+            elif ft == 2: p = u
+            elif ft == 3: p = (l + u) // 2
+            else:
+                pa, pb, pc = abs(u - ul), abs(l - ul), abs(l + u - 2 * ul)
+                p = l if (pa <= pb and pa <= pc) else (u if pb <= pc else ul)
+            out[i] = (v - p) & 255
+        raw += bytes([ft]) + bytes(out)
+        prev = row
+    def chunk(t, d):
+        return struct.pack(">I", len(d)) + t + d + struct.pack(">I", zlib.crc32(t + d) & 0xffffffff)
+    png = b"\x89PNG\r\n\x1a\n" + chunk(b"IHDR", struct.pack(">IIBBBBB", w, h, depth, ctype, 0, 0, 0))
+    if palette is not None:
+        png += chunk(b"PLTE", bytes(np.asarray(palette, np.uint8).reshape(-1)))
+    comp = zlib.compress(raw)
+    png += chunk(b"IDAT", comp[:len(comp) // 2]) + chunk(b"IDAT", comp[len(comp) // 2:]) + chunk(b"IEND", b"")
+    with open(path, "wb") as f:
+        f.write(png)
+
+
+def _image_scene(workdir, filename, **tex):
+    cfg, root = scenes.cfg2(workdir, xres=16, yres=16, nsamp=2)
+    cfg["rgb_texture"] = [dict({"texture_name": "img", "texture_type": "ImageTexture", "filename": filename}, **tex)]
+    cfg["materials"] = cfg["materials"] + [{"material_type": "MatteMaterial", "material_name": "m_img", "kd": "img"}]
+    cfg["Aggregate"]["primitives"][0]["material_name"] = "m_img"
+    return cfg, root
+
+
+def _levels(desc, k=0):
+    im = desc.images[k]
+    tex = np.ctypeslib.as_array(desc.image_texels, shape=(desc.n_image_texels, 3))
+    return im, [tex[im.levels[i].offset:im.levels[i].offset + im.levels[i].n] for i in range(im.n_levels)]
+
+
+def test_image_texture_decode_and_mipmap(workdir):
+    rng = np.random.default_rng(11)
+    # 128 x 128 RGB, every PNG filter type, two IDAT chunks: levels 128 and 64 through the aliasing BlockedArray (Q32)
+    rgb = rng.integers(0, 256, size=(128, 128, 3), dtype=np.uint8)
+    write_png_fixture(os.path.join(workdir, "a.png"), rgb, filters=[0, 1, 2, 3, 4])
+    cfg, root = _image_scene(workdir, "a.png")
+    sc = Scene.loads(cfg, root)      # (keep the scene alive: desc points into it)
+    d = sc.desc
+    assert d.n_images == 1 and d.textures[0].type == 9 and d.textures[0].image == 0 and d.materials[d.n_materials - 1].tex[0] == 0
+    im, lv = _levels(d)
+    assert (im.do_trilinear, im.wrap, im.max_aniso, im.n_levels) == (0, 0, 8.0, 2)
+    ref = HR.build_mipmap(rgb, wrap=0)
+    assert [(l.u_res, l.v_res, l.u_blocks) for l in ref] == [(im.levels[i].u_res, im.levels[i].v_res, im.levels[i].u_blocks) for i in range(2)]
+    for got, want in zip(lv, ref):
+        assert np.array_equal(got, want.data)
+    # the storage really aliases: 128 x 128 texels land in far fewer cells, the rest of the vector stays zero
+    used = {HR.ba_index(32, u, v) for u in range(128) for v in range(128)}
+    assert len(used) < 128 * 128 // 8 and not lv[0][sorted(set(range(len(lv[0]))) - used)].any()
+    # the value left in a cell is the last one written in BlockedArray::new's order (u outer, v inner), of the vertically flipped image
+    u, v = 127, 127
+    assert np.array_equal(lv[0][HR.ba_index(32, u, v)], rgb[128 - 1 - v, u] / 255.0)
+
+    # other sample layouts decode to the same rgb8 the image crate's into_rgb8() gives: alpha dropped, grey replicated, palette expanded,
+    # sub-byte grey scaled by bit replication
+    grey = rng.integers(0, 256, size=(128, 128), dtype=np.uint8)
+    cases = {
+        "rgba.png": (dict(arr=np.concatenate([rgb, rng.integers(0, 256, size=(128, 128, 1), dtype=np.uint8)], -1), ctype=6), rgb),
+        "grey.png": (dict(arr=grey, ctype=0), np.repeat(grey[..., None], 3, -1)),
+        "greya.png": (dict(arr=np.stack([grey, 255 - grey], -1), ctype=4), np.repeat(grey[..., None], 3, -1)),
+        "grey4.png": (dict(arr=grey >> 4, ctype=0, depth=4), np.repeat(((grey >> 4) * 17)[..., None], 3, -1)),
+        "grey1.png": (dict(arr=grey >> 7, ctype=0, depth=1), np.repeat(((grey >> 7) * 255)[..., None], 3, -1)),
+        "pal2.png": (dict(arr=grey >> 6, ctype=3, depth=2, palette=[[255, 0, 0], [0, 255, 0], [0, 0, 255], [9, 8, 7]]),
+                     np.array([[255, 0, 0], [0, 255, 0], [0, 0, 255], [9, 8, 7]], np.uint8)[grey >> 6]),
+    }
+    for name, (kw, want_rgb) in cases.items():
+        write_png_fixture(os.path.join(workdir, name), filters=[4, 1], **kw)
+        cfg, root = _image_scene(workdir, name)
+        sc2 = Scene.loads(cfg, root)
+        _, lv2 = _levels(sc2.desc)
+        assert np.array_equal(lv2[0], HR.build_mipmap(want_rgb.astype(np.uint8))[0].data), name
+
+    # not a power of two: Lanczos resampling to 128 x 256 first (clamp wrap, trilinear flag, max_aniso carried through)
+    odd = rng.integers(0, 256, size=(130, 100, 3), dtype=np.uint8)
+    write_png_fixture(os.path.join(workdir, "odd.png"), odd)
+    cfg, root = _image_scene(workdir, "odd.png", wrap="clamp", do_trilinear=True, max_aniso=4.0)
+    sc3 = Scene.loads(cfg, root)
+    im, lv = _levels(sc3.desc)
+    assert (im.do_trilinear, im.wrap, im.max_aniso, im.n_levels) == (1, 2, 4.0, 2)
+    ref = HR.build_mipmap(odd, wrap=2)
+    assert (ref[0].u_res, ref[0].v_res, ref[1].u_res, ref[1].v_res) == (128, 256, 64, 128)
+    for got, want in zip(lv, ref):
+        np.testing.assert_allclose(got, want.data, rtol=1e-13, atol=1e-15)
+
+    # two textures over the same file and parameters share one MIPMap (images: HashMap<TexInfo, ..>)
+    cfg, root = _image_scene(workdir, "a.png")
+    cfg["rgb_texture"].append(dict(cfg["rgb_texture"][0], texture_name="img2"))
+    assert Scene.loads(cfg, root).desc.n_images == 1
+
+
+def test_image_texture_load_failures(workdir):
+    rng = np.random.default_rng(3)
+    rgb = rng.integers(0, 256, size=(128, 128, 3), dtype=np.uint8)
+    # broken files: load_image returns Err, the texture is not registered and the material falls back to its default (renderprocess.rs:428-436, 644-661)
+    write_png_fixture(os.path.join(workdir, "ok.png"), rgb)
+    blob = bytearray(open(os.path.join(workdir, "ok.png"), "rb").read())
+    blob[60] ^= 0xff                                    # inside IDAT: chunk CRC mismatch
+    open(os.path.join(workdir, "crc.png"), "wb").write(bytes(blob))
+    open(os.path.join(workdir, "short.png"), "wb").write(bytes(blob[:50]))
+    for name in ("crc.png", "short.png", "missing.png"):
+        cfg, root = _image_scene(workdir, name)
+        sc = Scene.loads(cfg, root)
+        assert sc.desc.n_images == 0 and list(sc.desc.materials[sc.desc.n_materials - 1].kd) == [0.5, 0.5, 0.5]
+        assert any("not loadable" in w for w in sc.warnings)
+    # decodable by the image crate but not restated here: refused where a material uses the texture
+    for name, kw in (("deep.png", dict(depth=16)), ):
+        import struct, zlib
+        write_png_fixture(os.path.join(workdir, name), rgb)     # patch the IHDR depth byte to 16 (and its CRC): the header is enough to classify
+        b = bytearray(open(os.path.join(workdir, name), "rb").read())
+        b[24] = 16
+        b[29:33] = struct.pack(">I", zlib.crc32(bytes(b[12:29])) & 0xffffffff)
+        open(os.path.join(workdir, name), "wb").write(bytes(b))
+        cfg, root = _image_scene(workdir, name)
+        with pytest.raises(RrtUnsupported, match="16-bit"):
+            Scene.loads(cfg, root)
+    # images narrower than 16 texels index past BlockedArray's vector while it is filled: the reference panics at load
+    write_png_fixture(os.path.join(workdir, "tiny.png"), rgb[:8, :8])
+    cfg, root = _image_scene(workdir, "tiny.png")
+    with pytest.raises(RrtPanic, match="BlockedArray"):
+        Scene.loads(cfg, root)

@@ -538,3 +538,90 @@ def test_textured_render_uses_camera_differentials(workdir):
     assert imgs["none"].max() > 0
     differ = np.abs(imgs["closedform"] - imgs["none"]).max(-1) > 1e-12 * imgs["none"].max()
     assert 0.005 < differ.mean() < 0.6, differ.mean()
+
+
+def test_image_texture_lookups_against_numpy(workdir):
+    """MIPMap::lookup_d (mipmap.rs:150-192): trilinear (lookup_w / triangle) and EWA, over the aliasing BlockedArray levels the loader
+    built; numpy restatement below. Also where the reference indexes out of bounds (EWA of the level past the last one)."""
+    import math
+    import sys
+    sys.path.insert(0, os.path.join(os.path.dirname(__file__), "..", "oracle"))
+    import host_ref as HR
+    from test_host import write_png_fixture as write_png
+    rng = np.random.default_rng(21)
+    rgb = rng.integers(0, 256, size=(256, 256, 3), dtype=np.uint8)
+    write_png(os.path.join(workdir, "t.png"), rgb)
+    pyr = HR.build_mipmap(rgb, wrap=0)
+    assert len(pyr) == 3
+    usize = lambda v: 0 if not (v > 0.0) else int(v)
+
+    def triangle(level, st, wrap=0):
+        level = min(level, len(pyr) - 1)
+        L = pyr[level]
+        s, t = st[0] * L.u_res - 0.5, st[1] * L.v_res - 0.5
+        s0, t0 = usize(math.floor(s)), usize(math.floor(t))
+        ds, dt = s - math.trunc(s), t - math.trunc(t)
+        tx = lambda a, b: HR.mip_texel(L, wrap, a, b)
+        return tx(s0, t0) * (1 - ds) * (1 - dt) + tx(s0, t0 + 1) * (1 - ds) * dt + tx(s0 + 1, t0) * ds * (1 - dt) + tx(s0 + 1, t0 + 1) * ds * dt
+
+    def ewa(level, st, d0, d1):
+        L = pyr[level]
+        s, t = st[0] * L.u_res - 0.5, st[1] * L.v_res - 0.5
+        d0 = (d0[0] * L.u_res, d0[1] * L.v_res); d1 = (d1[0] * L.u_res, d1[1] * L.v_res)
+        a = d0[1] * d0[1] + d1[1] * d1[1] + 1.0
+        b = -2.0 * (d0[0] * d0[1] + d1[0] * d1[1])
+        c = d0[0] * d0[0] + d1[0] * d1[0] + 1.0
+        inv_f = 1.0 / (a * c - b * b * 0.25)
+        a, b, c = a * inv_f, b * inv_f, c * inv_f
+        det = -b * b + 4.0 * a * c
+        us, vs = math.sqrt(det * c), math.sqrt(det * a)
+        s0, s1 = usize(math.ceil(s - 2.0 / det * us)), usize(math.floor(s + 2.0 / det * us))
+        t0, t1 = usize(math.ceil(t - 2.0 / det * vs)), usize(math.floor(t + 2.0 / det * vs))
+        acc, wsum = np.zeros(3), 0.0
+        for it in range(t0, t1 + 1):
+            tt = it - s                      # (st[0]: mipmap.rs:250)
+            for i_s in range(s0, s1 + 1):
+                ss = i_s - s
+                r2 = a * ss * ss + b * ss * tt + c * tt * tt
+                if r2 < 1.0:
+                    w = math.exp(-2.0 * (usize(min(r2 * 128.0, 127.0)) / 127.0)) - math.exp(-2.0)
+                    acc = acc + HR.mip_texel(L, 0, i_s, it) * w
+                    wsum += w
+        return acc / wsum
+
+    def lookup_d(st, dx, dy, trilinear, max_aniso=8.0):
+        n = len(pyr)
+        if trilinear:
+            width = max(abs(dx[0]), abs(dx[1]), abs(dy[0]), abs(dy[1]))
+            level = n - 1.0 + math.log2(max(width, 1e-8))
+            if level < 0: return triangle(0, st)
+            if level >= n - 1: return HR.mip_texel(pyr[-1], 0, 0, 0)
+            il = usize(math.floor(level)); dl = level - math.trunc(level)
+            return triangle(il, st) * (1 - dl) + triangle(il + 1, st) * dl
+        d0, d1 = (dy, dx) if dx[0] ** 2 + dx[1] ** 2 < dy[0] ** 2 + dy[1] ** 2 else (dx, dy)
+        major, minor = math.hypot(*d0), math.hypot(*d1)
+        if minor * max_aniso < major and minor > 0:
+            sc = major / (minor * max_aniso); d1 = (d1[0] * sc, d1[1] * sc); minor *= sc
+        if minor == 0: return triangle(0, st)
+        lod = max(n - 1 + math.log2(minor), 0.0)
+        il = usize(math.floor(lod)); fr = lod - math.trunc(lod)
+        return ewa(il, st, d0, d1) * (1 - fr) + ewa(il + 1, st, d0, d1) * fr
+
+    cfg, root = scenes.cfg2(workdir, xres=16, yres=16, nsamp=2)
+    mp = {"mapping": "uv", "su": 1.0, "sv": 1.0, "du": 0.0, "dv": 0.0}
+    cfg["rgb_texture"] = [{"texture_name": "ewa", "texture_type": "ImageTexture", "filename": "t.png", "mapping": mp},
+                          {"texture_name": "tri", "texture_type": "ImageTexture", "filename": "t.png", "do_trilinear": True, "mapping": mp}]
+    sc = Scene.loads(cfg, root)
+    assert sc.desc.n_images == 2
+    for k in range(40):
+        uv = rng.uniform(-0.5, 1.5, 2)
+        # footprints from a fraction of a texel to a few dozen texels, anisotropic; every 5th sample without differentials
+        duv = np.zeros(4) if k % 5 == 0 else rng.normal(size=4) * 10.0 ** rng.uniform(-3.5, -1.2)
+        dx, dy = (duv[0], duv[1]), (duv[2], duv[3])
+        np.testing.assert_allclose(O.texture_eval(sc, 1, uv=uv, duv=duv), lookup_d(uv, dx, dy, True), rtol=1e-12, atol=1e-15)
+        np.testing.assert_allclose(O.texture_eval(sc, 0, uv=uv, duv=duv), lookup_d(uv, dx, dy, False), rtol=1e-11, atol=1e-14)
+    # a footprint of the whole texture: lod >= levels - 1, so ewa(levels) indexes the pyramid out of bounds
+    with pytest.raises(O.OracleError, match="out of bounds"):
+        O.texture_eval(sc, 0, uv=(0.3, 0.3), duv=(1.5, 0.0, 0.0, 1.5))
+    # ... whereas the trilinear path returns the last level's texel (0, 0)
+    np.testing.assert_array_equal(O.texture_eval(sc, 1, uv=(0.3, 0.3), duv=(1.5, 0.0, 0.0, 1.5)), HR.mip_texel(pyr[-1], 0, 0, 0))
