@@ -21,7 +21,8 @@ for f in glob.glob(f"{root}/pass*/**/*counter_collection.csv", recursive=True):
 FRAMES = max(1, round(disp["closest"]["FETCH_SIZE"] / 16))
 out = {"units": "bytes per frame; FETCH_SIZE x1024 x2 (gfx950 correction), WRITE_SIZE x1024", "frames_profiled": FRAMES}
 for k in fam:
-    rd = tot[k]["FETCH_SIZE"] * 1024 * 2 / FRAMES
-    wr = tot[k]["WRITE_SIZE"] * 1024 / FRAMES
-    out[k] = {"read_bytes": rd, "write_bytes": wr, "hbm_bytes": rd + wr, "dispatches_per_frame": disp[k]["FETCH_SIZE"] / FRAMES}
+    nf = FRAMES if k in ("closest", "any") else FRAMES + 1     # raygen / shading / film kernels also run in the counting frame
+    rd = tot[k]["FETCH_SIZE"] * 1024 * 2 / nf
+    wr = tot[k]["WRITE_SIZE"] * 1024 / nf
+    out[k] = {"read_bytes": rd, "write_bytes": wr, "hbm_bytes": rd + wr, "dispatches_per_frame": disp[k]["FETCH_SIZE"] / nf}
 print(json.dumps(out, indent=1))
