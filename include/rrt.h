@@ -32,7 +32,7 @@
 extern "C" {
 #endif
 
-#define RRT_ABI_VERSION 5
+#define RRT_ABI_VERSION 6
 
 /* ---- error codes ------------------------------------------------------- */
 enum {
@@ -157,7 +157,7 @@ typedef struct rrt_material {
   double reflect[3], transmit[3];   /* translucent */
   double index;         /* glass "eta" (a float texture there; `eta` above is MetalMaterial's spectrum) */
   int32_t tex[RRT_P_COUNT];   /* index into rrt_scene_desc.textures per RRT_P_* slot, -1 = the constant above */
-  int32_t pad;
+  int32_t bump;               /* "bump_map": float texture displacing the shading geometry (Material::bump, material/mod.rs:22-62), -1 = none */
 } rrt_material;
 
 /* PointLight lights/point.rs:13-19, DiffuseAreaLight lights/diffuse.rs:13-22 */

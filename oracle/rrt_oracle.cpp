@@ -1508,10 +1508,32 @@ rrt_material resolve_material(const rrt_scene_desc* d, const rrt_material& m0, c
 
 // SurfaceInteraction::compute_scattering_functions interaction.rs:203-214 (compute_differentials first) +
 // Material::compute_scattering_functions for the in-scope materials
+// Material::bump material/mod.rs:22-62 (every in-scope material calls it first when it has a bump_map)
+void bump_shading(const rrt_scene_desc* d, int tex, SI* si) {
+  SI ev = *si;
+  double du = std::fabs(si->dudx) * 0.5 + std::fabs(si->dudy);   // (as written at :26; pbrt halves the sum)
+  if (du == 0.0) du = 0.0005;
+  ev.p = si->p + si->sdpdu * du;
+  ev.u = si->u + du; ev.v = si->v;
+  const double u_displace = tex_eval(d, tex, ev).c[0];
+  double dv = (std::fabs(si->dvdx) + std::fabs(si->dvdy)) * 0.5;
+  if (dv == 0.0) dv = 0.0005;
+  ev.p = si->p + si->sdpdv * dv;
+  ev.u = si->u; ev.v = si->v + dv;
+  const double v_displace = tex_eval(d, tex, ev).c[0];
+  const double displace = tex_eval(d, tex, *si).c[0];
+  V3 dpdu = si->sdpdu + si->sn * (u_displace - displace) / du + si->sdndu * displace;
+  V3 dpdv = si->sdpdv + si->sn * (v_displace - displace) / dv + si->sdndv * displace;
+  si_set_shading(si, dpdu, dpdv, si->sdndu, si->sdndv, false);
+}
+
 void compute_scattering(const Scene& sc, SI& si, const RayDiff& rd, Bsdf* bsdf, bool allow_multiple_lobes = true) {
   compute_differentials(&si, rd);
-
   if (!(dot(si.n, si.sn) >= 0.0)) throw OraclePanic{"primitives.rs:100 assert!(dot3(&si.ist.n, &si.shading.n) >= 0.0)"};
+  {
+    const rrt_material& mb = sc.d->materials[sc.d->prims[si.prim].material];
+    if (mb.bump >= 0 && mb.type != RRT_MAT_DEBUG) bump_shading(sc.d, mb.bump, &si);   // (the Debug material has no bump_map)
+  }
   const rrt_material m = resolve_material(sc.d, sc.d->materials[sc.d->prims[si.prim].material], si);
   bsdf->init(si);
   switch (m.type) {

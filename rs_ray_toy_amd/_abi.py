@@ -48,7 +48,7 @@ class Material(C.Structure):
                 ("kr", C.c_double * 3), ("eta", C.c_double * 3), ("k", C.c_double * 3), ("sigma", C.c_double),
                 ("roughness", C.c_double), ("u_roughness", C.c_double), ("v_roughness", C.c_double),
                 ("kt", C.c_double * 3), ("reflect", C.c_double * 3), ("transmit", C.c_double * 3), ("index", C.c_double),
-                ("tex", C.c_int32 * 13), ("pad", C.c_int32)]
+                ("tex", C.c_int32 * 13), ("bump", C.c_int32)]
 
 
 class Texture(C.Structure):

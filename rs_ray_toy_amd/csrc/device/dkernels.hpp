@@ -187,7 +187,7 @@ struct SphereSI { V3<R> p, n, wo, sn, sdpdu; };
 // the parts of SurfaceInteraction only textured scenes read: uv, geometric dpdu / dpdv (compute_differentials),
 // shading dndu / dndv (specular ray differentials, integrator/mod.rs:188-196)
 template <typename R>
-struct SurfExt { R u, v; V3<R> dpdu, dpdv, sdndu, sdndv; };
+struct SurfExt { R u, v; V3<R> dpdu, dpdv, sdpdv, sdndu, sdndv; };
 
 // The rays the sphere code works with: the ray handed to the sphere (instance space, Q16) and the object-space ray.
 template <typename R>
@@ -271,6 +271,7 @@ RRT_DEV void sphere_surface(const SphereDev<R>& S, V3<R> wo_, V3<R> wd_, R th, R
     const V3<R> dndv = dpdu * ((g * F - f * G) * inv_EFG2) + dpdv * ((f * F - g * E) * inv_EFG2);
     ext->dpdu = aff_vec(S.m, dpdu); ext->dpdv = aff_vec(S.m, dpdv);
     ext->sdndu = aff_nrm(S.mi, dndu); ext->sdndv = aff_nrm(S.mi, dndv);
+    ext->sdpdv = ext->dpdv;
   }
   if (S.has_inst && !S.inst_identity) {   // TransformedPrimitive::intersect primitives.rs:131-136
     si->p = aff_pt(S.im, si->p);
@@ -282,6 +283,7 @@ RRT_DEV void sphere_surface(const SphereDev<R>& S, V3<R> wo_, V3<R> wd_, R th, R
     if (ext) {
       ext->dpdu = aff_vec(S.im, ext->dpdu); ext->dpdv = aff_vec(S.im, ext->dpdv);
       ext->sdndu = aff_nrm(S.imi, ext->sdndu); ext->sdndv = aff_nrm(S.imi, ext->sdndv);
+      ext->sdpdv = ext->dpdv;
     }
   }
 }
@@ -667,7 +669,7 @@ RRT_DEV Surf<R> build_surface(const SceneDev<R>& s, int prim, V3<R> o, V3<R> d, 
   if (ext) {
     ext->u = uv[0][0] * (R(1) - u - v) + uv[1][0] * u + uv[2][0] * v;
     ext->v = uv[0][1] * (R(1) - u - v) + uv[1][1] * u + uv[2][1] * v;
-    ext->dpdu = dpdu; ext->dpdv = dpdv;
+    ext->dpdu = dpdu; ext->dpdv = dpdv; ext->sdpdv = dpdv;
     ext->sdndu = ext->sdndv = V3<R>();
     if (has_n == 1) {   // triangle.rs:351-386
       const V3<R> dn1 = vn0 - vn2, dn2 = vn1 - vn2;
@@ -693,6 +695,7 @@ RRT_DEV Surf<R> build_surface(const SceneDev<R>& s, int prim, V3<R> o, V3<R> d, 
     V3<R> nn = nnormalize(cross(ss, ts));
     si.sn = faceforward(si.n, nn);
     si.sdpdu = ss;
+    if (ext) ext->sdpdv = ts;
     // ... and primitives.rs:66 asserts dot(ist.n, shading.n) >= 0, i.e. panics when vn opposes the winding.
     if (!(dot(si.n, si.sn) >= R(0))) si.ok = false;
   }
@@ -711,14 +714,35 @@ RRT_DEV void build_bsdf(const SceneDev<R>& s, const Surf<R>& si, Bsdf<R, NL>* b,
 // Returns false for a Glass / Translucent whose evaluated colours are all black: the reference leaves `bsdf` None there
 // and path.rs:103 underflows `bounces` (constant materials are checked on the host).
 template <typename R, int NL>
-RRT_DEV bool build_bsdf_tex(const SceneDev<R>& s, const Surf<R>& si, const SurfExt<R>& ext, const DiffRay<R>& rd, TexCtx<R>* c,
+RRT_DEV bool build_bsdf_tex(const SceneDev<R>& s, Surf<R>& si, const SurfExt<R>& ext, const DiffRay<R>& rd, TexCtx<R>* c,
                             Bsdf<R, NL>* b, bool allow_multiple_lobes = true) {
+  c->p = si.p; c->u = ext.u; c->v = ext.v;
+  c->pd = V3<double>((double)si.p.x + (double)si.p_lo.x, (double)si.p.y + (double)si.p_lo.y, (double)si.p.z + (double)si.p_lo.z);
+  compute_differentials(c, si.n, ext.dpdu, ext.dpdv, rd);
+  const int bump = s.materials[si.material].bump;
+  if (bump >= 0) {   // Material::bump material/mod.rs:22-62: the displacement texture at (u + du, v), (u, v + dv) and (u, v)
+    TexCtx<R> ev = *c;
+    R du = rabs(c->dudx) * R(0.5) + rabs(c->dudy);   // (as written at :26)
+    if (du == R(0)) du = R(0.0005);
+    auto step_d = [&](V3<R> dir, R h) { return V3<double>(c->pd.x + (double)dir.x * (double)h, c->pd.y + (double)dir.y * (double)h, c->pd.z + (double)dir.z * (double)h); };
+    ev.p = si.p + si.sdpdu * du; ev.pd = step_d(si.sdpdu, du); ev.u = c->u + du; ev.v = c->v;
+    const R u_displace = TexEval<R, kTexDepth>::eval(s, bump, ev).r;
+    R dv = (rabs(c->dvdx) + rabs(c->dvdy)) * R(0.5);
+    if (dv == R(0)) dv = R(0.0005);
+    ev.p = si.p + ext.sdpdv * dv; ev.pd = step_d(ext.sdpdv, dv); ev.u = c->u; ev.v = c->v + dv;
+    const R v_displace = TexEval<R, kTexDepth>::eval(s, bump, ev).r;
+    const R displace = TexEval<R, kTexDepth>::eval(s, bump, *c).r;
+    c->err |= ev.err;
+    const V3<R> dpdu = si.sdpdu + si.sn * (u_displace - displace) / du + ext.sdndu * displace;
+    const V3<R> dpdv = ext.sdpdv + si.sn * (v_displace - displace) / dv + ext.sdndv * displace;
+    // set_shading_geometry(.., orientation_is_authoritative = false) interaction.rs:183-202
+    si.sn = faceforward(nnormalize(cross(dpdu, dpdv)), si.n);
+    si.sdpdu = dpdu;
+  }
   b->ns = si.sn;
   b->ss = vnormalize(si.sdpdu);
   b->ng = si.n;
   b->ts = cross(b->ns, b->ss);
-  c->p = si.p; c->u = ext.u; c->v = ext.v;
-  compute_differentials(c, si.n, ext.dpdu, ext.dpdv, rd);
   const Material<R> m = resolve_material(s, s.materials[si.material], *c);
   build_lobes(m, b, allow_multiple_lobes);
   if (c->err) return false;
@@ -1152,7 +1176,7 @@ __global__ void __launch_bounds__(kBlock) k_direct_tree(SceneDev<R> s, Pools<R> 
     if (f.phase == 0) n_closest++;   // the phase-1 re-intersection is bookkeeping, not a reference query
     if (hit < 0) { sp--; continue; }   // `for light in lights { l += le; return l }`: le = 0
     SurfExt<R> ext;
-    const Surf<R> si = build_surface(s, hit, f.o, f.d, r.tmax, hu, hv, TEX ? &ext : nullptr);
+    Surf<R> si = build_surface(s, hit, f.o, f.d, r.tmax, hu, hv, TEX ? &ext : nullptr);
     if (!si.ok) { atomicOr(&p.counters[C_ERROR], (uint32_t)ERR_SHADING_NORMAL); sp--; continue; }
     Bsdf<R, 4> bsdf;
     TexCtx<R> tc;

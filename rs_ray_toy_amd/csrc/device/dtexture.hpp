@@ -19,6 +19,9 @@ struct DiffRay {
 template <typename R>
 struct TexCtx {
   V3<R> p, dpdx, dpdy;
+  // the hit point in double (fp32 mode: p + the low word of the double-float spawn point): the 3D textures work on it, because
+  // Material::bump differentiates them over a step of 5e-4 of a triangle edge - below fp32 resolution at scene coordinates
+  V3<double> pd;
   R u = 0, v = 0, dudx = 0, dvdx = 0, dudy = 0, dvdy = 0;
   uint32_t err = 0;   // set where the reference's MIPMap lookup would index out of bounds (-> RRT_EPANIC)
 };
@@ -70,14 +73,13 @@ static __device__ const uint8_t kNoisePerm[256] = {
     218, 246, 97, 228, 251, 34, 242, 193, 238, 210, 144, 12, 191, 179, 162, 241, 81, 51, 145, 235, 249, 14, 239, 107, 49, 192, 214, 31, 181, 199, 106, 157,
     184, 84, 204, 176, 115, 121, 50, 45, 127, 4, 150, 254, 138, 236, 205, 93, 222, 114, 67, 29, 24, 72, 243, 141, 128, 195, 78, 66, 215, 61, 156, 180};
 RRT_DEV int noise_perm(int i) { return (int)kNoisePerm[i & 255]; }   // the reference doubles the table instead of masking
-template <typename R>
-RRT_DEV R noise_grad(int x, int y, int z, R dx, R dy, R dz) {
+RRT_DEV double noise_grad(int x, int y, int z, double dx, double dy, double dz) {
   const int h = noise_perm(noise_perm(noise_perm(x) + y) + z) & 15;
-  const R u = (h < 8 || h == 12 || h == 13) ? dx : dy;
-  const R v = (h < 4 || h == 12 || h == 13) ? dy : dz;
+  const double u = (h < 8 || h == 12 || h == 13) ? dx : dy;
+  const double v = (h < 4 || h == 12 || h == 13) ? dy : dz;
   return ((h & 1) ? -u : u) + ((h & 2) ? -v : v);
 }
-template <typename R> RRT_DEV R noise_weight(R t) { const R t3 = t * t * t, t4 = t3 * t; return R(6) * t4 * t - R(15) * t4 + R(10) * t3; }
+RRT_DEV double noise_weight(double t) { const double t3 = t * t * t, t4 = t3 * t; return 6.0 * t4 * t - 15.0 * t4 + 10.0 * t3; }
 template <typename R> RRT_DEV R lerp_r(R t, R a, R b) { return a * (R(1) - t) + b * t; }   // misc.rs:223-228
 template <typename R>
 RRT_DEV int f2i_sat(R v) {   // Rust `as i32`: saturating, NaN -> 0
@@ -86,42 +88,52 @@ RRT_DEV int f2i_sat(R v) {   // Rust `as i32`: saturating, NaN -> 0
   if (v <= R(-2147483648.0)) return -2147483647 - 1;
   return (int)v;
 }
-template <typename R>
-RRT_DEV R noise_flt(V3<R> q) {
+// the noise functions run in double in both device modes (see TexCtx::pd); the f64 mode is unchanged by that
+RRT_DEV double noise_flt(V3<double> q) {
   int ix = f2i_sat(floor(q.x)), iy = f2i_sat(floor(q.y)), iz = f2i_sat(floor(q.z));
-  const R dx = q.x - (R)ix, dy = q.y - (R)iy, dz = q.z - (R)iz;
+  const double dx = q.x - (double)ix, dy = q.y - (double)iy, dz = q.z - (double)iz;
   ix &= 255; iy &= 255; iz &= 255;
-  const R w000 = noise_grad(ix, iy, iz, dx, dy, dz), w100 = noise_grad(ix + 1, iy, iz, dx - R(1), dy, dz);
-  const R w010 = noise_grad(ix, iy + 1, iz, dx, dy - R(1), dz), w110 = noise_grad(ix + 1, iy + 1, iz, dx - R(1), dy - R(1), dz);
-  const R w001 = noise_grad(ix, iy, iz + 1, dx, dy, dz - R(1)), w101 = noise_grad(ix + 1, iy, iz + 1, dx - R(1), dy, dz - R(1));
-  const R w011 = noise_grad(ix, iy + 1, iz + 1, dx, dy - R(1), dz - R(1)), w111 = noise_grad(ix + 1, iy + 1, iz + 1, dx - R(1), dy - R(1), dz - R(1));
-  const R wx = noise_weight(dx), wy = noise_weight(dy), wz = noise_weight(dz);
-  const R x00 = lerp_r(wx, w000, w100), x10 = lerp_r(wx, w010, w110), x01 = lerp_r(wx, w001, w101), x11 = lerp_r(wx, w011, w111);
-  const R y0 = lerp_r(wy, x00, x10), y1 = lerp_r(wy, x01, x11);
+  const double w000 = noise_grad(ix, iy, iz, dx, dy, dz), w100 = noise_grad(ix + 1, iy, iz, dx - 1.0, dy, dz);
+  const double w010 = noise_grad(ix, iy + 1, iz, dx, dy - 1.0, dz), w110 = noise_grad(ix + 1, iy + 1, iz, dx - 1.0, dy - 1.0, dz);
+  const double w001 = noise_grad(ix, iy, iz + 1, dx, dy, dz - 1.0), w101 = noise_grad(ix + 1, iy, iz + 1, dx - 1.0, dy, dz - 1.0);
+  const double w011 = noise_grad(ix, iy + 1, iz + 1, dx, dy - 1.0, dz - 1.0), w111 = noise_grad(ix + 1, iy + 1, iz + 1, dx - 1.0, dy - 1.0, dz - 1.0);
+  const double wx = noise_weight(dx), wy = noise_weight(dy), wz = noise_weight(dz);
+  const double x00 = lerp_r(wx, w000, w100), x10 = lerp_r(wx, w010, w110), x01 = lerp_r(wx, w001, w101), x11 = lerp_r(wx, w011, w111);
+  const double y0 = lerp_r(wy, x00, x10), y1 = lerp_r(wy, x01, x11);
   return lerp_r(wz, y0, y1);
 }
 template <typename R> RRT_DEV R smooth_step(R mn, R mx, R v) { const R t = clampr((v - mn) / (mx - mn), R(0), R(1)); return t * t * (R(-2) * t + R(3)); }
 // fbm :138-153 (turb = false) / turbulence :155-185 (turb = true)
-template <typename R>
-RRT_DEV R noise_sum(V3<R> p, V3<R> dpdx, V3<R> dpdy, R omega, int max_octaves, bool turb) {
-  const R l2 = rmax(len2(dpdx), len2(dpdy));
-  const R n = clampr(R(-1) - R(0.5) * (R)log2(l2), R(0), (R)max_octaves);
+RRT_DEV double noise_sum(V3<double> p, V3<double> dpdx, V3<double> dpdy, double omega, int max_octaves, bool turb) {
+  const double l2 = rmax(len2(dpdx), len2(dpdy));
+  const double n = clampr(-1.0 - 0.5 * log2(l2), 0.0, (double)max_octaves);
   const int n_int = f2i_sat(floor(n));
-  R sum = R(0), lambda = R(1), o = R(1);
+  double sum = 0.0, lambda = 1.0, o = 1.0;
   for (int i = 0; i < n_int; i++) {
-    const R nz = noise_flt(p * lambda);
+    const double nz = noise_flt(p * lambda);
     sum += o * (turb ? rabs(nz) : nz);
-    lambda *= R(1.99); o *= omega;
+    lambda *= 1.99; o *= omega;
   }
-  const R n_partial = n - (R)n_int;
-  const R nz = noise_flt(p * lambda);
+  const double n_partial = n - (double)n_int;
+  const double nz = noise_flt(p * lambda);
   if (turb) {
-    sum += o * lerp_r(smooth_step(R(0.3), R(0.7), n_partial), R(0.2), rabs(nz));
-    for (int i = n_int; i < max_octaves; i++) { sum += o * R(0.2); o *= omega; }
+    sum += o * lerp_r(smooth_step(0.3, 0.7, n_partial), 0.2, rabs(nz));
+    for (int i = n_int; i < max_octaves; i++) { sum += o * 0.2; o *= omega; }
   } else {
-    sum += o * smooth_step(R(0.3), R(0.7), n_partial) * nz;
+    sum += o * smooth_step(0.3, 0.7, n_partial) * nz;
   }
   return sum;
+}
+// world_to_texture in double (the matrix itself is stored in the mode's precision)
+template <typename R> RRT_DEV V3<double> aff_pt_d(const R* m, V3<double> p) {
+  return V3<double>((double)m[0] * p.x + (double)m[1] * p.y + (double)m[2] * p.z + (double)m[3],
+                    (double)m[4] * p.x + (double)m[5] * p.y + (double)m[6] * p.z + (double)m[7],
+                    (double)m[8] * p.x + (double)m[9] * p.y + (double)m[10] * p.z + (double)m[11]);
+}
+template <typename R> RRT_DEV V3<double> aff_vec_d(const R* m, V3<R> v) {
+  return V3<double>((double)m[0] * (double)v.x + (double)m[1] * (double)v.y + (double)m[2] * (double)v.z,
+                    (double)m[4] * (double)v.x + (double)m[5] * (double)v.y + (double)m[6] * (double)v.z,
+                    (double)m[8] * (double)v.x + (double)m[9] * (double)v.y + (double)m[10] * (double)v.z);
 }
 
 // ---- TextureMapping2D::map texture/mod.rs:205-352 ----------------------------------------------------------------
@@ -287,7 +299,7 @@ struct TexEval {
         return child(0) * (R(1) - area2) + child(1) * area2;
       }
       case 4: {   // Checkerboard3DTexture checkerboard.rs:121-131
-        const V3<R> p = aff_pt(t.w2t, c.p);
+        const V3<double> p = aff_pt_d(t.w2t, c.pd);
         return child(f2i_sat(floor(p.x) + floor(p.y) + floor(p.z)) % 2 == 0 ? 0 : 1);
       }
       case 9: {   // ImageTexture imagemap.rs:74-81
@@ -296,14 +308,14 @@ struct TexEval {
         return mip_lookup_d(s, s.images[t.image], st, dx, dy, &c.err);
       }
       case 6: {   // WindyTexture windy.rs:15-23
-        const V3<R> p = aff_pt(t.w2t, c.p), dpdx = aff_vec(t.w2t, c.dpdx), dpdy = aff_vec(t.w2t, c.dpdy);
-        const R wind_strength = noise_sum(p * R(0.1), dpdx * R(0.1), dpdy * R(0.1), R(0.5), 3, false);
-        const R wave_height = noise_sum(p, dpdx, dpdy, R(0.5), 6, false);
-        return Rgb<R>(rabs(wind_strength) * wave_height);
+        const V3<double> p = aff_pt_d(t.w2t, c.pd), dpdx = aff_vec_d(t.w2t, c.dpdx), dpdy = aff_vec_d(t.w2t, c.dpdy);
+        const double wind_strength = noise_sum(p * 0.1, dpdx * 0.1, dpdy * 0.1, 0.5, 3, false);
+        const double wave_height = noise_sum(p, dpdx, dpdy, 0.5, 6, false);
+        return Rgb<R>((R)(rabs(wind_strength) * wave_height));
       }
       default: {   // 7: WrinkledTexture wrinkled.rs:21-28
-        const V3<R> p = aff_pt(t.w2t, c.p), dpdx = aff_vec(t.w2t, c.dpdx), dpdy = aff_vec(t.w2t, c.dpdy);
-        return Rgb<R>(noise_sum(p, dpdx, dpdy, t.omega, t.octaves, true));
+        const V3<double> p = aff_pt_d(t.w2t, c.pd), dpdx = aff_vec_d(t.w2t, c.dpdx), dpdy = aff_vec_d(t.w2t, c.dpdy);
+        return Rgb<R>((R)noise_sum(p, dpdx, dpdy, (double)t.omega, t.octaves, true));
       }
     }
   }

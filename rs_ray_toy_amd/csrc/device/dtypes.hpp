@@ -58,6 +58,7 @@ struct Material {
   R kt[3], reflect[3], transmit[3], index;   // glass / translucent
   int32_t tex[13];       // RRT_P_* slot -> SceneDev::textures index evaluated at every hit, -1 = the constant above
   int32_t has_tex;       // any slot >= 0
+  int32_t bump, pad;     // bump_map texture (Material::bump), -1 = none
 };
 
 // one node of the texture graph (rrt_texture, include/rrt.h): float textures carry their value in all three channels

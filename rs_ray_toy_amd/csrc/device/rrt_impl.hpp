@@ -672,6 +672,8 @@ class Handle : public HandleBase {
       for (int k = 0; k < 3; k++) { o.kt[k] = (R)m.kt[k]; o.reflect[k] = (R)m.reflect[k]; o.transmit[k] = (R)m.transmit[k]; }
       o.index = (R)m.index;
       o.has_tex = 0;
+      o.bump = m.type == RRT_MAT_DEBUG ? -1 : m.bump; o.pad = 0;
+      if (o.bump >= 0 && (size_t)o.bump >= d->n_textures) throw std::invalid_argument("material bump texture index out of range");
       for (int k = 0; k < RRT_P_COUNT; k++) {
         o.tex[k] = m.tex[k];
         if (m.tex[k] >= 0) {
@@ -705,6 +707,7 @@ class Handle : public HandleBase {
       for (size_t i = 0; i < d->n_prims; i++) {
         const rrt_material& m = d->materials[d->prims[i].material];
         for (int k = 0; k < RRT_P_COUNT; k++) if (m.tex[k] >= 0) tex_depth_ = std::max(tex_depth_, depth[m.tex[k]]);
+        if (m.bump >= 0 && m.type != RRT_MAT_DEBUG) tex_depth_ = std::max(tex_depth_, depth[m.bump]);
       }
     }
     std::vector<ImageDev<R>> imgs(d->n_images);

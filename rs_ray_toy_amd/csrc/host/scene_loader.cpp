@@ -330,7 +330,6 @@ struct Loader {
       auto it = float_tex.find(v->str);
       if (it == float_tex.end()) throw Panic("renderprocess.rs:619 float_texture[\"" + v->str + "\"] missing (material " + mat + ")");
       if (!it->second.is_const) {
-        if (slot < 0) throw Unsupported("material '" + mat + "': bump_map is out of scope (Material::bump, material/mod.rs:22-62)");
         bind_texture(it->second.node, it->second.type, v->str, slot, key, mat);
       }
       return it->second.v;
@@ -356,9 +355,14 @@ struct Loader {
       rrt_material m{};
       for (int k = 0; k < RRT_P_COUNT; k++) m.tex[k] = -1;
       cur = &m;
-      double bump;
-      auto no_bump = [&]() {
-        if (fetch_float_opt(mc, "bump_map", &bump, name, -1)) throw Unsupported("material '" + name + "': bump_map is out of scope (Material::bump, material/mod.rs:22-62)");
+      m.bump = -1;
+      auto no_bump = [&]() {   // fetch_float_texture_opt(.., "bump_map", None) :627-642: any float texture, constant ones included
+        const Json* v = mc.get("bump_map");
+        if (!(v && v->kind == Json::Str)) return;
+        auto it = float_tex.find(v->str);
+        if (it == float_tex.end()) throw Panic("renderprocess.rs:634 float_texture[\"" + v->str + "\"] missing (material " + name + ")");
+        if (it->second.node < 0 || !tex_ok[it->second.node]) throw Unsupported("material '" + name + "': bump_map '" + v->str + "' holds an ImageTexture that cannot be decoded here");
+        m.bump = it->second.node;
       };
       auto put = [&](const Rgb& r, double* dst) { for (int k = 0; k < 3; k++) dst[k] = r.c[k]; };
       if (type == "MatteMaterial") {

@@ -753,6 +753,36 @@ def _tex_case(which, wd):
         # s = t; DirectLighting drops NaN samples at the film (integrator/mod.rs:105) where the path integrator would assert on beta.
         if not tri:
             cfg["Integrator"] = {"integrator_type": "DirectLighting", "light_strategy": "all", "max_depth": 3}
+    elif which in ("path_bump_patch", "direct_bump_spheres"):
+        # Material::bump (material/mod.rs:22-62): displacement texture at (u + du, v), (u, v + dv), (u, v); du / dv from the differentials
+        cfg["float_texture"] = [{"texture_name": "wr", "texture_type": "WrinkledTexture", "octaves": 4, "omega": 0.5, **ROT, "scale": [2.0, 2.0, 2.0]},
+                                {"texture_name": "amp", "texture_type": "BilerpTexture", "v00": 0.03, "v01": 0.03},
+                                {"texture_name": "bumpy", "texture_type": "ScaleTexture", "t1": "wr", "t2": "amp"},
+                                {"texture_name": "chk", "texture_type": "CheckerBoardTexture", "t1": "amp", "aamode": "none",
+                                 "mapping": {"mapping": "uv", "su": 6.0, "sv": 6.0, "du": 0.0, "dv": 0.0}},
+                                {"texture_name": "lift", "texture_type": "BilerpTexture", "v00": 0.2, "v01": 0.2}]
+        if which == "path_bump_patch":
+            # depth 3, not 5: a bump-mapped normal is a finite difference of the displacement (step 0.0005), and each further bounce off the
+            # noise-bumped walls multiplies the rounding difference between device and oracle by ~100 (measured: 5e-14, 2e-10, 2e-8, 3e-6 of
+            # the image maximum at depths 2..5) - chaos in the scene, not a difference in the algorithm
+            cfg["Integrator"]["max_depth"] = 3
+            _write_patch(wd)
+            cfg["objs"] = cfg["objs"] + [{"filename": "patch.obj", "obj_name": "patch_01"}]
+            cfg["materials"] = cfg["materials"] + [{"material_type": "MatteMaterial", "material_name": "m_box", "bump_map": "bumpy"},
+                                                   {"material_type": "PlasticMaterial", "material_name": "m_cube", "bump_map": "chk"},
+                                                   {"material_type": "MetalMaterial", "material_name": "m_patch", "bump_map": "lift", "roughness": "amp"}]
+            cube["material_name"], box["material_name"] = "m_cube", "m_box"
+            cfg["Aggregate"]["primitives"].append({"primitive_type": "triangle", "material_name": "m_patch", "obj_name": "patch_01",
+                                                   "instances": [{"world_pos": [33.0, -2.5, 0.0], "rotation_axis": [0.2, 1.0, 0.1], "rotation_angle": 20}]})
+        else:
+            cfg, root = scenes.cfg1(wd, xres=64, yres=64, nsamp=5)
+            cfg["float_texture"] = [{"texture_name": "lift", "texture_type": "BilerpTexture", "v00": 0.2, "v01": 0.2},
+                                    {"texture_name": "ramp", "texture_type": "BilerpTexture", "v00": 0.0, "v01": 0.5}]
+            cfg["materials"] = cfg["materials"] + [{"material_type": "MatteMaterial", "material_name": "m_s", "bump_map": "lift"},   # constant, but dndu != 0 on a sphere
+                                                   {"material_type": "MirrorMaterial", "material_name": "m_mirror", "bump_map": "ramp"}]
+            inst = cfg["Aggregate"]["primitives"][0]["instances"]
+            cfg["Aggregate"]["primitives"] = [{"primitive_type": "sphere", "material_name": "m_s", "radius": 0.75, "instances": inst[::2]},
+                                              {"primitive_type": "sphere", "material_name": "m_mirror", "radius": 0.75, "instances": inst[1::2]}]
     elif which == "direct_spheres":
         cfg, root = scenes.cfg1(wd, xres=64, yres=64, nsamp=5)
         cfg["rgb_texture"] = [_const_rgb("w", [0.9, 0.9, 0.9]), _const_rgb("k", [0.2, 0.1, 0.1]),
@@ -767,14 +797,14 @@ def _tex_case(which, wd):
 
 
 @pytest.mark.parametrize("which", ["path_checker_uv", "path_noise", "direct_mirror_patch", "debug_glass_patch", "direct_spheres", "direct_image_ewa",
-                                   "path_image_trilinear"])
+                                   "path_image_trilinear", "path_bump_patch", "direct_bump_spheres"])
 def test_textured_materials(which, workdir):
     """Texture graph evaluated per hit (texture/*.rs), with the camera ray differentials (camera.rs:582-628, scaled by 1 / sqrt(spp)),
     compute_differentials incl. its `ty` quirk (interaction.rs:234), and - DirectLighting / Debug - the differentials specular
     children inherit (integrator/mod.rs:183-201 with its factor 0.2, :238-292)."""
     cfg, root = _tex_case(which, workdir)
     sc = Scene.loads(cfg, root)
-    assert sc.desc.n_textures > 0 and any(t >= 0 for m in sc.desc.materials[:sc.desc.n_materials] for t in m.tex)
+    assert sc.desc.n_textures > 0 and any(t >= 0 for m in sc.desc.materials[:sc.desc.n_materials] for t in list(m.tex) + [m.bump])
     ref, st_ref = O.render(sc, stats=True, flat=True)
     assert ref[..., :3].max() > 0
     r = Renderer(sc, 0, RRT_F64)
@@ -783,7 +813,7 @@ def test_textured_materials(which, workdir):
     assert np.array_equal(film[..., 3], ref[..., 3])
     assert st.camera_rays == st_ref.camera_rays
     diff = np.abs(film[..., :3] - ref[..., :3]).max(-1) / np.abs(ref[..., :3]).max()
-    if which == "direct_spheres":     # rays spawned on a sphere re-test it with c ~ +-1e-16 (test_sphere_primitives_render)
+    if which.endswith("spheres"):     # rays spawned on a sphere re-test it with c ~ +-1e-16 (test_sphere_primitives_render)
         assert (diff > 1e-9).mean() < 0.01, ((diff > 1e-9).mean(), diff.max())
     else:
         assert st.any_queries == st_ref.any_queries
@@ -795,9 +825,11 @@ def test_textured_materials(which, workdir):
     r.close()
     d32 = np.abs(f32[..., :3] - ref[..., :3]).max(-1) / np.abs(ref[..., :3]).max()
     print(which, "f32: within 1e-4:", (d32 < 1e-4).mean(), "median", np.median(d32), "max", d32.max(), "mean rel", abs(f32[..., :3].mean() / ref[..., :3].mean() - 1))
-    if which != "direct_spheres":     # fp32 spheres: parity in the mean only
+    if which == "path_bump_patch":        # the same chaos from an fp32 rounding (6e-8) instead of an f64 one: per-pixel bar at 1e-3
+        assert (d32 < 1e-3).mean() > 0.97, ((d32 < 1e-3).mean(), d32.max())
+    elif not which.endswith("spheres"):   # fp32 spheres: parity in the mean only
         assert (d32 < 1e-4).mean() > 0.97 and np.median(d32) < 1e-5, ((d32 < 1e-4).mean(), d32.max())
-    assert abs(f32[..., :3].mean() / ref[..., :3].mean() - 1) < (0.15 if which == "direct_spheres" else 0.02)
+    assert abs(f32[..., :3].mean() / ref[..., :3].mean() - 1) < (0.15 if which.endswith("spheres") else 0.02)
 
 
 def test_image_texture_ewa_panics_like_the_reference(workdir):

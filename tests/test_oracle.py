@@ -625,3 +625,26 @@ def test_image_texture_lookups_against_numpy(workdir):
         O.texture_eval(sc, 0, uv=(0.3, 0.3), duv=(1.5, 0.0, 0.0, 1.5))
     # ... whereas the trilinear path returns the last level's texel (0, 0)
     np.testing.assert_array_equal(O.texture_eval(sc, 1, uv=(0.3, 0.3), duv=(1.5, 0.0, 0.0, 1.5)), HR.mip_texel(pyr[-1], 0, 0, 0))
+
+
+def test_bump_map_tilts_the_shading_frame(tmp_path):
+    """Material::bump (material/mod.rs:22-62) on the unit frame of oracle_bsdf_eval (p = 0, uv = 0, dpdu = +x, dpdv = +y, no
+    differentials -> du = dv = 0.0005): a bilinear displacement d = c (1 - (1 - u)(1 - v)) (the loader's (v00, v01, v01, v01) corners)
+    has slope c in u and in v at the origin, so the shading normal becomes normalize(-c, -c, 1) and a mirror reflects about it."""
+    c = 0.3
+    cfg, root = scenes.cfg2(str(tmp_path), xres=16, yres=16, nsamp=2)
+    cfg["float_texture"] = [{"texture_name": "ramp", "texture_type": "BilerpTexture", "v00": 0.0, "v01": c},
+                            {"texture_name": "flat", "texture_type": "BilerpTexture", "v00": 0.7, "v01": 0.7}]
+    cfg["materials"] = [{"material_type": "MirrorMaterial", "material_name": "m0", "bump_map": "ramp"},
+                        {"material_type": "MirrorMaterial", "material_name": "m1", "bump_map": "flat"},
+                        {"material_type": "MirrorMaterial", "material_name": "m2"}]
+    cfg["Aggregate"]["primitives"][0]["material_name"] = "m0"
+    sc = Scene.loads(cfg, root)
+    assert [m.bump for m in sc.desc.materials[:3]] == [0, 1, -1]
+    wo = _dir(0.4, 1.1)
+    n = np.array([-c, -c, 1.0]); n /= np.linalg.norm(n)
+    got = O.bsdf_eval(sc, 0, wo, wo)["s_wi"]
+    np.testing.assert_allclose(got, -wo + 2 * (wo @ n) * n, rtol=0, atol=2e-12)     # finite differences of a bilinear function: exact up to rounding
+    # a constant displacement moves nothing on a flat surface (dndu = dndv = 0); no bump_map: the geometric frame
+    for k in (1, 2):
+        np.testing.assert_allclose(O.bsdf_eval(sc, k, wo, wo)["s_wi"], [-wo[0], -wo[1], wo[2]], rtol=0, atol=1e-15)
