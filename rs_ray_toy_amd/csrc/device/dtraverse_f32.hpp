@@ -584,11 +584,17 @@ static __global__ void __launch_bounds__(kBlock) k_compact_alive(Pools<float> p,
 // p_film + 0.05 px in x (then - 0.05 if that one is blocked), then the same in y. Nearly every main-ray survivor
 // passes x+ and y+, so all lanes run the same 2 x 13 interfaces. A sample whose x or y pair is blocked both ways
 // gets weight 0; the others enter q_active with ray, path record and a zeroed L. `enqueue` = 0 for AOIntegrator.
-RRT_DEV bool rg_trace(const SceneDev<float>& s, const float4* lens_s, float pfx, float pfy, float lx, float ly) {
+RRT_DEV bool rg_trace(const SceneDev<float>& s, const float4* lens_s, float pfx, float pfy, float lx, float ly, RayT<float>* out = nullptr) {
   RgLane L; L.phase = 0;
   float w = 0.0f;
   rg_begin(s, pfx, pfy, lx, ly, &L, &w);
   while (L.i >= 0) if (!rg_step(lens_s, &L)) return false;
+  if (out) {   // the auxiliary ray itself (textured scenes: ray differentials), as generate_ray leaves it (camera.rs:558-565)
+    RayT<float> rl; rl.o = L.o; rl.d = L.d;
+    const RayT<float> rc = flip_z(rl);
+    out->o = aff_pt(s.cam_m, rc.o);
+    out->d = vnormalize(vnormalize(vnormalize(aff_vec(s.cam_m, rc.d))));
+  }
   return w != 0.0f;
 }
 static __global__ void __launch_bounds__(kRgBlock) k_raygen_aux_f32(SceneDev<float> s, Pools<float> p, int enqueue) {
@@ -606,15 +612,28 @@ static __global__ void __launch_bounds__(kRgBlock) k_raygen_aux_f32(SceneDev<flo
     slot = p.q_next[i].slot;
     const float4 cs = p.samp[slot];
     const float pfx = cs.x, pfy = cs.y, lx = cs.z, ly = cs.w;
-    bool okx = rg_trace(s, lens_s, pfx + 0.05f, pfy, lx, ly);
-    if (!okx) okx = rg_trace(s, lens_s, pfx - 0.05f, pfy, lx, ly);
+    const bool diffs = p.rdx_o != nullptr;   // block-uniform
+    RayT<float> aux, auy;
+    float epsx = 0.05f, epsy = 0.05f;
+    bool okx = rg_trace(s, lens_s, pfx + 0.05f, pfy, lx, ly, diffs ? &aux : nullptr);
+    if (!okx) { epsx = -0.05f; okx = rg_trace(s, lens_s, pfx - 0.05f, pfy, lx, ly, diffs ? &aux : nullptr); }
     bool oky = false;
     if (okx) {
-      oky = rg_trace(s, lens_s, pfx, pfy + 0.05f, lx, ly);
-      if (!oky) oky = rg_trace(s, lens_s, pfx, pfy - 0.05f, lx, ly);
+      oky = rg_trace(s, lens_s, pfx, pfy + 0.05f, lx, ly, diffs ? &auy : nullptr);
+      if (!oky) { epsy = -0.05f; oky = rg_trace(s, lens_s, pfx, pfy - 0.05f, lx, ly, diffs ? &auy : nullptr); }
     }
     alive = okx && oky;
     if (!alive) p.weight[slot] = 0.0f;
+    if (alive && diffs) {   // rx / ry (camera.rs:597-598, 613-614), then scale_differentials (geometry.rs:1883-1888); see k_raygen_aux
+      const float4 mo = p.nray_o[slot], md = p.nray_d[slot];
+      const V3<float> o(mo.x, mo.y, mo.z), d(md.x, md.y, md.z);
+      V3<float> rxo = o + (aux.o - o) / epsx, rxd = d + (aux.d - d) / epsx;
+      V3<float> ryo = o + (auy.o - o) / epsy, ryd = d + (auy.d - d) / epsy;
+      rxo = o + (rxo - o) * s.diff_scale; ryo = o + (ryo - o) * s.diff_scale;
+      rxd = d + (rxd - d) * s.diff_scale; ryd = d + (ryd - d) * s.diff_scale;
+      p.rdx_o[slot] = make_float4(rxo.x, rxo.y, rxo.z, 0.0f); p.rdx_d[slot] = make_float4(rxd.x, rxd.y, rxd.z, 0.0f);
+      p.rdy_o[slot] = make_float4(ryo.x, ryo.y, ryo.z, 0.0f); p.rdy_d[slot] = make_float4(ryd.x, ryd.y, ryd.z, 0.0f);
+    }
   }
   const bool enq = alive && enqueue;
   const uint32_t q = block_push(&p.counters[C_ACTIVE], enq, push_lds);

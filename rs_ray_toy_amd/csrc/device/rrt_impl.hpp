@@ -908,7 +908,7 @@ class Handle : public HandleBase {
   // camera ray generation: persistent-thread kernel in fp32, two-stage (main trace, compaction, auxiliary traces) in f64
   void launch_raygen(const PassDesc& pd, uint32_t grid, double* dims_out, int enqueue) {
     if constexpr (std::is_same<R, float>::value) {
-      if (raygen_pt_ && scene_.n_lens <= 32 && scene_.sampler_type == RRT_SAMPLER_HALTON && tex_depth_ == 0) {   // textured scenes: the generic raygen keeps the auxiliary rays (differentials)
+      if (raygen_pt_ && scene_.n_lens <= 32 && scene_.sampler_type == RRT_SAMPLER_HALTON) {
         if (rg_grid_ == 0) {
           int per_cu = 0, cus = 0;
           HIP_CHECK(hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, dev_));
