@@ -65,8 +65,8 @@ def cpu_baseline(scene, target_seconds):
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
-    ap.add_argument("--steps", type=int, default=3)
-    ap.add_argument("--warmup", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=6)
+    ap.add_argument("--warmup", type=int, default=2)
     ap.add_argument("--res", type=int, default=1024)
     ap.add_argument("--spp", type=int, default=256)
     ap.add_argument("--depth", type=int, default=8)
@@ -85,7 +85,7 @@ def main():
     import torch
     import torch.distributed as dist
 
-    from rs_ray_toy_amd import RRT_F32, RRT_FIXED_BVH, Renderer, Scene, scenes
+    from rs_ray_toy_amd import RRT_F32, RRT_FIXED_BVH, Renderer, RrtError, Scene, scenes
     from rs_ray_toy_amd.partition import band_rects, reduce_film
 
     rank = int(os.environ.get("RANK", "0"))
@@ -160,7 +160,24 @@ def main():
     r.set_option("count_traversal", 1)
     counted = step(collect=True)
     r.set_option("count_traversal", 0)
-    run_frames(max(args.warmup, nfl if nfl > 1 else 0))   # (at least one untimed frame per handle: pool allocation)
+    try:
+        run_frames(max(args.warmup, nfl if nfl > 1 else 0))   # (at least one untimed frame per handle: pool allocation)
+    except RrtError as e:
+        # e.g. not enough free HBM for a second set of wavefront pools: go on with one frame at a time (every rank still reduces once
+        # per frame, in frame order, so ranks may differ in this)
+        if nfl == 1:
+            raise
+        print(f"[rank {rank}] two frames in flight not possible here ({e}); one frame at a time", file=sys.stderr)
+        for h in handles:
+            try:
+                h.render_end()
+            except RrtError:
+                pass
+        for h in handles[1:]:
+            h.close()
+        nfl = 1
+        del handles[1:], films[1:]
+        run_frames(args.warmup)
     sync()
     t0 = time.perf_counter()
     run_frames(args.steps)
