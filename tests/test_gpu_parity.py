@@ -856,3 +856,44 @@ def test_image_texture_ewa_panics_like_the_reference(workdir):
         if not tri:
             with pytest.raises(O.OracleError, match="out of bounds"):
                 O.render(sc)
+
+
+@pytest.mark.parametrize("which", ["stratified_gaussian_passes", "bands_and_frames_in_flight"])
+def test_textured_scene_across_features(which, workdir):
+    """Textures and ray differentials together with the other features of the path: the stratified sampler (scale_differentials takes
+    1 / sqrt(xsamp * ysamp)), a wide film filter, several pool passes (the per-slot differential records are per pass), band
+    partitions and frames in flight."""
+    import torch
+    cfg, root = _tex_case("path_checker_uv", workdir)
+    if which == "stratified_gaussian_passes":
+        cfg["Sampler"] = {"sampler_type": "StratifiedSampler", "xsamp": 3, "ysamp": 3, "jitter": True, "dimension": 6}
+        cfg["Film"]["Filter"] = {"filter_type": "GaussianFilter", "radius": [1.5, 1.5], "alpha": 1.0}
+    sc = Scene.loads(cfg, root)
+    ref = O.render(sc, flat=True)
+    scale = np.abs(ref[..., :3]).max()
+    if which == "stratified_gaussian_passes":
+        for prec, tol in ((RRT_F64, 1e-9), (RRT_F32, 1e-4)):
+            r = Renderer(sc, 0, prec)
+            r.set_option("max_paths", 64 * 64 * 3)       # 8 samples per pixel -> 3 passes
+            film = r.render().astype(np.float64)
+            r.close()
+            np.testing.assert_allclose(film[..., 3], ref[..., 3], rtol=1e-6 if prec == RRT_F32 else 1e-12)
+            d = np.abs(film[..., :3] - ref[..., :3]).max(-1) / scale
+            assert (d < tol).mean() > (0.97 if prec == RRT_F32 else 0.9999), (prec, (d < tol).mean(), d.max())
+    else:
+        hs = [Renderer(sc, 0, RRT_F64) for _ in range(2)]
+        for h in hs:
+            h.set_option("nonblocking_streams", 1)
+        films = [torch.zeros((64, 64, 4), dtype=torch.float64, device="cuda:0") for _ in range(2)]
+        torch.cuda.synchronize()
+        for k in range(2):
+            hs[k].render_bands_begin(k, 2, films[k].data_ptr())
+        for h in hs:
+            h.render_end()
+        torch.cuda.synchronize()
+        film = (films[0] + films[1]).cpu().numpy()
+        for h in hs:
+            h.close()
+        assert np.array_equal(film[..., 3], ref[..., 3])
+        d = np.abs(film[..., :3] - ref[..., :3]).max(-1) / scale
+        assert d.max() < 1e-9, d.max()
