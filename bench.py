@@ -76,6 +76,8 @@ def main():
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--max-paths", type=int, default=0)
     ap.add_argument("--opt", action="append", default=[], help="handle option key=value (rrt_set_option), e.g. pt_split_any=1e9")
+    ap.add_argument("--dist-backend", default="nccl", choices=("nccl", "gloo"),
+                    help="gloo: rehearse the multi-rank path with more ranks than GPUs (ranks share devices, films reduced on the host)")
     ap.add_argument("--frames-in-flight", type=int, default=2, choices=(1, 2),
                     help="2: alternate two handles (rrt_render_bands_begin / _end): a frame's latency-bound last bounces drain "
                          "while the next frame's camera rays fill the chip; 1: one synchronous frame at a time")
@@ -96,10 +98,15 @@ def main():
             raise SystemExit("launch with torch.distributed.run --nproc-per-node N for --gpus N")
     if not torch.cuda.is_available():
         raise SystemExit("bench.py needs a GPU (no CPU fallback exists for the product path)")
+    if args.dist_backend == "gloo":
+        local_rank = local_rank % torch.cuda.device_count()   # rehearsal: ranks may share a device
     torch.cuda.set_device(local_rank)
     if world > 1:
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
-        dist.init_process_group("nccl", rank=rank, world_size=world, device_id=torch.device("cuda", local_rank))
+        if args.dist_backend == "gloo":
+            dist.init_process_group("gloo", rank=rank, world_size=world)
+        else:
+            dist.init_process_group("nccl", rank=rank, world_size=world, device_id=torch.device("cuda", local_rank))
 
     # ---- setup (untimed): scene build on the host, upload, pools ------------------------------------------------
     wd = tempfile.mkdtemp(prefix=f"rrt_bench_r{rank}_")
@@ -193,11 +200,12 @@ def main():
     r.set_option("overlap_shadow", 1)
     sync()
 
-    tt = torch.tensor([elapsed], dtype=torch.float64, device=f"cuda:{local_rank}")
+    stat_dev = "cpu" if args.dist_backend == "gloo" else f"cuda:{local_rank}"
+    tt = torch.tensor([elapsed], dtype=torch.float64, device=stat_dev)
     keys = ["camera_samples", "camera_rays", "closest_queries", "any_queries", "closest_nodes", "closest_prims", "any_nodes", "any_prims", "closest_launches"]
     counted["closest_launches"] = timed["closest_launches"]
     cnt = torch.tensor([float(counted[k]) for k in keys] + [timed["ms_closest"], timed["ms_any"], timed["ms_shade"], timed["ms_raygen"], timed["ms_film"], timed["ms_total"], isolated["ms_closest"]],
-                       dtype=torch.float64, device=f"cuda:{local_rank}")
+                       dtype=torch.float64, device=stat_dev)
     if world > 1:
         dist.all_reduce(tt, op=dist.ReduceOp.MAX)
         mx = cnt.clone()
