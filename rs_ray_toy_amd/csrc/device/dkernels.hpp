@@ -522,8 +522,8 @@ __global__ void __launch_bounds__(kBlock) k_raygen(SceneDev<R> s, Pools<R> p, Pa
 }
 
 // Stage 2 (survivors): the auxiliary rays of generate_ray_differential (camera.rs:582-628) at p_film +- 0.05 px in
-// x then y. Only whether they make it through the lens is observable (the differentials feed texture filtering,
-// and only constant textures are in scope): a sample whose x or y pair both fail gets weight 0. Living samples
+// x then y. A sample whose x or y pair both fail gets weight 0; on scenes with textured materials the auxiliary rays
+// themselves are kept as the camera ray's differentials (p.rdx_* / p.rdy_*). Living samples
 // enter q_active with their ray at the same position. `enqueue` = 0 for AOIntegrator, whose li returns 0 before
 // drawing anything (ao.rs:62-64).
 template <typename R>
@@ -1067,8 +1067,9 @@ __global__ void __launch_bounds__(ShadeBlock<R>::n) k_shade_nee(SceneDev<R> s, P
   }
 }
 
-// specular_reflect (integrator/mod.rs:150-198) as the chain's continuation; specular_transmit (:199-301) finds
-// no transmissive lobe among the in-scope materials and its 2D draw lands after the recursion returns.
+// specular_reflect (integrator/mod.rs:150-198) as the chain's continuation; this chain only runs on scenes without
+// transmissive or textured materials (those take k_direct_tree), where specular_transmit (:199-301) finds no lobe and
+// its 2D draw lands after the recursion returns.
 // `depth` of the reference starts at 1; the high half of dim_bounce stores depth - 1.
 template <typename R>
 __global__ void __launch_bounds__(ShadeBlock<R>::n) k_shade_specular(SceneDev<R> s, Pools<R> p, int grey_only) {

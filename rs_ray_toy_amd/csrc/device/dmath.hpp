@@ -742,7 +742,8 @@ struct Bsdf {
 };
 
 // Material::compute_scattering_functions (matte.rs:35-60, plastic.rs:42-73, metal.rs:48-89, mirror.rs:27-47,
-// debug_material.rs:37-48) with constant textures
+// debug_material.rs:37-48, glass.rs:52-112, translucent.rs:52-107) from parameter values (textured parameters are
+// evaluated first, resolve_material() in dtexture.hpp)
 template <typename R, int NL> RRT_DEV void build_lobes(const Material<R>& m, Bsdf<R, NL>* b, bool allow_multiple_lobes = true) {
   b->n = 0;
   b->eta = R(1);

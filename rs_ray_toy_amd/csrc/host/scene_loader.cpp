@@ -492,7 +492,7 @@ struct Loader {
   }
   uint32_t material_index(const std::string& name, const std::string& who) {
     const MatEntry& me = materials[name];
-    if (me.index < 0) throw Unsupported(who + " uses material '" + name + "' of type " + me.unsupported_type + " (out of scope this round, SURVEY §8f rank 2)");
+    if (me.index < 0) throw Unsupported(who + " uses material '" + name + "' of type " + me.unsupported_type + " (outside the hot-path scope, SURVEY §2 row 22)");
     return (uint32_t)me.index;
   }
 
