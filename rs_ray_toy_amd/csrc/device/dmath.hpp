@@ -156,7 +156,7 @@ RRT_DEV uint32_t div_base(uint32_t a, const HaltonDim& hd, uint32_t fast) {
 }
 // radical_inverse_specialized lowdiscrepancy.rs:188-202
 RRT_DEV double radical_inverse_dev(uint32_t a, const HaltonDim& hd, uint32_t fast) {
-  const double inv_base = 1.0 / (double)hd.base;
+  const double inv_base = hd.inv;   // = 1.0 / (double)base, the same correctly rounded quotient (an f64 division costs ~60 issue slots here)
   uint64_t reversed = 0;
   double inv_base_n = 1.0;
   while (a != 0) {
@@ -170,7 +170,7 @@ RRT_DEV double radical_inverse_dev(uint32_t a, const HaltonDim& hd, uint32_t fas
 }
 // scrambled_radical_inverse_specialized lowdiscrepancy.rs:204-227
 RRT_DEV double scrambled_radical_inverse_dev(uint32_t a, const HaltonDim& hd, const uint16_t* perm, uint32_t fast) {
-  const double inv_base = 1.0 / (double)hd.base;
+  const double inv_base = hd.inv;
   uint64_t reversed = 0;
   double inv_base_n = 1.0;
   while (a > 0) {
@@ -180,7 +180,8 @@ RRT_DEV double scrambled_radical_inverse_dev(uint32_t a, const HaltonDim& hd, co
     inv_base_n *= inv_base;
     a = next;
   }
-  return fmin(inv_base_n * ((double)reversed + inv_base * (double)perm[0] / (1.0 - inv_base)), 0.99999999999999989);
+  // hd.tail = inv_base * perm[0] / (1 - inv_base), evaluated once per dimension on the host with the same three f64 operations
+  return fmin(inv_base_n * ((double)reversed + hd.tail), 0.99999999999999989);
 }
 // Halton::sample_dimension halton.rs:107-128 (index < 2^32 checked on the host)
 template <typename R>

@@ -106,6 +106,7 @@ struct HaltonDim {   // one entry per sampler dimension >= 2
   uint32_t perm_offset;   // PRIME_SUMS[dim]
   uint64_t magic;         // floor(2^40 / base) + 1 : exact a / base for a < 2^26, base <= 8192
   double inv;             // 1 / base: a / base for any 32-bit a = (uint32_t)(a * inv) with a +-1 fix-up (div_base())
+  double tail;            // inv * perm[0] / (1 - inv): the infinitely many trailing zero digits of the scrambled radical inverse
 };
 
 template <typename R>

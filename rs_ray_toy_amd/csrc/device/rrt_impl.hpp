@@ -778,6 +778,14 @@ class Handle : public HandleBase {
     }
     std::vector<uint16_t> perms;
     if (d->sampler.type == RRT_SAMPLER_HALTON && d->sampler.perms) perms.assign(d->sampler.perms, d->sampler.perms + d->sampler.n_perms);
+    for (auto& h : hd) {   // lowdiscrepancy.rs:225: inv_base * perm[0] / (1 - inv_base), operation by operation
+      h.tail = 0.0;
+      if (h.perm_offset < perms.size()) {
+        volatile double num = h.inv * (double)perms[h.perm_offset];
+        volatile double den = 1.0 - h.inv;
+        h.tail = num / den;
+      }
+    }
 
     nodes_.upload(nodes, st_); tris_.upload(tris, st_); build_pairs(nodes, tris.size()); shades_.upload(shades, st_); spheres_.upload(spheres, st_);
     materials_.upload(mats, st_); textures_.upload(texs, st_); images_.upload(imgs, st_); image_texels_.upload(texels, st_);
