@@ -932,12 +932,18 @@ __global__ void __launch_bounds__(ShadeBlock<R>::n) __attribute__((amdgpu_waves_
         R eta_scale = st_b.w;
         // uniform_sample_one_light integrator/mod.rs:359-401 with the uniform Distribution1D (path.rs:47-49)
         if (bsdf.num_components(BXDF_ALL & ~BXDF_SPECULAR) > 0 && s.n_lights > 0) {
-          double du0, du1;
-          R u_pick = to_real<R>(draw_1d(s, index, &dim));
-          draw_2d(s, index, &dim, &du0, &du1);
+          // Sampler values nobody reads are not computed, only counted (a radical inverse in a high dimension is ~6 digit
+          // steps of f64 / u64 arithmetic, and these three were half of this kernel's draws): with one light the discrete
+          // distribution returns light 0 for every u; point and distant lights ignore their 2D sample (point.rs:55-77,
+          // distant.rs:67-92).
+          double du0 = 0.0, du1 = 0.0;
+          uint32_t ln = 0;
+          if (s.n_lights == 1u) skip_1d(s, &dim);
+          else ln = sample_light_discrete(s, to_real<R>(draw_1d(s, index, &dim)));
+          if (s.lights[ln].type != 1) skip_2d(s, &dim);
+          else draw_2d(s, index, &dim, &du0, &du1);
           R ul0 = to_real<R>(du0), ul1 = to_real<R>(du1);
           skip_2d(s, &dim);  // u_scattering: drawn, only used by the BSDF-sampling half
-          uint32_t ln = sample_light_discrete(s, u_pick);
           V3<R> so, sd;
           Rgb<R> ld;
           if (s.light_pick_pdf != R(0) && estimate_direct_light(si, bsdf, s.lights[ln], ul0, ul1, &so, &sd, &ld)) {

@@ -273,6 +273,10 @@ template <typename R> RRT_DEV void skip_2d(const SceneDev<R>& s, uint32_t* d) {
   if (s.sampler_type == 1u) { const uint32_t k = (*d >> 8) & 0xffu; *d = (*d & ~0xff00u) | (((k + 1u) & 0xffu) << 8); }
   else *d += 2u;
 }
+template <typename R> RRT_DEV void skip_1d(const SceneDev<R>& s, uint32_t* d) {
+  if (s.sampler_type == 1u) { const uint32_t k = *d & 0xffu; *d = (*d & ~0xffu) | ((k + 1u) & 0xffu); }
+  else *d += 1u;
+}
 template <typename R> RRT_DEV R to_real(double u) { return (R)u; }
 template <> RRT_DEV float to_real<float>(double u) { return fminf((float)u, Const<float>::one_minus_eps); }  // keep u < 1 after narrowing
 
