@@ -476,13 +476,22 @@ RRT_DEV bool rg_step(const float4* lens_s, RgLane* L) {
 // Stage 1, dense (one thread per slot, every lane busy): get_camerasample (samplers/mod.rs:28-34) = Halton index and
 // the four film / lens dimensions, plus the initial path state. All stores are coalesced in slot order, which is why
 // the sample of every slot is written: 6 streamed words per slot (one 128-bit sample record, index, weight). `dims_out` (optional): the five sampler dimensions per slot, [pixel][sample] order (rrt_camera_samples)
-static __global__ void __launch_bounds__(kBlock) k_sample_f32(SceneDev<float> s, Pools<float> p, PassDesc pd, double* dims_out) {
-  const uint32_t slot = blockIdx.x * blockDim.x + threadIdx.x;
-  if (slot >= pd.npix * pd.ns) return;
-  const uint32_t pl = slot % pd.npix, sl = slot / pd.npix;
+static __global__ void __launch_bounds__(kBlock) k_pixel_offsets(SceneDev<float> s, Pools<float> p, PassDesc pd) {
+  const uint32_t pl = blockIdx.x * blockDim.x + threadIdx.x;
+  if (pl >= pd.npix) return;
   uint32_t px, py;
   pass_pixel(pd, pd.pix_begin + pl, &px, &py);
-  const uint32_t index = halton_pixel_offset(s, px, py) + (pd.s_begin + sl) * s.stride;
+  p.pix_off[2 * pl] = halton_pixel_offset(s, px, py);
+  p.pix_off[2 * pl + 1] = (py << 16) | px;
+}
+// grid: x = pixel blocks, y = sample of the pass (no division by runtime values per slot)
+static __global__ void __launch_bounds__(kBlock) k_sample_f32(SceneDev<float> s, Pools<float> p, PassDesc pd, double* dims_out) {
+  const uint32_t pl = blockIdx.x * blockDim.x + threadIdx.x, sl = blockIdx.y;
+  if (pl >= pd.npix) return;
+  const uint32_t slot = sl * pd.npix + pl;
+  const uint2 po = reinterpret_cast<const uint2*>(p.pix_off)[pl];
+  const uint32_t px = po.y & 0xffffu, py = po.y >> 16;
+  const uint32_t index = po.x + (pd.s_begin + sl) * s.stride;
   const double d0 = halton_dim(s, index, 0), d1 = halton_dim(s, index, 1), d2 = halton_cam_dim(s, index, 0), d3 = halton_cam_dim(s, index, 1);
   p.samp[slot] = make_float4((float)px + to_real<float>(d0), (float)py + to_real<float>(d1), to_real<float>(d2) + 0.5f, to_real<float>(d3) + 0.5f);   // p_film, p_lens (Q5)
   p.hindex[slot] = index;

@@ -193,6 +193,8 @@ struct Pools {
   R* weight;             // camera ray weight (0 = dead sample: its L is never read)
   V4* samp;              // camera sample {p_film.x, p_film.y, p_lens.x, p_lens.y}: one 128-bit gather per survivor
   uint32_t* hindex;      // Halton index (raygen -> first queue entry)
+  uint32_t* pix_off;     // per pixel of the pass, two words: {Halton index of its sample 0, y << 16 | x} (halton_pixel_offset: two 64-bit products and a 64-bit
+                         // modulo, the same for all samples of a pixel), filled by k_pixel_offsets before the fp32 sampling kernel
   // camera ray differentials after scale_differentials (scenes with textured materials only, else null):
   // {rx_origin, -}, {rx_direction, -}, {ry_origin, -}, {ry_direction, -} per slot
   V4 *rdx_o, *rdx_d, *rdy_o, *rdy_d;

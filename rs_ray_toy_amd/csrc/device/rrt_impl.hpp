@@ -494,6 +494,7 @@ class Handle : public HandleBase {
   int trav_mode_ = 3;   // 1 = LDS-treelet grid-stride kernel, 2 = persistent-thread kernel, 3 = by queue size
   uint32_t pt_split_closest_ = 100000u, pt_split_any_ = 100000u;   // re-tuned with the shadow launches overlapped (tools/band_scaling.py)
   DevBuf<uint32_t> pt_overflow_, pt_overflow_any_;
+  DevBuf<uint32_t> pix_off_;
   TravScene trav_{};
   DevBuf<PairNode> pairs_;
   DevBuf<uint32_t> overflow_, overflow_any_;
@@ -871,6 +872,7 @@ class Handle : public HandleBase {
     auto nu = [&]() { uint32_t* x = u; u += cap_; return x; };
     p.q_active = (QEnt*)u; u += 4 * cap_; p.q_next = (QEnt*)u; u += 4 * cap_; p.hindex = nu();
     p.counters = counters_.p;
+    p.pix_off = pix_off_.p;
     p.shadow_count = counters_.p + C_SHADOW;
     shadow_buf_[0][0] = p.sray_o; shadow_buf_[0][1] = p.sray_d; shadow_buf_[0][2] = p.sld;
     shadow_buf_[1][0] = shadow_buf_[1][1] = shadow_buf_[1][2] = nullptr;
@@ -916,7 +918,7 @@ class Handle : public HandleBase {
   // camera ray generation: persistent-thread kernel in fp32, two-stage (main trace, compaction, auxiliary traces) in f64
   void launch_raygen(const PassDesc& pd, uint32_t grid, double* dims_out, int enqueue) {
     if constexpr (std::is_same<R, float>::value) {
-      if (raygen_pt_ && scene_.n_lens <= 32 && scene_.sampler_type == RRT_SAMPLER_HALTON) {
+      if (raygen_pt_ && scene_.n_lens <= 32 && scene_.sampler_type == RRT_SAMPLER_HALTON && scene_.xres < 65536 && scene_.yres < 65536 && pd.ns <= 65535u) {
         if (rg_grid_ == 0) {
           int per_cu = 0, cus = 0;
           HIP_CHECK(hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, dev_));
@@ -925,7 +927,10 @@ class Handle : public HandleBase {
         }
         const uint32_t total = pd.npix * pd.ns;
         const uint32_t g = std::max(1u, std::min((total + kRgBlock - 1) / kRgBlock, rg_grid_));
-        hipLaunchKernelGGL(k_sample_f32, dim3((total + kBlock - 1) / kBlock), dim3(kBlock), 0, st_, scene_, pool_, pd, dims_out);
+        if (pix_off_.n < 2 * (size_t)pd.npix) { HIP_CHECK(hipStreamSynchronize(st_)); pix_off_.alloc(2 * (size_t)pd.npix); }
+        pool_.pix_off = pix_off_.p;
+        hipLaunchKernelGGL(k_pixel_offsets, dim3((pd.npix + kBlock - 1) / kBlock), dim3(kBlock), 0, st_, scene_, pool_, pd);
+        hipLaunchKernelGGL(k_sample_f32, dim3((pd.npix + kBlock - 1) / kBlock, pd.ns), dim3(kBlock), 0, st_, scene_, pool_, pd, dims_out);
         hipLaunchKernelGGL(k_raygen_pt_f32, dim3(g), dim3(kRgBlock), 0, st_, scene_, pool_, pd, &counters_.p[C_WORK_AUX]);
         const uint32_t n_cw = (total + 64u * kCompactRun - 1) / (64u * kCompactRun);   // waves
         hipLaunchKernelGGL(k_compact_alive, dim3((n_cw * 64u + kBlock - 1) / kBlock), dim3(kBlock), 0, st_, pool_, total);
