@@ -147,7 +147,7 @@ RRT_DEV uint32_t block_push(uint32_t* counter, bool pred, uint32_t* lds) {
 // hardware-less 32-bit division costs ~40 instructions per digit of every dimension: a double-precision reciprocal
 // (relative error 2^-53 against the 2^-45 needed) plus a one-step correction is exact and 5 instructions.
 RRT_DEV uint32_t div_base(uint32_t a, const HaltonDim& hd, uint32_t fast) {
-  if (fast) return (uint32_t)(((uint64_t)a * hd.magic) >> 40);
+  if (fast || a < (1u << 26)) return (uint32_t)(((uint64_t)a * hd.magic) >> 40);   // (every digit after the first: a has shrunk below 2^26)
   uint32_t q = (uint32_t)((double)a * hd.inv);
   const uint32_t r = a - q * hd.base;          // wraps when q is one too large
   if ((int32_t)r < 0) q -= 1;
