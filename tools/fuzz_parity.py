@@ -1,0 +1,99 @@
+"""Randomised parity sweep (not part of the test suite): small scenes mixing the features of the path - integrators, samplers,
+filters, materials incl. textures / bump maps, lights - rendered by the f64 device mode and by the oracle.
+usage: python tools/fuzz_parity.py [n_cases] [seed]"""
+import os, sys, tempfile, traceback
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, ROOT); sys.path.insert(0, os.path.join(ROOT, "tests"))
+import numpy as np
+import oracle_lib as O
+from rs_ray_toy_amd import RRT_F64, RRT_FIXED_BVH, Renderer, RrtError, Scene, scenes
+
+n_cases = int(sys.argv[1]) if len(sys.argv) > 1 else 40
+rng = np.random.default_rng(int(sys.argv[2]) if len(sys.argv) > 2 else 1)
+ROT = {"rotation_axis": [1.0, 2.0, 0.5], "rotation_angle": 25.0}
+
+def const_rgb(name, v):
+    return {"texture_name": name, "texture_type": "BilerpTexture", "v00": {"values": v}, "v01": {"values": v}}
+
+def palette(cfg):
+    cfg["float_texture"] = [{"texture_name": "f_lo", "texture_type": "BilerpTexture", "v00": 0.05, "v01": 0.05},
+                            {"texture_name": "f_hi", "texture_type": "BilerpTexture", "v00": 0.3, "v01": 0.3},
+                            {"texture_name": "f_ramp", "texture_type": "BilerpTexture", "v00": 0.0, "v01": 30.0},
+                            {"texture_name": "f_chk3", "texture_type": "CheckerBoardTexture", "dimension": 3, "t1": "f_lo", "t2": "f_hi", **ROT, "scale": [0.5, 0.5, 0.5]},
+                            {"texture_name": "f_ior", "texture_type": "BilerpTexture", "v00": 1.5, "v01": 1.5},
+                            {"texture_name": "f_bump", "texture_type": "BilerpTexture", "v00": 0.0, "v01": 0.02}]
+    cfg["rgb_texture"] = [const_rgb("c_w", [0.8, 0.8, 0.7]), const_rgb("c_k", [0.2, 0.1, 0.3]), const_rgb("c_one", [1.0, 1.0, 1.0]),
+                          {"texture_name": "t_uv", "texture_type": "UVTexture", "mapping": {"mapping": "uv", "su": 2.0, "sv": 3.0}},
+                          {"texture_name": "t_chk", "texture_type": "CheckerBoardTexture", "t1": "c_w", "t2": "c_k", "aamode": "none",
+                           "mapping": {"mapping": "uv", "su": 5.0, "sv": 5.0, "du": 0.0, "dv": 0.0}},
+                          {"texture_name": "t_chk_aa", "texture_type": "CheckerBoardTexture", "t1": "c_w", "t2": "t_uv",
+                           "mapping": {"mapping": "planar", "v1": [0.3, 0.0, 0.0], "v2": [0.0, 0.1, 0.3], "udelta": 0.3, "vdelta": 0.1}},
+                          {"texture_name": "t_wr", "texture_type": "WrinkledTexture", "octaves": 3, "omega": 0.5, **ROT},
+                          {"texture_name": "t_mix", "texture_type": "MixTexture", "t1": "t_chk", "t2": "t_uv"},
+                          {"texture_name": "t_scale", "texture_type": "ScaleTexture", "t1": "t_wr", "t2": "c_w"}]
+    mats = [{"material_type": "MatteMaterial", "kd": "t_chk", "sigma": "f_ramp"}, {"material_type": "MatteMaterial", "kd": "t_chk_aa"},
+            {"material_type": "MatteMaterial", "kd": "t_scale"}, {"material_type": "MatteMaterial"},
+            {"material_type": "PlasticMaterial", "kd": "t_mix", "ks": "c_w", "roughness": "f_chk3"}, {"material_type": "PlasticMaterial", "remap_roughness": True},
+            {"material_type": "MetalMaterial", "roughness": "f_hi"}, {"material_type": "MetalMaterial", "u_roughness": "f_lo", "v_roughness": "f_hi", "bump_map": "f_bump"},
+            {"material_type": "MirrorMaterial", "kr": "t_chk"}, {"material_type": "MirrorMaterial"},
+            {"material_type": "GlassMaterial", "kr": "c_one", "kt": "c_w", "eta": "f_ior"}, {"material_type": "GlassMaterial", "u_roughness": "f_hi", "v_roughness": "f_lo", "kt": "c_w"},
+            {"material_type": "TranslucentMaterial", "kd": "t_uv", "ks": "c_k", "reflect": "c_w", "transmit": "c_w"}, {"material_type": "Debug"}]
+    for i, m in enumerate(mats):
+        m["material_name"] = f"fz{i}"
+    cfg["materials"] = list(cfg["materials"]) + mats
+    return [m["material_name"] for m in mats]
+
+worst = []
+for case in range(n_cases):
+    wd = tempfile.mkdtemp()
+    base = rng.choice(["cfg2", "cfg3", "cfg4", "cfg1"])
+    try:
+        if base == "cfg2": cfg, root = scenes.cfg2(wd, xres=40, yres=40, nsamp=5, max_depth=4)
+        elif base == "cfg3":
+            cfg, root = scenes.cfg3(wd, xres=40, yres=40, nsamp=5, max_depth=4)
+            cfg["Aggregate"]["primitives"][0]["instances"][0]["rotation_axis"] = [1.0, 2.0, 3.0]
+            cfg["Aggregate"]["primitives"][1]["instances"] = [{"world_pos": [0.0, 0.0, 0.0], "rotation_axis": [3.0, 1.0, 2.0], "rotation_angle": 7}]
+        elif base == "cfg4": cfg, root = scenes.cfg4(wd, xres=40, yres=40, nsamp=5, max_depth=5, n=24)
+        else: cfg, root = scenes.cfg1(wd, xres=40, yres=40, nsamp=5)
+        if base == "cfg2":      # generic axes (exact box / face ties otherwise, tests/test_gpu_parity.py)
+            for inst in cfg["Aggregate"]["primitives"][0]["instances"]: inst["rotation_axis"] = [1.0, 2.0, 3.0]
+        names = palette(cfg)
+        for prim in cfg["Aggregate"]["primitives"]:
+            prim["material_name"] = str(rng.choice(names))
+        integ = rng.choice(["Path", "DirectLighting", "Debug", "AO"], p=[0.5, 0.25, 0.2, 0.05])
+        cfg["Integrator"] = {"integrator_type": str(integ), "max_depth": int(rng.integers(1, 7 if integ == "Path" else 5)), "light_strategy": str(rng.choice(["all", "one"]))}
+        if rng.random() < 0.3:
+            cfg["Sampler"] = {"sampler_type": "StratifiedSampler", "xsamp": 2, "ysamp": 2, "jitter": bool(rng.random() < 0.5), "dimension": int(rng.choice([2, 8]))}
+        f = rng.random()
+        if f < 0.2: cfg["Film"]["Filter"] = {"filter_type": "GaussianFilter", "radius": [1.5, 1.5], "alpha": 1.0}
+        elif f < 0.4: cfg["Film"]["Filter"] = {"filter_type": "TriangleFilter", "radius": [2.0, 1.0]}
+        if rng.random() < 0.3:    # sphere area light (sample-only, Q18)
+            cfg["lights"] = list(cfg["lights"]) + [{"light_type": "diffuse", "spectrum": {"values": [40.0, 35.0, 30.0]},
+                                                    "light_shape": {"shape_type": "sphere", "radius": 1.5, "world_pos": [30.0, 9.0, -3.0]}}]
+        if rng.random() < 0.4:
+            cfg["lights"] = list(cfg["lights"]) + [{"light_type": "distant", "l": {"values": [2.0, 2.0, 1.5]}, "from": [20.0, 30.0, 10.0], "to": [35.0, 0.0, 0.0]}]
+        sc = Scene.loads(cfg, root, flags=RRT_FIXED_BVH if rng.random() < 0.5 else 0)
+    except RrtError as e:
+        print(f"case {case} {base}: scene refused: {str(e)[:100]}"); continue
+    tag = f"case {case} {base} {cfg['Integrator']} mats={[p['material_name'] for p in cfg['Aggregate']['primitives']]} sampler={cfg['Sampler'].get('sampler_type')} filter={cfg['Film'].get('Filter', {}).get('filter_type')}"
+    try:
+        ref = O.render(sc, flat=True)
+        o_err = None
+    except O.OracleError as e:
+        ref, o_err = None, str(e)
+    try:
+        r = Renderer(sc, 0, RRT_F64); film = r.render(); r.close(); d_err = None
+    except RrtError as e:
+        film, d_err = None, str(e)
+    if o_err or d_err:
+        same = (o_err is not None) == (d_err is not None)
+        print(("ok-both-refuse " if same else "MISMATCH-REFUSAL ") + tag + f" oracle={str(o_err)[:80]} device={str(d_err)[:80]}")
+        continue
+    scale = max(np.abs(ref[..., :3]).max(), 1e-300)
+    d = np.abs(film[..., :3] - ref[..., :3]).max(-1) / scale
+    wdiff = np.abs(film[..., 3] - ref[..., 3]).max()
+    bad = (d > 1e-9).mean()
+    flag = "ok " if (bad < 0.01 and wdiff < 1e-9 * max(1.0, ref[..., 3].max())) else "DIFF "
+    print(f"{flag}{tag}: max {d.max():.2e}, frac>1e-9 {bad:.4f}, weight diff {wdiff:.1e}")
+    worst.append((d.max(), tag))
+print("worst:", sorted(worst, reverse=True)[:3])
