@@ -1367,7 +1367,7 @@ __global__ void __launch_bounds__(kBlock) k_film_wide(SceneDev<R> s, Pools<R> p,
   if (t >= (uint32_t)ew * (uint32_t)eh) return;
   const int x = ex0 + (int)(t % (uint32_t)ew), y = ey0 + (int)(t / (uint32_t)ew);
   R cr = R(0), cg = R(0), cb = R(0), wsum = R(0);
-  const R inv_rx = R(1) / s.filter_rx, inv_ry = R(1) / s.filter_ry;
+  const R inv_rx = s.filter_inv_rx, inv_ry = s.filter_inv_ry;
   for (int sy = y - reach_y; sy <= y + reach_y; sy++) {
     if (sy < 0 || sy >= ymax) continue;
     for (int sx = x - reach_x; sx <= x + reach_x; sx++) {

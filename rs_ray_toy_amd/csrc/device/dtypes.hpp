@@ -138,6 +138,8 @@ struct SceneDev {
   R max_sample_luminance;
   const R* filter_table;       // 16 x 16 (film.rs:163-173, incl. Q4), only read by the wide-filter film kernel
   R filter_rx, filter_ry;
+  R filter_inv_rx, filter_inv_ry;   // 1 / radius (film.rs:43-46), divided on the host: the fp32 build's fast reciprocal is 1 ulp off, and
+                               // `distance * inv_radius * 16` sits exactly on table-index boundaries for unjittered strata
   // sampler
   const HaltonDim* hdims;
   const uint16_t* perms;

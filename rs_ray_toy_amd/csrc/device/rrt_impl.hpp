@@ -833,6 +833,7 @@ class Handle : public HandleBase {
       HIP_CHECK(hipStreamSynchronize(st_));
       s.filter_table = filter_table_.p;
       s.filter_rx = (R)d->film.filter_radius[0]; s.filter_ry = (R)d->film.filter_radius[1];
+      s.filter_inv_rx = (R)(1.0 / d->film.filter_radius[0]); s.filter_inv_ry = (R)(1.0 / d->film.filter_radius[1]);
     }
     s.sampler_type = (uint32_t)d->sampler.type;
     s.st_nx = (uint32_t)std::max(1, d->sampler.xsamp); s.st_ny = (uint32_t)std::max(1, d->sampler.ysamp);

@@ -897,3 +897,22 @@ def test_textured_scene_across_features(which, workdir):
         assert np.array_equal(film[..., 3], ref[..., 3])
         d = np.abs(film[..., :3] - ref[..., :3]).max(-1) / scale
         assert d.max() < 1e-9, d.max()
+
+
+def test_unjittered_strata_on_filter_table_boundaries(workdir):
+    """2 x 2 unjittered strata put every sample 0.75 px from a pixel centre; with radius 1.5 the filter-table index
+    |d| * (1 / r) * 16 is exactly 8.0 (film.rs:100-112). The fp32 build's fast reciprocal (1 ulp low) made it 7.99..: weight sums off
+    by up to 2.6 per pixel until 1 / radius came from the host (found by tools/fuzz_parity.py)."""
+    cfg, root = _cfg3_tilted(workdir)
+    cfg["Sampler"] = {"sampler_type": "StratifiedSampler", "xsamp": 2, "ysamp": 2, "jitter": False, "dimension": 8}
+    cfg["Integrator"] = {"integrator_type": "Debug", "max_depth": 1}
+    for filt in ({"filter_type": "GaussianFilter", "radius": [1.5, 1.5], "alpha": 1.0}, {"filter_type": "TriangleFilter", "radius": [1.5, 1.5]}):
+        cfg["Film"]["Filter"] = filt
+        sc = Scene.loads(cfg, root)
+        ref = O.render(sc, flat=True)
+        r = Renderer(sc, 0, RRT_F32)
+        film = r.render().astype(np.float64)
+        r.close()
+        np.testing.assert_allclose(film[..., 3], ref[..., 3], rtol=1e-5)
+        d = np.abs(film[..., :3] - ref[..., :3]).max(-1) / np.abs(ref[..., :3]).max()
+        assert (d < 1e-4).mean() > 0.99, ((d < 1e-4).mean(), d.max())
