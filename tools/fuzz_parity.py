@@ -33,7 +33,13 @@ def palette(cfg):
                           {"texture_name": "t_wr", "texture_type": "WrinkledTexture", "octaves": 3, "omega": 0.5, **ROT},
                           {"texture_name": "t_mix", "texture_type": "MixTexture", "t1": "t_chk", "t2": "t_uv"},
                           {"texture_name": "t_scale", "texture_type": "ScaleTexture", "t1": "t_wr", "t2": "c_w"}]
-    mats = [{"material_type": "MatteMaterial", "kd": "t_chk", "sigma": "f_ramp"}, {"material_type": "MatteMaterial", "kd": "t_chk_aa"},
+    if not os.path.exists(os.path.join(cfg["_wd"], "fz.png")):
+        from test_host import write_png_fixture
+        yy, xx = np.mgrid[0:128, 0:128]
+        write_png_fixture(os.path.join(cfg["_wd"], "fz.png"), np.stack([(xx ^ yy) & 255, (xx * 3 + yy) & 255, (xx + yy * 5) & 255], -1).astype(np.uint8), filters=[4, 1])
+    cfg["rgb_texture"].append({"texture_name": "t_img", "texture_type": "ImageTexture", "filename": "fz.png", "do_trilinear": True,
+                               "mapping": {"mapping": "uv", "su": 2.0, "sv": 2.0, "du": 0.1, "dv": 0.2}})
+    mats = [{"material_type": "MatteMaterial", "kd": "t_img"}, {"material_type": "MatteMaterial", "kd": "t_chk", "sigma": "f_ramp"}, {"material_type": "MatteMaterial", "kd": "t_chk_aa"},
             {"material_type": "MatteMaterial", "kd": "t_scale"}, {"material_type": "MatteMaterial"},
             {"material_type": "PlasticMaterial", "kd": "t_mix", "ks": "c_w", "roughness": "f_chk3"}, {"material_type": "PlasticMaterial", "remap_roughness": True},
             {"material_type": "MetalMaterial", "roughness": "f_hi"}, {"material_type": "MetalMaterial", "u_roughness": "f_lo", "v_roughness": "f_hi", "bump_map": "f_bump"},
@@ -59,7 +65,12 @@ for case in range(n_cases):
         else: cfg, root = scenes.cfg1(wd, xres=40, yres=40, nsamp=5)
         if base == "cfg2":      # generic axes (exact box / face ties otherwise, tests/test_gpu_parity.py)
             for inst in cfg["Aggregate"]["primitives"][0]["instances"]: inst["rotation_axis"] = [1.0, 2.0, 3.0]
+        cfg["_wd"] = wd
         names = palette(cfg)
+        del cfg["_wd"]
+        if base != "cfg1" and rng.random() < 0.25:   # a sphere primitive among the triangles
+            cfg["Aggregate"]["primitives"].append({"primitive_type": "sphere", "material_name": "mat_matte", "radius": 1.2, "world_pos": [33.0, 2.5, -2.0],
+                                                   "rotation_axis": [0.0, 1.0, 0.0], "rotation_angle": 30.0})
         for prim in cfg["Aggregate"]["primitives"]:
             prim["material_name"] = str(rng.choice(names))
         integ = rng.choice(["Path", "DirectLighting", "Debug", "AO"], p=[0.5, 0.25, 0.2, 0.05])
@@ -84,13 +95,21 @@ for case in range(n_cases):
         with open(os.path.join(wd, "scene.json"), "w") as fjs: json.dump(cfg, fjs)
         print("scene written to", wd)
     tag = f"case {case} {base} {cfg['Integrator']} mats={[p['material_name'] for p in cfg['Aggregate']['primitives']]} sampler={cfg['Sampler'].get('sampler_type')} filter={cfg['Film'].get('Filter', {}).get('filter_type')}"
+    rect = None
+    if rng.random() < 0.3:
+        x0, y0 = int(rng.integers(0, 20)), int(rng.integers(0, 20))
+        rect = (x0, y0, x0 + int(rng.integers(4, 20)), y0 + int(rng.integers(4, 20)))
+    max_paths = int(rng.choice([0, 0, 1 << 16, 3000]))
+    tag += f" rect={rect} max_paths={max_paths}"
     try:
-        ref = O.render(sc, flat=True)
+        ref = O.render(sc, rect, flat=True)
         o_err = None
     except O.OracleError as e:
         ref, o_err = None, str(e)
     try:
-        r = Renderer(sc, 0, RRT_F32 if F32 else RRT_F64); film = r.render().astype(np.float64); r.close(); d_err = None
+        r = Renderer(sc, 0, RRT_F32 if F32 else RRT_F64)
+        if max_paths: r.set_option("max_paths", max_paths)
+        film = r.render(rect).astype(np.float64); r.close(); d_err = None
     except RrtError as e:
         film, d_err = None, str(e)
     if o_err or d_err:
