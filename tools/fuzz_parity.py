@@ -12,6 +12,7 @@ n_cases = int(sys.argv[1]) if len(sys.argv) > 1 else 40
 rng = np.random.default_rng(int(sys.argv[2]) if len(sys.argv) > 2 else 1)
 F32 = len(sys.argv) > 3 and sys.argv[3] == "f32"
 ONLY = int(sys.argv[4]) if len(sys.argv) > 4 else -1      # render only this case (the others still consume the random stream)
+RES = int(os.environ.get("FUZZ_RES", "40")); NS = int(os.environ.get("FUZZ_NSAMP", "5"))
 ROT = {"rotation_axis": [1.0, 2.0, 0.5], "rotation_angle": 25.0}
 
 def const_rgb(name, v):
@@ -56,13 +57,13 @@ for case in range(n_cases):
     wd = tempfile.mkdtemp()
     base = rng.choice(["cfg2", "cfg3", "cfg4", "cfg1"])
     try:
-        if base == "cfg2": cfg, root = scenes.cfg2(wd, xres=40, yres=40, nsamp=5, max_depth=4)
+        if base == "cfg2": cfg, root = scenes.cfg2(wd, xres=RES, yres=RES, nsamp=NS, max_depth=4)
         elif base == "cfg3":
-            cfg, root = scenes.cfg3(wd, xres=40, yres=40, nsamp=5, max_depth=4)
+            cfg, root = scenes.cfg3(wd, xres=RES, yres=RES, nsamp=NS, max_depth=4)
             cfg["Aggregate"]["primitives"][0]["instances"][0]["rotation_axis"] = [1.0, 2.0, 3.0]
             cfg["Aggregate"]["primitives"][1]["instances"] = [{"world_pos": [0.0, 0.0, 0.0], "rotation_axis": [3.0, 1.0, 2.0], "rotation_angle": 7}]
-        elif base == "cfg4": cfg, root = scenes.cfg4(wd, xres=40, yres=40, nsamp=5, max_depth=5, n=24)
-        else: cfg, root = scenes.cfg1(wd, xres=40, yres=40, nsamp=5)
+        elif base == "cfg4": cfg, root = scenes.cfg4(wd, xres=RES, yres=RES, nsamp=NS, max_depth=5, n=int(os.environ.get("FUZZ_GRID", "24")))
+        else: cfg, root = scenes.cfg1(wd, xres=RES, yres=RES, nsamp=NS)
         if base == "cfg2":      # generic axes (exact box / face ties otherwise, tests/test_gpu_parity.py)
             for inst in cfg["Aggregate"]["primitives"][0]["instances"]: inst["rotation_axis"] = [1.0, 2.0, 3.0]
         cfg["_wd"] = wd
@@ -97,8 +98,8 @@ for case in range(n_cases):
     tag = f"case {case} {base} {cfg['Integrator']} mats={[p['material_name'] for p in cfg['Aggregate']['primitives']]} sampler={cfg['Sampler'].get('sampler_type')} filter={cfg['Film'].get('Filter', {}).get('filter_type')}"
     rect = None
     if rng.random() < 0.3:
-        x0, y0 = int(rng.integers(0, 20)), int(rng.integers(0, 20))
-        rect = (x0, y0, x0 + int(rng.integers(4, 20)), y0 + int(rng.integers(4, 20)))
+        x0, y0 = int(rng.integers(0, RES // 2)), int(rng.integers(0, RES // 2))
+        rect = (x0, y0, x0 + int(rng.integers(4, RES // 2)), y0 + int(rng.integers(4, RES // 2)))
     max_paths = int(rng.choice([0, 0, 1 << 16, 3000]))
     tag += f" rect={rect} max_paths={max_paths}"
     try:
