@@ -570,21 +570,31 @@ static __global__ void __launch_bounds__(kBlock) k_compact_alive(Pools<float> p,
   const uint32_t wave = (blockIdx.x * blockDim.x + threadIdx.x) >> 6;
   const uint64_t base_slot = (uint64_t)wave * 64u * kCompactRun;
   if (base_slot >= total) return;
+  // the 64 liveness masks of the run are kept in registers (one per lane: lane k holds the ballot of group k), so the weights
+  // are read once, eight independent loads in flight at a time
+  uint64_t my_mask = 0;
   uint32_t n_alive = 0;
-  for (uint32_t k = 0; k < kCompactRun; k++) {
-    const uint64_t slot = base_slot + (uint64_t)k * 64u + lane;
-    const bool alive = slot < total && p.weight[slot] > 0.0f;
-    n_alive += (uint32_t)__popcll(__ballot(alive));
+  for (uint32_t k0 = 0; k0 < kCompactRun; k0 += 8) {
+    float w[8];
+#pragma unroll
+    for (uint32_t j = 0; j < 8; j++) {
+      const uint64_t slot = base_slot + (uint64_t)(k0 + j) * 64u + lane;
+      w[j] = slot < total ? p.weight[slot] : 0.0f;
+    }
+#pragma unroll
+    for (uint32_t j = 0; j < 8; j++) {
+      const uint64_t m = __ballot(w[j] > 0.0f);
+      if (lane == k0 + j) my_mask = m;
+      n_alive += (uint32_t)__popcll(m);
+    }
   }
   if (n_alive == 0) return;
   uint32_t out = 0;
   if (lane == 0) out = atomicAdd(&p.counters[C_NEXT], n_alive);
   out = __shfl(out, 0);
   for (uint32_t k = 0; k < kCompactRun; k++) {
-    const uint64_t slot = base_slot + (uint64_t)k * 64u + lane;
-    const bool alive = slot < total && p.weight[slot] > 0.0f;
-    const uint64_t m = __ballot(alive);
-    if (alive) p.q_next[out + (uint32_t)__popcll(m & ((1ull << lane) - 1ull))] = QEnt{(uint32_t)slot, 0u, 0u, 0u};
+    const uint64_t m = __shfl(my_mask, (int)k);
+    if ((m >> lane) & 1ull) p.q_next[out + (uint32_t)__popcll(m & ((1ull << lane) - 1ull))] = QEnt{(uint32_t)(base_slot + (uint64_t)k * 64u + lane), 0u, 0u, 0u};
     out += (uint32_t)__popcll(m);
   }
 }
