@@ -260,6 +260,20 @@ def test_distant_light_construction(tmp_path):
     np.testing.assert_allclose(list(L.w_light), w, atol=1e-15)
     wb = np.array(list(d.world_bound))
     assert L.world_radius == pytest.approx(np.linalg.norm(wb[3:] - (wb[:3] + wb[3:]) / 2), rel=1e-15)
+    # the reference's own known answers for these two helpers, geometry.rs:1949-1971 test_bound3: the union of the box
+    # (0,-10,5)-(-10,20,10) with the point (-15,10,30) is (-15,-10,5)-(0,20,30), and the box's bounding sphere sits at (-5,5,7.5)
+    with open(os.path.join(root, "b3.obj"), "w") as f:
+        f.write("v 0 -10 5\nv -10 20 10\nv -15 10 30\nf 1 2 3\n")
+    cfg["objs"] = [{"filename": "b3.obj", "obj_name": "b3"}]
+    cfg["Aggregate"]["primitives"] = [{"primitive_type": "triangle", "material_name": "mat_matte", "obj_name": "b3"}]
+    sc = Scene.loads(cfg, root)
+    assert list(sc.desc.world_bound) == [-15.0, -10.0, 5.0, 0.0, 20.0, 30.0]
+    with open(os.path.join(root, "b3.obj"), "w") as f:      # the box itself, as a triangle through its two corners
+        f.write("v 0 -10 5\nv -10 20 10\nv -10 -10 10\nf 1 2 3\n")
+    sc = Scene.loads(cfg, root)
+    assert list(sc.desc.world_bound) == [-10.0, -10.0, 5.0, 0.0, 20.0, 10.0]
+    centre = np.array([-5.0, 5.0, 7.5])
+    assert sc.desc.lights[0].world_radius == np.linalg.norm(np.array([0.0, 20.0, 10.0]) - centre)
 
 
 # ---- ImageTexture: PNG decode as `image::open(..).decode().into_rgb8()` + MIPMap::create ---------------------------------------
