@@ -184,8 +184,12 @@ RRT_DEV double scrambled_radical_inverse_dev(uint32_t a, const HaltonDim& hd, co
   return fmin(inv_base_n * ((double)reversed + hd.tail), 0.99999999999999989);
 }
 // Halton::sample_dimension halton.rs:107-128 (index < 2^32 checked on the host)
+constexpr uint32_t kErrHaltonDims = 32u;   // ERR_HALTON_DIMS of dkernels.hpp
 template <typename R>
 RRT_DEV double halton_dim(const SceneDev<R>& s, uint32_t index, uint32_t dim) {
+  // permutation_for_dimension halton.rs:63-69: dimension 1000 and beyond panics (PRIME_TABLE_SIZE). A DirectLighting / Debug tree
+  // over smooth glass reaches it at depth ~7 (16 dimensions per vertex, 2^depth vertices)
+  if (dim >= 1000u) { atomicOr(s.err, kErrHaltonDims); return 0.0; }
   if (s.sample_at_center && dim < 2) return 0.5;
   if (dim == 0) {
     uint32_t a = index >> s.base_exp0;                     // radical_inverse(0, a) = reverse_bits_64(a) * 2^-64
@@ -271,11 +275,11 @@ template <typename R> RRT_DEV void draw_2d(const SceneDev<R>& s, uint32_t index,
 // a 2D draw whose value is never read (u_scattering of the removed BSDF-sampling half): only the counters move
 template <typename R> RRT_DEV void skip_2d(const SceneDev<R>& s, uint32_t* d) {
   if (s.sampler_type == 1u) { const uint32_t k = (*d >> 8) & 0xffu; *d = (*d & ~0xff00u) | (((k + 1u) & 0xffu) << 8); }
-  else *d += 2u;
+  else { if (*d + 1u >= 1000u) atomicOr(s.err, kErrHaltonDims); *d += 2u; }
 }
 template <typename R> RRT_DEV void skip_1d(const SceneDev<R>& s, uint32_t* d) {
   if (s.sampler_type == 1u) { const uint32_t k = *d & 0xffu; *d = (*d & ~0xffu) | ((k + 1u) & 0xffu); }
-  else *d += 1u;
+  else { if (*d >= 1000u) atomicOr(s.err, kErrHaltonDims); *d += 1u; }   // (the reference computes the value, so it panics here too)
 }
 template <typename R> RRT_DEV R to_real(double u) { return (R)u; }
 template <> RRT_DEV float to_real<float>(double u) { return fminf((float)u, Const<float>::one_minus_eps); }  // keep u < 1 after narrowing

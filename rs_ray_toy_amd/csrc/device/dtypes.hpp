@@ -142,6 +142,7 @@ struct SceneDev {
                                // `distance * inv_radius * 16` sits exactly on table-index boundaries for unjittered strata
   // sampler
   const HaltonDim* hdims;
+  uint32_t* err;               // the handle's error word (counters[C_ERROR]): device-side counterparts of the reference's panics
   const uint16_t* perms;
   uint32_t nsamp, sample_at_center;
   uint32_t base_exp0, base_exp1, base_scale0, base_scale1, stride, mult_inv0, mult_inv1;

@@ -920,3 +920,35 @@ def test_unjittered_strata_on_filter_table_boundaries(workdir):
         np.testing.assert_allclose(film[..., 3], ref[..., 3], rtol=1e-5)
         d = np.abs(film[..., :3] - ref[..., :3]).max(-1) / np.abs(ref[..., :3]).max()
         assert (d < 1e-4).mean() > 0.99, ((d < 1e-4).mean(), d.max())
+
+
+def test_halton_dimension_limit_panics_like_the_reference(workdir):
+    """HaltonSampler::permutation_for_dimension panics at dimension 1000 (samplers/halton.rs:63-69). A Debug / DirectLighting tree
+    over smooth glass (16 dimensions per vertex, two children per vertex) gets there at depth ~7; found by tools/fuzz_parity.py as a
+    device read past the 1000-entry dimension table."""
+    cfg, root = scenes.cfg1(workdir, xres=24, yres=24, nsamp=3)
+    _with_material(cfg, "mat_t", TRANSMISSIVE["glass"])
+    cfg["Aggregate"]["primitives"][0]["material_name"] = "mat_t"
+    cfg["Integrator"] = {"integrator_type": "Debug", "max_depth": 11}
+    sc = Scene.loads(cfg, root)
+    with pytest.raises(O.OracleError, match="1000 dimensions"):
+        O.render(sc)
+    for prec in (RRT_F64, RRT_F32):
+        r = Renderer(sc, 0, prec)
+        with pytest.raises(RrtPanic, match="1000 dimensions"):
+            r.render()
+        r.close()
+    # the path integrator: 8 dimensions per bounce at most, so only absurd depths get there
+    cfg, root = scenes.cfg3(workdir, xres=16, yres=16, nsamp=3, max_depth=400)
+    cfg["Integrator"]["rr_threshold"] = 0.0      # no Russian roulette: paths live until max_depth
+    cfg["materials"] = cfg["materials"] + [{"material_type": "MatteMaterial", "material_name": "white", "kd": "w"}]
+    cfg["rgb_texture"] = [_const_rgb("w", [0.99, 0.99, 0.99])]
+    for prim in cfg["Aggregate"]["primitives"]:
+        prim["material_name"] = "white"
+    sc = Scene.loads(cfg, root)
+    with pytest.raises(O.OracleError, match="1000 dimensions"):
+        O.render(sc)
+    r = Renderer(sc, 0, RRT_F32)
+    with pytest.raises(RrtPanic, match="1000 dimensions"):
+        r.render()
+    r.close()

@@ -75,7 +75,12 @@ for case in range(n_cases):
         for prim in cfg["Aggregate"]["primitives"]:
             prim["material_name"] = str(rng.choice(names))
         integ = rng.choice(["Path", "DirectLighting", "Debug", "AO"], p=[0.5, 0.25, 0.2, 0.05])
-        cfg["Integrator"] = {"integrator_type": str(integ), "max_depth": int(rng.integers(1, 7 if integ == "Path" else 5)), "light_strategy": str(rng.choice(["all", "one"]))}
+        deep = os.environ.get("FUZZ_DEEP_DIRECT") == "1"     # stress the per-sample recursion kernel: deep specular trees
+        if deep: integ = rng.choice(["DirectLighting", "Debug"])
+        cfg["Integrator"] = {"integrator_type": str(integ), "max_depth": int(rng.integers(1, 7 if integ == "Path" else (12 if deep else 5))), "light_strategy": str(rng.choice(["all", "one"]))}
+        if deep:
+            for prim in cfg["Aggregate"]["primitives"]:
+                prim["material_name"] = str(rng.choice(["fz9", "fz10", "fz11", "fz13", "fz1", "fz5"]))   # mirror, glass, rough glass, translucent, textured matte / plastic
         if rng.random() < 0.3:
             cfg["Sampler"] = {"sampler_type": "StratifiedSampler", "xsamp": 2, "ysamp": 2, "jitter": bool(rng.random() < 0.5), "dimension": int(rng.choice([2, 8]))}
         f = rng.random()
@@ -96,6 +101,10 @@ for case in range(n_cases):
         with open(os.path.join(wd, "scene.json"), "w") as fjs: json.dump(cfg, fjs)
         print("scene written to", wd)
     tag = f"case {case} {base} {cfg['Integrator']} mats={[p['material_name'] for p in cfg['Aggregate']['primitives']]} sampler={cfg['Sampler'].get('sampler_type')} filter={cfg['Film'].get('Filter', {}).get('filter_type')}"
+    if os.environ.get("FUZZ_DUMP") == str(case):     # keep the random stream intact (unlike `only`) and leave the scene behind
+        import json
+        with open(os.path.join(wd, "scene.json"), "w") as fjs: json.dump(cfg, fjs)
+        print("scene written to", wd, flush=True)
     rect = None
     if rng.random() < 0.3:
         x0, y0 = int(rng.integers(0, RES // 2)), int(rng.integers(0, RES // 2))
@@ -108,6 +117,7 @@ for case in range(n_cases):
     except O.OracleError as e:
         ref, o_err = None, str(e)
     try:
+        print(f"[device] {tag}", flush=True) if os.environ.get("FUZZ_TRACE") else None
         r = Renderer(sc, 0, RRT_F32 if F32 else RRT_F64)
         if max_paths: r.set_option("max_paths", max_paths)
         film = r.render(rect).astype(np.float64); r.close(); d_err = None
