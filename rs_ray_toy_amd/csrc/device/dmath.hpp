@@ -237,8 +237,10 @@ RRT_DEV uint32_t st_permute(uint32_t i, uint32_t n, uint32_t p) {   // Kensler, 
 }
 RRT_DEV double st_rand(uint32_t key, uint32_t i) { return (double)st_mix(key ^ st_mix(i + 0x632be5abu)) * 2.3283064365386963e-10; }   // [0, 1)
 // index word of a stratified sample: pixel (22 bits) << 10 | sample number (10 bits); d = 1D counter | 2D counter << 8
+constexpr uint32_t kErrStDims = 64u;   // ERR_ST_DIMS of dkernels.hpp: a sample ran out of the 8-bit dimension counters (device limit, not a reference panic)
 template <typename R> RRT_DEV double st_get_1d(const SceneDev<R>& s, uint32_t index, uint32_t* d) {
   const uint32_t pixel = index >> 10, sn = index & 1023u, k = *d & 0xffu;
+  if (k == 0xffu) atomicOr(s.err, kErrStDims);
   *d = (*d & ~0xffu) | ((k + 1u) & 0xffu);
   if (k >= s.st_dims) return 2.0 * st_rand(st_key(s.st_seed_lo, s.st_seed_hi, pixel, 0x10000u + k), sn) - 1.0;
   const uint32_t spp = s.st_nx * s.st_ny, key = st_key(s.st_seed_lo, s.st_seed_hi, pixel, k);
@@ -248,6 +250,7 @@ template <typename R> RRT_DEV double st_get_1d(const SceneDev<R>& s, uint32_t in
 }
 template <typename R> RRT_DEV void st_get_2d(const SceneDev<R>& s, uint32_t index, uint32_t* d, double* a, double* b) {
   const uint32_t pixel = index >> 10, sn = index & 1023u, k = (*d >> 8) & 0xffu;
+  if (k == 0xffu) atomicOr(s.err, kErrStDims);
   *d = (*d & ~0xff00u) | (((k + 1u) & 0xffu) << 8);
   if (k >= s.st_dims) {
     const uint32_t key = st_key(s.st_seed_lo, s.st_seed_hi, pixel, 0x20000u + k);
@@ -274,11 +277,11 @@ template <typename R> RRT_DEV void draw_2d(const SceneDev<R>& s, uint32_t index,
 }
 // a 2D draw whose value is never read (u_scattering of the removed BSDF-sampling half): only the counters move
 template <typename R> RRT_DEV void skip_2d(const SceneDev<R>& s, uint32_t* d) {
-  if (s.sampler_type == 1u) { const uint32_t k = (*d >> 8) & 0xffu; *d = (*d & ~0xff00u) | (((k + 1u) & 0xffu) << 8); }
+  if (s.sampler_type == 1u) { const uint32_t k = (*d >> 8) & 0xffu; if (k == 0xffu) atomicOr(s.err, kErrStDims); *d = (*d & ~0xff00u) | (((k + 1u) & 0xffu) << 8); }
   else { if (*d + 1u >= 1000u) atomicOr(s.err, kErrHaltonDims); *d += 2u; }
 }
 template <typename R> RRT_DEV void skip_1d(const SceneDev<R>& s, uint32_t* d) {
-  if (s.sampler_type == 1u) { const uint32_t k = *d & 0xffu; *d = (*d & ~0xffu) | ((k + 1u) & 0xffu); }
+  if (s.sampler_type == 1u) { const uint32_t k = *d & 0xffu; if (k == 0xffu) atomicOr(s.err, kErrStDims); *d = (*d & ~0xffu) | ((k + 1u) & 0xffu); }
   else { if (*d >= 1000u) atomicOr(s.err, kErrHaltonDims); *d += 1u; }   // (the reference computes the value, so it panics here too)
 }
 template <typename R> RRT_DEV R to_real(double u) { return (R)u; }

@@ -259,6 +259,7 @@ class Handle : public HandleBase {
     uint32_t err = 0;
     HIP_CHECK(hipMemcpy(&err, counters_.p + C_ERROR, sizeof(err), hipMemcpyDeviceToHost));
     if (err & ERR_SHADING_NORMAL) throw PanicError("primitives.rs:66 assert!(dot3(&si.ist.n, &si.shading.n) >= 0.0) (vertex normals oppose the winding, Q14)");
+    if (err & ERR_ST_DIMS) throw UnsupportedError("StratifiedSampler on the device: a sample drew more than 255 1D or 2D dimensions (8-bit counters); deep DirectLighting / Debug trees do");
     if (err & ERR_HALTON_DIMS) throw PanicError("samplers/halton.rs:65 HaltonSampler can only sample 1000 dimensions.");
     if (err & ERR_MIPMAP) throw PanicError("mipmap.rs:217 / memory.rs:84 index out of bounds in an ImageTexture lookup (EWA of the level past the last one: images with fewer than two pyramid levels, or a footprint >= the whole texture)");
     if (err & ERR_NULL_BSDF) throw PanicError("glass.rs:70 / translucent.rs:66 null BSDF (textures evaluate to black): path.rs:103 `bounces -= 1` underflows");

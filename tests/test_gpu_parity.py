@@ -952,3 +952,27 @@ def test_halton_dimension_limit_panics_like_the_reference(workdir):
     with pytest.raises(RrtPanic, match="1000 dimensions"):
         r.render()
     r.close()
+
+
+def test_stratified_dimension_counters_overflow_is_refused(workdir):
+    """The device packs the stratified sampler's 1D / 2D dimension counters in 8 bits each; a deep Debug / DirectLighting tree over
+    smooth glass draws more 2D samples than that per camera sample. Refused loudly (RRT_EUNSUP), never wrapped silently."""
+    cfg, root = _cfg3_tilted(workdir)
+    cfg["Sampler"] = {"sampler_type": "StratifiedSampler", "xsamp": 2, "ysamp": 1, "jitter": True, "dimension": 4}
+    cfg["Integrator"] = {"integrator_type": "Debug", "max_depth": 10}
+    cfg["lights"] = cfg["lights"] * 8           # Debug samples every light at every vertex: 2 x 8 + 2 two-dimensional draws each
+    _with_material(cfg, "mat_t", TRANSMISSIVE["glass"])
+    for prim in cfg["Aggregate"]["primitives"]:
+        prim["material_name"] = "mat_t"
+    sc = Scene.loads(cfg, root)
+    r = Renderer(sc, 0, RRT_F64)
+    with pytest.raises(RrtUnsupported, match="8-bit counters"):
+        r.render()
+    r.close()
+    cfg["Integrator"]["max_depth"] = 3          # a shallow tree stays within the counters and matches the oracle
+    sc = Scene.loads(cfg, root)
+    ref = O.render(sc, flat=True)
+    r = Renderer(sc, 0, RRT_F64)
+    film = r.render()
+    r.close()
+    assert np.abs(film[..., :3] - ref[..., :3]).max() <= 1e-9 * np.abs(ref[..., :3]).max()
