@@ -17,7 +17,7 @@ template <typename R> struct ShadeBlock { static constexpr int n = 256; };
 #define RRT_SHADE_BLOCK 256
 #endif
 template <> struct ShadeBlock<float> { static constexpr int n = RRT_SHADE_BLOCK; };
-enum { ERR_SHADING_NORMAL = 1, ERR_STACK = 2, ERR_BETA = 4, ERR_NULL_BSDF = 8, ERR_MIPMAP = 16, ERR_HALTON_DIMS = 32, ERR_ST_DIMS = 64 };
+enum { ERR_SHADING_NORMAL = 1, ERR_STACK = 2, ERR_BETA = 4, ERR_NULL_BSDF = 8, ERR_MIPMAP = 16, ERR_HALTON_DIMS = 32, ERR_ST_DIMS = 64, ERR_NO_LIGHTS = 128 };
 static_assert(ERR_ST_DIMS == kErrStDims, "error bit shared with dmath.hpp");
 static_assert(ERR_HALTON_DIMS == kErrHaltonDims, "error bit shared with dmath.hpp");
 
@@ -1097,6 +1097,9 @@ __global__ void __launch_bounds__(ShadeBlock<R>::n) k_shade_specular(SceneDev<R>
     slot = qe.slot;
     const V4 h = p.hit[i];
     prim = (int)real_to_bits(h.y);
+    // DirectLightingIntegrator::li on a miss: `for light in &scene.lights { .. return l }` falls through to a call of itself when the
+    // list is empty (directlighting.rs:83-99, Q20): unbounded recursion in the reference, a panic here
+    if (prim < 0 && s.integrator == 1 && s.n_lights == 0u) atomicOr(&p.counters[C_ERROR], (uint32_t)ERR_NO_LIGHTS);
     if (prim >= 0) {
       const V4 st_b = p.path[i];
       const uint32_t db = qe.db;
@@ -1183,7 +1186,10 @@ __global__ void __launch_bounds__(kBlock) k_direct_tree(SceneDev<R> s, Pools<R> 
     int hit;
     { PrivStack stack; hit = traverse_closest(s, r, stack, f.skip, &hu, &hv, &nn, &np); }
     if (f.phase == 0) n_closest++;   // the phase-1 re-intersection is bookkeeping, not a reference query
-    if (hit < 0) { sp--; continue; }   // `for light in lights { l += le; return l }`: le = 0
+    if (hit < 0) {   // `for light in lights { l += le; return l }`: le = 0; with no light at all DirectLighting recurses for ever (Q20)
+      if (s.integrator == 1 && s.n_lights == 0u) atomicOr(&p.counters[C_ERROR], (uint32_t)ERR_NO_LIGHTS);
+      sp--; continue;
+    }
     SurfExt<R> ext;
     Surf<R> si = build_surface(s, hit, f.o, f.d, r.tmax, hu, hv, TEX ? &ext : nullptr);
     if (!si.ok) { atomicOr(&p.counters[C_ERROR], (uint32_t)ERR_SHADING_NORMAL); sp--; continue; }

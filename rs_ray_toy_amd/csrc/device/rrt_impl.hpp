@@ -259,6 +259,7 @@ class Handle : public HandleBase {
     uint32_t err = 0;
     HIP_CHECK(hipMemcpy(&err, counters_.p + C_ERROR, sizeof(err), hipMemcpyDeviceToHost));
     if (err & ERR_SHADING_NORMAL) throw PanicError("primitives.rs:66 assert!(dot3(&si.ist.n, &si.shading.n) >= 0.0) (vertex normals oppose the winding, Q14)");
+    if (err & ERR_NO_LIGHTS) throw PanicError("directlighting.rs:91 unbounded recursion on a miss with an empty light list (Q20)");
     if (err & ERR_ST_DIMS) throw UnsupportedError("StratifiedSampler on the device: a sample drew more than 255 1D or 2D dimensions (8-bit counters); deep DirectLighting / Debug trees do");
     if (err & ERR_HALTON_DIMS) throw PanicError("samplers/halton.rs:65 HaltonSampler can only sample 1000 dimensions.");
     if (err & ERR_MIPMAP) throw PanicError("mipmap.rs:217 / memory.rs:84 index out of bounds in an ImageTexture lookup (EWA of the level past the last one: images with fewer than two pyramid levels, or a footprint >= the whole texture)");
@@ -274,12 +275,12 @@ class Handle : public HandleBase {
     HIP_CHECK(hipSetDevice(dev_));
     check_renderable();
     const rrt_film& f = desc_.film;
-    const bool wide_filter = f.filter_type != RRT_FILTER_BOX || f.filter_radius[0] > 0.5 || f.filter_radius[1] > 0.5;
+    // k_film_box is the closed form for the default box filter (radius exactly 0.5: every sample lands in its own pixel with weight 1);
+    // a smaller radius leaves samples near the pixel borders in no pixel at all, a larger one splats: both take the general kernel
+    const bool wide_filter = f.filter_type != RRT_FILTER_BOX || f.filter_radius[0] != 0.5 || f.filter_radius[1] != 0.5;
     if (f.crop[0] != 0 || f.crop[1] != 0 || f.crop[2] != f.xres || f.crop[3] != f.yres) throw UnsupportedError("film crop window");
     if (rect[0] < 0 || rect[1] < 0 || rect[2] > f.xres || rect[3] > f.yres || rect[0] >= rect[2] || rect[1] >= rect[3])
       throw std::invalid_argument("render rect outside the film");
-    if (desc_.integrator.type == RRT_INT_DIRECT && desc_.n_lights == 0)
-      throw PanicError("directlighting.rs:91 unbounded recursion on a miss with an empty light list (Q20)");
     const uint64_t nsamp = desc_.sampler.samples_per_pixel;
     const size_t W = (size_t)f.xres, H = (size_t)f.yres;
     size_t rh_all = (size_t)(rect[3] - rect[1]);
@@ -555,6 +556,9 @@ class Handle : public HandleBase {
       if (desc_.sampler.dimension > 255 || 3 * (int64_t)desc_.integrator.max_depth + 4 > 255)
         throw UnsupportedError("StratifiedSampler on the device: dimension counters are 8 bits");
       if (desc_.sampler.xsamp < 1 || desc_.sampler.ysamp < 1) throw PanicError("stratified sampler with zero strata");
+      // `dimension` 0: even the film sample is one of the rng.gen_range(-1.0..1.0) draws (samplers/mod.rs:211-226), i.e. it can leave
+      // its pixel towards -x / -y; the film kernels assume p_film inside the sample's pixel
+      if (desc_.sampler.dimension < 1) throw UnsupportedError("StratifiedSampler with dimension 0 (film samples outside their pixel)");
       return;
     }
     if (desc_.sampler.type != RRT_SAMPLER_HALTON) throw UnsupportedError("unknown sampler type");

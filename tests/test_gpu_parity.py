@@ -976,3 +976,31 @@ def test_stratified_dimension_counters_overflow_is_refused(workdir):
     film = r.render()
     r.close()
     assert np.abs(film[..., :3] - ref[..., :3]).max() <= 1e-9 * np.abs(ref[..., :3]).max()
+
+
+def test_edge_configurations_found_by_the_sweeps(workdir):
+    """tools/fuzz_edges.py findings: (1) a box filter narrower than 0.5 leaves samples near a pixel border in no pixel at all
+    (film.rs:93-99: p0 > p1), so only radius exactly 0.5 may take the closed-form film kernel; (2) DirectLighting with an empty light
+    list recurses for ever only on a MISS (Q20): inside an enclosure it renders (black), it does not panic."""
+    cfg, root = _cfg3_tilted(workdir)
+    cfg["Film"]["Filter"] = {"filter_type": "BoxFilter", "radius": [0.2, 0.35]}
+    sc = Scene.loads(cfg, root)
+    ref = O.render(sc, flat=True)
+    assert ref[..., 3].min() < 3 * 4 and ref[..., 3].max() <= 3 * 4      # fewer than the 4 samples reach some pixels
+    for prec, tol in ((RRT_F64, 1e-9), (RRT_F32, 1e-4)):
+        r = Renderer(sc, 0, prec)
+        film = r.render().astype(np.float64)
+        r.close()
+        assert np.array_equal(film[..., 3], ref[..., 3])
+        d = np.abs(film[..., :3] - ref[..., :3]).max(-1) / np.abs(ref[..., :3]).max()
+        assert (d < tol).mean() > 0.99, (prec, d.max())
+    cfg, root = _cfg3_tilted(workdir)
+    cfg["lights"] = []
+    cfg["Integrator"] = {"integrator_type": "DirectLighting", "max_depth": 3}
+    sc = Scene.loads(cfg, root)
+    ref = O.render(sc, flat=True)                      # every camera ray hits the enclosure: no miss, no recursion, no light
+    assert not ref[..., :3].any()
+    r = Renderer(sc, 0, RRT_F32)
+    film = r.render()
+    r.close()
+    assert not film[..., :3].any() and np.array_equal(film[..., 3].astype(np.float64), ref[..., 3])
