@@ -424,10 +424,12 @@ __global__ void __launch_bounds__(kBlock) k_shadow(SceneDev<R> s, Pools<R> p, co
 // Public batches (rrt_rays / rrt_hits are SoA arrays): pack into / unpack from the pool's records.
 template <typename R>
 __global__ void __launch_bounds__(kBlock) k_pack_rays(Pools<R> p, const R* ox, const R* oy, const R* oz, const R* dx, const R* dy, const R* dz, const R* tmax,
-                                                       const int32_t* skip, uint32_t n) {
+                                                       const int32_t* skip, uint32_t n, uint32_t n_tris) {
   const uint32_t i = blockIdx.x * blockDim.x + threadIdx.x;
   if (i >= n) return;
-  store_ray<R>(p.ray_o, p.ray_d, i, V3<R>(ox[i], oy[i], oz[i]), V3<R>(), V3<R>(dx[i], dy[i], dz[i]), tmax[i], skip ? skip[i] : -1);
+  // caller data: an index outside the triangle array means "none" (the kernels index tris[] with it)
+  const int32_t sk = (skip && (uint32_t)skip[i] < n_tris) ? skip[i] : -1;
+  store_ray<R>(p.ray_o, p.ray_d, i, V3<R>(ox[i], oy[i], oz[i]), V3<R>(), V3<R>(dx[i], dy[i], dz[i]), tmax[i], sk);
 }
 template <typename R>
 __global__ void __launch_bounds__(kBlock) k_unpack_hits(Pools<R> p, const Tri<R>* tris, R* t, int32_t* prim, R* u, R* v, uint32_t n) {

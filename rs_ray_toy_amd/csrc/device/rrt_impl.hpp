@@ -893,7 +893,7 @@ class Handle : public HandleBase {
     const uint32_t g = (uint32_t)((n + kBlock - 1) / kBlock);
     if (rays->mem == RRT_MEM_DEVICE) {
       hipLaunchKernelGGL((k_pack_rays<R>), dim3(g), dim3(kBlock), 0, st_, pool_, (const R*)rays->ox, (const R*)rays->oy, (const R*)rays->oz,
-                         (const R*)rays->dx, (const R*)rays->dy, (const R*)rays->dz, (const R*)rays->tmax, (const int32_t*)rays->skip_prim, (uint32_t)n);
+                         (const R*)rays->dx, (const R*)rays->dy, (const R*)rays->dz, (const R*)rays->tmax, (const int32_t*)rays->skip_prim, (uint32_t)n, scene_.n_tris);
       return;
     }
     DevBuf<R> sr; DevBuf<int32_t> sk;
@@ -902,7 +902,7 @@ class Handle : public HandleBase {
     for (int k = 0; k < 7; k++) HIP_CHECK(hipMemcpyAsync(sr.p + k * n, src[k], n * sizeof(R), hipMemcpyHostToDevice, st_));
     if (rays->skip_prim) { sk.alloc(n); HIP_CHECK(hipMemcpyAsync(sk.p, rays->skip_prim, n * sizeof(int32_t), hipMemcpyHostToDevice, st_)); }
     hipLaunchKernelGGL((k_pack_rays<R>), dim3(g), dim3(kBlock), 0, st_, pool_, sr.p, sr.p + n, sr.p + 2 * n, sr.p + 3 * n, sr.p + 4 * n, sr.p + 5 * n, sr.p + 6 * n,
-                       (const int32_t*)sk.p, (uint32_t)n);
+                       (const int32_t*)sk.p, (uint32_t)n, scene_.n_tris);
     HIP_CHECK(hipStreamSynchronize(st_));   // staging buffers go out of scope
   }
   // active <- next for the queue and for the rays stored at its positions

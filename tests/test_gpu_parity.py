@@ -1004,3 +1004,33 @@ def test_edge_configurations_found_by_the_sweeps(workdir):
     film = r.render()
     r.close()
     assert not film[..., :3].any() and np.array_equal(film[..., 3].astype(np.float64), ref[..., 3])
+
+
+@pytest.mark.parametrize("prec", [RRT_F64, RRT_F32])
+def test_trace_api_survives_garbage_rays(prec, hf_scene):
+    """rrt_trace_closest / rrt_trace_any are fed by callers: zero / NaN / infinite components, t_max of 0, negative, NaN, and skip_prim
+    indices outside the triangle array must neither fault nor hang, and must not disturb the sane rays of the same batch."""
+    sc = hf_scene
+    o, d, tmax, skip = _rays_for(sc, 2048, 5)
+    dt = np.float32 if prec == RRT_F32 else np.float64
+    o, d, tmax = o.astype(dt), d.astype(dt), tmax.astype(dt)
+    r = Renderer(sc, 0, prec)
+    clean = r.trace_closest(o, d, tmax, skip_prim=skip)
+    clean_any = r.trace_any(o, d, np.full(len(o), 1.0 - 1e-4, dt), skip_prim=skip)
+    o2, d2, t2, s2 = o.copy(), d.copy(), tmax.copy(), skip.copy()
+    bad = np.arange(0, len(o), 7)
+    d2[bad[0::6]] = 0.0
+    d2[bad[1::6], 1] = np.nan
+    o2[bad[2::6], 0] = np.inf
+    t2[bad[3::6]] = np.array([0.0, -1.0, np.nan, np.inf], dt)[np.arange(len(bad[3::6])) % 4]
+    s2[bad[4::6]] = 2 ** 31 - 1
+    s2[bad[5::6]] = -12345
+    good = np.ones(len(o), bool); good[bad] = False
+    got = r.trace_closest(o2, d2, t2, skip_prim=s2)
+    t_any = np.full(len(o), 1.0 - 1e-4, dt)
+    t_any[bad[3::6]] = t2[bad[3::6]]
+    got_any = r.trace_any(o2, d2, t_any, skip_prim=s2)
+    r.close()
+    assert np.array_equal(got["prim"][good], clean["prim"][good]) and np.array_equal(got["t"][good], clean["t"][good])
+    assert np.array_equal(got_any[good], clean_any[good])
+    assert (got["prim"][bad] >= -1).all() and (got["prim"][bad] < sc.desc.n_prim_order).all()
