@@ -587,8 +587,55 @@ class Handle : public HandleBase {
     for (int r = 0; r < 3; r++) o[r] = mi[0 * 4 + r] * n[0] + mi[1 * 4 + r] * n[1] + mi[2 * 4 + r] * n[2];
   }
 
+  // A desc normally comes from rrt_scene_load, but the ABI lets a caller fill one: every index the kernels follow is checked here once
+  // (a kernel reading past an array can take the GPU down for everybody on the host)
+  static void validate_desc(const rrt_scene_desc* d) {
+    auto bad = [](const std::string& what) { throw std::invalid_argument("scene desc: " + what); };
+    if ((d->n_positions && !d->positions) || (d->n_tris && !d->tris) || (d->n_prims && !d->prims) || (d->n_materials && !d->materials) ||
+        (d->n_bvh_nodes && !d->bvh_nodes) || (d->n_prim_order && !d->prim_order) || (d->n_lights && !d->lights) || (d->n_xforms && !d->xforms) ||
+        (d->n_spheres && !d->spheres) || (d->n_textures && !d->textures) || (d->n_images && !d->images) || (d->n_image_texels && !d->image_texels))
+      bad("null array with a non-zero count");
+    for (size_t i = 0; i < d->n_tris; i++) {
+      const rrt_tri& t = d->tris[i];
+      for (int k = 0; k < 3; k++) {
+        if (t.v[k] >= d->n_positions) bad("triangle vertex index out of range");
+        if (t.mesh_has_n && t.n[k] >= d->n_normals) bad("triangle normal index out of range");
+        if (t.mesh_has_uv && t.uv[k] >= d->n_uvs) bad("triangle uv index out of range");
+      }
+    }
+    for (size_t i = 0; i < d->n_spheres; i++)
+      if (d->spheres[i].xform < 0 || (size_t)d->spheres[i].xform >= d->n_xforms) bad("sphere transform index out of range");
+    for (size_t i = 0; i < d->n_prims; i++) {
+      const rrt_prim& p = d->prims[i];
+      if (p.type != RRT_PRIM_TRIANGLE && p.type != RRT_PRIM_SPHERE) bad("unknown primitive type");
+      if (p.shape >= (p.type == RRT_PRIM_TRIANGLE ? d->n_tris : d->n_spheres)) bad("primitive shape index out of range");
+      if (p.instance < -1 || (p.instance >= 0 && (size_t)p.instance >= d->n_xforms)) bad("primitive instance transform out of range");
+      if (p.material >= d->n_materials) bad("primitive material index out of range");
+    }
+    for (size_t i = 0; i < d->n_prim_order; i++) if (d->prim_order[i] >= d->n_prims) bad("prim_order entry out of range");
+    for (size_t i = 0; i < d->n_bvh_nodes; i++) {
+      const rrt_bvh_node& n = d->bvh_nodes[i];
+      if (n.n_primitives > 0) { if ((size_t)n.offset + n.n_primitives > d->n_prim_order) bad("BVH leaf outside prim_order"); }
+      else if (n.offset >= d->n_bvh_nodes || i + 1 >= d->n_bvh_nodes) bad("BVH interior node child out of range");
+      if (n.axis > 2) bad("BVH split axis out of range");
+    }
+    for (size_t i = 0; i < d->n_lights; i++) {
+      const rrt_light& l = d->lights[i];
+      if (l.type < RRT_LIGHT_POINT || l.type > RRT_LIGHT_DISTANT) bad("unknown light type");
+      if (l.type == RRT_LIGHT_DIFFUSE && l.shape >= (l.shape_type == RRT_PRIM_SPHERE ? d->n_spheres : d->n_tris)) bad("area light shape index out of range");
+    }
+    for (size_t i = 0; i < d->n_textures; i++) {
+      const rrt_texture& t = d->textures[i];
+      if (t.type < RRT_TEX_CONSTANT || t.type > RRT_TEX_IMAGE || t.mapping < RRT_MAP_UV || t.mapping > RRT_MAP_IDENTITY3D) bad("unknown texture / mapping type");
+    }
+    if (d->camera.n_elems < 1 || d->camera.n_elems > 64 || !d->camera.elems) bad("camera lens description missing");
+    if (d->film.xres < 1 || d->film.yres < 1) bad("empty film");
+    if (d->sampler.type == RRT_SAMPLER_HALTON && d->sampler.n_perms && !d->sampler.perms) bad("Halton permutation table missing");
+  }
+
   void upload_scene(const rrt_scene_desc* d) {
     if (d->abi_version != RRT_ABI_VERSION) throw std::invalid_argument("scene desc ABI version mismatch");
+    validate_desc(d);
     // nodes: conservative narrowing of the f64 boxes
     std::vector<Node<R>> nodes(d->n_bvh_nodes);
     for (size_t i = 0; i < d->n_bvh_nodes; i++) {

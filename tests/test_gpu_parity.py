@@ -1034,3 +1034,30 @@ def test_trace_api_survives_garbage_rays(prec, hf_scene):
     assert np.array_equal(got["prim"][good], clean["prim"][good]) and np.array_equal(got["t"][good], clean["t"][good])
     assert np.array_equal(got_any[good], clean_any[good])
     assert (got["prim"][bad] >= -1).all() and (got["prim"][bad] < sc.desc.n_prim_order).all()
+
+
+def test_create_rejects_inconsistent_descs(workdir):
+    """rrt_create follows indices of a caller-owned rrt_scene_desc: each is range-checked up front (RRT_EINVAL), not found by a kernel."""
+    from rs_ray_toy_amd import RrtError
+    cfg, root = scenes.cfg2(workdir, xres=16, yres=16, nsamp=3)
+    sc = Scene.loads(cfg, root)
+    d = sc.desc
+    def broken(setter, restore):
+        setter()
+        try:
+            with pytest.raises(RrtError, match="scene desc"):
+                Renderer(sc, 0, RRT_F32)
+        finally:
+            restore()
+    m0 = d.prims[0].material
+    broken(lambda: setattr(d.prims[0], "material", 10 ** 6), lambda: setattr(d.prims[0], "material", m0))
+    v0 = d.tris[0].v[0]
+    broken(lambda: d.tris[0].v.__setitem__(0, d.n_positions), lambda: d.tris[0].v.__setitem__(0, v0))
+    o0 = d.prim_order[0]
+    broken(lambda: d.prim_order.__setitem__(0, d.n_prims), lambda: d.prim_order.__setitem__(0, o0))
+    leaf = next(i for i in range(d.n_bvh_nodes) if d.bvh_nodes[i].n_primitives > 0)
+    n0 = d.bvh_nodes[leaf].offset
+    broken(lambda: setattr(d.bvh_nodes[leaf], "offset", d.n_prim_order), lambda: setattr(d.bvh_nodes[leaf], "offset", n0))
+    r = Renderer(sc, 0, RRT_F32)        # restored: creates and renders
+    assert r.render()[..., 3].max() > 0
+    r.close()
