@@ -208,8 +208,12 @@ class Handle : public HandleBase {
   void camera_samples(const int32_t rect[4], uint64_t s0, uint64_t s1, double* dims5, double* ray_od6, double* weight) override {
     HIP_CHECK(hipSetDevice(dev_));
     check_renderable();
+    if (rect[0] < 0 || rect[1] < 0 || rect[2] > desc_.film.xres || rect[3] > desc_.film.yres || rect[0] > rect[2] || rect[1] > rect[3])
+      throw std::invalid_argument("camera_samples: rect outside the film");
+    if (s1 < s0 || s1 > desc_.sampler.samples_per_pixel) throw std::invalid_argument("camera_samples: sample range outside [0, samples_per_pixel]");
     const size_t npix = (size_t)(rect[2] - rect[0]) * (size_t)(rect[3] - rect[1]), ns = (size_t)(s1 - s0), n = npix * ns;
     if (n == 0) return;
+    if (n > max_paths_) throw std::invalid_argument("camera_samples: more samples than pool slots (max_paths)");
     ensure_pools(n);
     DevBuf<double> dd, dr, dw;
     dd.alloc(5 * n); dr.alloc(6 * n); dw.alloc(n);
