@@ -78,8 +78,8 @@ def main():
     ap.add_argument("--opt", action="append", default=[], help="handle option key=value (rrt_set_option), e.g. pt_split_any=1e9")
     ap.add_argument("--dist-backend", default="nccl", choices=("nccl", "gloo"),
                     help="gloo: rehearse the multi-rank path with more ranks than GPUs (ranks share devices, films reduced on the host)")
-    ap.add_argument("--frames-in-flight", type=int, default=2, choices=(1, 2),
-                    help="2: alternate two handles (rrt_render_bands_begin / _end): a frame's latency-bound last bounces drain "
+    ap.add_argument("--frames-in-flight", type=int, default=2, choices=(1, 2, 3, 4),
+                    help="n >= 2: alternate n handles (rrt_render_bands_begin / _end): a frame's latency-bound last bounces drain "
                          "while the next frame's camera rays fill the chip; 1: one synchronous frame at a time")
     args = ap.parse_args()
 
