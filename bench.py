@@ -78,8 +78,9 @@ def main():
     ap.add_argument("--opt", action="append", default=[], help="handle option key=value (rrt_set_option), e.g. pt_split_any=1e9")
     ap.add_argument("--dist-backend", default="nccl", choices=("nccl", "gloo"),
                     help="gloo: rehearse the multi-rank path with more ranks than GPUs (ranks share devices, films reduced on the host)")
-    ap.add_argument("--frames-in-flight", type=int, default=2, choices=(1, 2, 3, 4),
-                    help="n >= 2: alternate n handles (rrt_render_bands_begin / _end): a frame's latency-bound last bounces drain "
+    ap.add_argument("--frames-in-flight", type=int, default=0, choices=(0, 1, 2, 3, 4),
+                    help="0 (default): 2 on one GPU, 4 on several (a rank's pools shrink with its share of the film, and its shorter "
+                         "launches leave more of the chip to fill: tools/band_pipeline.py); n >= 2: alternate n handles (rrt_render_bands_begin / _end): a frame's latency-bound last bounces drain "
                          "while the next frame's camera rays fill the chip; 1: one synchronous frame at a time")
     args = ap.parse_args()
 
@@ -116,7 +117,7 @@ def main():
     scene = Scene.loads(cfg, root, flags=flags)
     t_build = time.time() - t0
     W, H = scene.resolution
-    nfl = args.frames_in_flight
+    nfl = args.frames_in_flight or (2 if world == 1 else 4)
     handles = [Renderer(scene, local_rank, RRT_F32) for _ in range(nfl)]
     for h in handles:
         if args.max_paths:
@@ -174,7 +175,7 @@ def main():
         # per frame, in frame order, so ranks may differ in this)
         if nfl == 1:
             raise
-        print(f"[rank {rank}] two frames in flight not possible here ({e}); one frame at a time", file=sys.stderr)
+        print(f"[rank {rank}] {nfl} frames in flight not possible here ({e}); one frame at a time", file=sys.stderr)
         for h in handles:
             try:
                 h.render_end()

@@ -123,7 +123,7 @@ class Handle : public HandleBase {
     upload_scene(d);
     HIP_CHECK(hipStreamSynchronize(st_));
     // Large pools matter: a launch lasts at least as long as the latency chain of its longest ray, so few big
-    // launches beat many small ones (whole 1024^2 x 256 spp frame in one pass: 268 M slots x 172 B = 46 GB).
+    // launches beat many small ones (whole 1024^2 x 256 spp frame in one pass: 268 M slots x 280 B = 75 GB in fp32).
     size_t free_b = 0, total_b = 0;
     HIP_CHECK(hipMemGetInfo(&free_b, &total_b));
     const size_t per_slot = (n_vec_records() * 4 + 1) * sizeof(R) + 9 * sizeof(uint32_t);
