@@ -1060,4 +1060,12 @@ def test_create_rejects_inconsistent_descs(workdir):
     broken(lambda: setattr(d.bvh_nodes[leaf], "offset", d.n_prim_order), lambda: setattr(d.bvh_nodes[leaf], "offset", n0))
     r = Renderer(sc, 0, RRT_F32)        # restored: creates and renders
     assert r.render()[..., 3].max() > 0
+    # the batch entry points validate their ranges the same way (the sample arrays are caller-sized from them)
+    with pytest.raises(RrtError, match="rect outside the film"):
+        r.camera_samples((0, 0, 17, 16), 0, 1)
+    with pytest.raises(RrtError, match="sample range"):
+        r.camera_samples((0, 0, 4, 4), 0, 4)               # samples_per_pixel is 3
+    with pytest.raises(RrtError, match="rect outside the film"):
+        r.render(rect=(0, 0, 16, 17))
+    assert r.camera_samples((0, 0, 4, 4), 0, 3)[2].shape == (48,)
     r.close()
