@@ -52,6 +52,27 @@ def palette(cfg):
     cfg["materials"] = list(cfg["materials"]) + mats
     return [m["material_name"] for m in mats]
 
+if os.environ.get("FUZZ_SPHERE_TABLE") == "1":
+    # fp32 against f64 device means on config 1 (spheres), one palette material at a time, at a converged sample count: what the
+    # sphere self-intersection coin costs the product mode per material
+    for integ in ("DirectLighting", "Path"):
+        wd = tempfile.mkdtemp()
+        cfg, root = scenes.cfg1(wd, xres=64, yres=64, nsamp=int(os.environ.get("FUZZ_NSAMP", "64")))
+        cfg["_wd"] = wd; names = palette(cfg); del cfg["_wd"]
+        for name in names[:-1]:          # (not Debug: the path integrator panics on it)
+            for prim in cfg["Aggregate"]["primitives"]: prim["material_name"] = name
+            cfg["Integrator"] = {"integrator_type": integ, "max_depth": 5, "light_strategy": "all"}
+            sc = Scene.loads(cfg, root)
+            means = []
+            for prec in (RRT_F64, RRT_F32):
+                try:
+                    r = Renderer(sc, 0, prec); means.append(r.render().astype(np.float64)[..., :3].mean()); r.close()
+                except RrtError as e:
+                    means.append(float("nan"))
+            mat = next(m for m in cfg["materials"] if m["material_name"] == name)
+            print(f"{integ:15s} {name:5s} {mat['material_type']:20s} f64 mean {means[0]:.5f}  f32 mean {means[1]:.5f}  f32/f64 {means[1] / means[0]:.3f}", flush=True)
+    sys.exit(0)
+
 worst = []
 for case in range(n_cases):
     wd = tempfile.mkdtemp()
