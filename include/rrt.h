@@ -32,7 +32,7 @@
 extern "C" {
 #endif
 
-#define RRT_ABI_VERSION 6
+#define RRT_ABI_VERSION 7
 
 /* ---- error codes ------------------------------------------------------- */
 enum {
@@ -352,10 +352,36 @@ int rrt_render_bands(rrt_handle*, int rank, int world, void* film_xyzw, int film
 int rrt_render_bands_begin(rrt_handle*, int rank, int world, void* film_xyzw_device);
 int rrt_render_end(rrt_handle*);
 
+/* ---- multi-GPU film reassembly: RCCL over xGMI, one collective per frame ----
+ * The reference has one address space: its rayon tiles merge under a lock (Film::merge_film_tile film.rs:248-263, driven from
+ * integrator/mod.rs:64-74,133). Across GPUs every rank renders its bands (rrt_render_bands / _begin) into its own device
+ * film and the films meet on `root`. Box filter of radius <= 0.5: the bands are disjoint and only they travel (grouped
+ * ncclSend / ncclRecv - a gather: every rank ships 1/world of the film over its direct xGMI link to root); wider filters
+ * splat across band borders and the collective is ncclReduce(sum) of the whole film. The call is enqueued on the handle's
+ * stream (after the frame it follows) and returns; rrt_render_end() or a stream synchronisation completes it. */
+
+/* rows [y0, y1) of the bands `rank` owns out of `world` (bands b of 16 rows, integrator/mod.rs:55, with b % world == rank).
+ * Returns the number of bands and fills up to max_bands {y0, y1} pairs (y0y1 may be NULL); host arithmetic only. */
+int rrt_band_rows(int yres, int rank, int world, int32_t* y0y1, int max_bands);
+
+typedef struct rrt_comm rrt_comm;
+#define RRT_COMM_ID_BYTES 128
+/* one process per GPU: rank 0 draws an id (ncclGetUniqueId) and hands the bytes to the other ranks by any channel it has;
+ * every rank then joins (ncclCommInitRank; collective: returns once all `world` ranks have called it) */
+int rrt_comm_id(uint8_t id[RRT_COMM_ID_BYTES]);
+int rrt_comm_create(const uint8_t id[RRT_COMM_ID_BYTES], int rank, int world, int device, rrt_comm** out);
+void rrt_comm_destroy(rrt_comm*);
+/* the collective; film_xyzw_device = the W*H*4 device film this rank rendered with (comm rank, comm world) */
+int rrt_film_gather(rrt_handle*, rrt_comm*, void* film_xyzw_device, int root);
+/* one process that owns all GPUs of the node (the shape of the reference's single binary): handles[i] rendered rank i of
+ * n into films_device[i] on its own device; communicators (ncclCommInitAll) are created on first use and kept */
+int rrt_film_gather_all(rrt_handle* const* handles, void* const* films_device, int n, int root);
+
 /* handle options: "max_paths" (wavefront pool slots; default 2^28 clamped to half of the free HBM), "count_traversal"
  * (exact node / triangle-test counters in rrt_render_stats, generic kernels), "persistent_traversal" (fp32: 0 generic
  * kernels, 1 grid-stride pair-node kernel, 2 persistent-thread kernel, 3 = default, by queue size), "pt_split_closest" /
- * "pt_split_any" (queue sizes at which 3 switches), "raygen_pt" (fp32: 0 = the generic two-stage raygen) */
+ * "pt_split_any" (queue sizes at which 3 switches), "raygen_pt" (fp32: 0 = the generic two-stage raygen in the reference's
+ * operation order, 1 = persistent-thread lens tracing, 2 = default: dense kernels with the lean lens arithmetic) */
 int rrt_set_option(rrt_handle*, const char* key, double value);
 
 const char* rrt_last_error(void);

@@ -7,7 +7,7 @@ import ctypes as C
 import os
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
-LIB_PATH = os.path.join(_HERE, "csrc", "librrt.so")
+LIB_PATH = os.environ.get("RRT_LIBRARY") or os.path.join(_HERE, "csrc", "librrt.so")   # RRT_LIBRARY: another build of the same library (kernel tuning variants)
 
 # error codes
 RRT_OK, RRT_EINVAL, RRT_EIO, RRT_EPARSE, RRT_EPANIC, RRT_EUNSUP, RRT_EDEVICE, RRT_ENOMEM = 0, -1, -2, -3, -4, -5, -6, -7
@@ -22,6 +22,7 @@ RRT_FILTER_BOX, RRT_FILTER_TRIANGLE, RRT_FILTER_GAUSSIAN = 0, 1, 2
 RRT_INT_PATH, RRT_INT_DIRECT, RRT_INT_DEBUG, RRT_INT_AO = range(4)
 RRT_F32, RRT_F64 = 0, 1
 RRT_MEM_HOST, RRT_MEM_DEVICE = 0, 1
+RRT_COMM_ID_BYTES = 128
 
 
 class Xform(C.Structure):
@@ -173,6 +174,12 @@ PROTOTYPES = {
     "rrt_render_bands": (C.c_int, [C.c_void_p, C.c_int, C.c_int, C.c_void_p, C.c_int, C.POINTER(RenderStats)]),
     "rrt_render_bands_begin": (C.c_int, [C.c_void_p, C.c_int, C.c_int, C.c_void_p]),
     "rrt_render_end": (C.c_int, [C.c_void_p]),
+    "rrt_band_rows": (C.c_int, [C.c_int, C.c_int, C.c_int, C.POINTER(C.c_int32), C.c_int]),
+    "rrt_comm_id": (C.c_int, [C.c_void_p]),
+    "rrt_comm_create": (C.c_int, [C.c_void_p, C.c_int, C.c_int, C.c_int, C.POINTER(C.c_void_p)]),
+    "rrt_comm_destroy": (None, [C.c_void_p]),
+    "rrt_film_gather": (C.c_int, [C.c_void_p, C.c_void_p, C.c_void_p, C.c_int]),
+    "rrt_film_gather_all": (C.c_int, [C.POINTER(C.c_void_p), C.POINTER(C.c_void_p), C.c_int, C.c_int]),
     "rrt_set_option": (C.c_int, [C.c_void_p, C.c_char_p, C.c_double]),
     "rrt_last_error": (C.c_char_p, []),
     "rrt_version": (C.c_char_p, []),

@@ -192,6 +192,50 @@ class Renderer:
         return st
 
 
+class Comm:
+    """RCCL communicator behind the C ABI (rrt_comm_*): one per rank, one process per GPU. Rank 0 draws the id
+    (`Comm.new_id()`) and ships the 128 bytes to the others over whatever channel the host has (torch.distributed
+    broadcast in bench.py); creation is collective."""
+
+    def __init__(self, comm_id, rank, world, device):
+        buf = (C.c_uint8 * A.RRT_COMM_ID_BYTES).from_buffer_copy(bytes(comm_id))
+        h = C.c_void_p()
+        _check(A.lib().rrt_comm_create(buf, rank, world, device, C.byref(h)))
+        self._h, self.rank, self.world = h, rank, world
+
+    @staticmethod
+    def new_id():
+        buf = (C.c_uint8 * A.RRT_COMM_ID_BYTES)()
+        _check(A.lib().rrt_comm_id(buf))
+        return bytes(buf)
+
+    def gather(self, renderer, film_ptr, root=0):
+        """rrt_film_gather: this rank's bands -> root (box filter) / sum of the films on root (wide filters); enqueued on the
+        renderer's stream."""
+        _check(A.lib().rrt_film_gather(renderer._h, self._h, film_ptr, root))
+
+    def close(self):
+        if getattr(self, "_h", None):
+            A.lib().rrt_comm_destroy(self._h)
+            self._h = None
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass
+
+
+def band_rows(yres, rank, world):
+    """[(y0, y1)] of the 16-row bands `rank` owns (rrt_band_rows: the C ABI's own partition arithmetic)."""
+    n = A.lib().rrt_band_rows(yres, rank, world, None, 0)
+    if n < 0:
+        _check(n)
+    buf = (C.c_int32 * (2 * max(n, 1)))()
+    A.lib().rrt_band_rows(yres, rank, world, buf, n)
+    return [(buf[2 * i], buf[2 * i + 1]) for i in range(n)]
+
+
 def resolve_rgba8(film, scale=1.0):
     """Film::write_image (film.rs:323-366) + gamma/quantise of renderprocess::write_image (:1501-1530)."""
     film = np.ascontiguousarray(film)

@@ -17,7 +17,7 @@ template <typename R> struct ShadeBlock { static constexpr int n = 256; };
 #define RRT_SHADE_BLOCK 256
 #endif
 template <> struct ShadeBlock<float> { static constexpr int n = RRT_SHADE_BLOCK; };
-enum { ERR_SHADING_NORMAL = 1, ERR_STACK = 2, ERR_BETA = 4, ERR_NULL_BSDF = 8, ERR_MIPMAP = 16, ERR_HALTON_DIMS = 32, ERR_ST_DIMS = 64, ERR_NO_LIGHTS = 128 };
+enum { ERR_SHADING_NORMAL = 1, ERR_BETA = 4, ERR_NULL_BSDF = 8, ERR_MIPMAP = 16, ERR_HALTON_DIMS = 32, ERR_ST_DIMS = 64, ERR_NO_LIGHTS = 128 };
 static_assert(ERR_ST_DIMS == kErrStDims, "error bit shared with dmath.hpp");
 static_assert(ERR_HALTON_DIMS == kErrHaltonDims, "error bit shared with dmath.hpp");
 

@@ -666,3 +666,222 @@ static __global__ void __launch_bounds__(kRgBlock) k_raygen_aux_f32(SceneDev<flo
 }
 
 }  // namespace rrtd
+
+// ------------------------------------------------------------------------------------------------------------
+// Lean lens arithmetic of the fp32 product path (the f64 parity mode keeps the reference's operation order).
+// On a spherical interface |p_hit - centre| = |radius|, so the normal is (p_hit - centre) / |radius| instead of a
+// normalisation; the ray direction is re-normalised with one v_rsq of the d.d the quadratic needs anyway instead of
+// Ray::new's repeated normalisations; cos_i of refract() is the dot product faceforward() already formed; the
+// reference's early returns become one accumulated `ok` flag (straight-line code: a dead lane computes garbage that
+// nothing reads). Per interface: 2 v_sqrt + 3 v_rcp / v_rsq and ~75 VALU slots instead of 3 sqrt + 8 divisions and
+// ~176 with a branch per rejection. Differences to the reference-order fp32 evaluation are of the size of its own
+// rounding (1e-7 relative per interface); tests/test_gpu_parity.py::test_camera_samples holds both to the f64 oracle.
+// ------------------------------------------------------------------------------------------------------------
+namespace rrtd {
+
+struct RgLensLds { float4 a[32]; float2 b[32]; };   // a = {curvature_radius, thickness, eta_i / eta_t, aperture_radius^2}, b = {1 / |curvature_radius|, curvature_radius^2}
+
+RRT_DEV void rg_lens_to_lds(const SceneDev<float>& s, RgLensLds* L, uint32_t tid) {
+  if (tid < (uint32_t)s.n_lens) {
+    const LensElem<float> e = s.lens[tid];
+    const float eta_prev = tid > 0 ? s.lens[tid - 1].eta : 0.0f;
+    const float eta_t = (tid > 0 && eta_prev != 0.0f) ? eta_prev : 1.0f;   // camera.rs:196-201
+    L->a[tid] = make_float4(e.curvature_radius, e.thickness, e.eta / eta_t, e.aperture_radius * e.aperture_radius);
+    L->b[tid] = make_float2(e.curvature_radius != 0.0f ? 1.0f / fabsf(e.curvature_radius) : 0.0f, e.curvature_radius * e.curvature_radius);
+  }
+}
+
+// generate_ray up to trace_lenses_from_film (camera.rs:534-556), lean form; returns the sample weight (cos^4 term)
+RRT_DEV float rg_begin_lean(const SceneDev<float>& s, float pfx, float pfy, float lx, float ly, RgLane* L) {
+  const float sx = pfx / (float)s.xres, sy = pfy / (float)s.yres;
+  const float p2x = s.extent[0] * (1.0f - sx) + s.extent[2] * sx, p2y = s.extent[1] * (1.0f - sy) + s.extent[3] * sy;
+  const float fx = -p2x, fy = p2y;
+  const float r2 = fx * fx + fy * fy;
+  const float r_film = __builtin_amdgcn_sqrtf(r2);
+  const float* pb = (r_film / (s.diagonal / 2.0f) >= 1.0f) ? s.pupil63 : s.pupil0;   // Q6
+  const float plx = pb[0] * (1.0f - lx) + pb[2] * lx, ply = pb[1] * (1.0f - ly) + pb[3] * ly;
+  const float inv_r = __builtin_amdgcn_rcpf(r_film);
+  const float sin_t = r_film != 0.0f ? fy * inv_r : 0.0f, cos_t = r_film != 0.0f ? fx * inv_r : 1.0f;
+  const float area = (pb[2] - pb[0]) * (pb[3] - pb[1]);
+  const float rear_z = s.lens[s.n_lens - 1].thickness;
+  const V3<float> dir(cos_t * plx - sin_t * ply - fx, sin_t * plx + cos_t * ply - fy, rear_z);
+  const float il = __builtin_amdgcn_rsqf(len2(dir));
+  const V3<float> d = dir * il;
+  const float cos4 = (d.z * d.z) * (d.z * d.z);
+  // flip_z: (x, y, -z); the film point has z = 0
+  L->o = V3<float>(fx, fy, 0.0f); L->d = V3<float>(d.x, d.y, -d.z); L->element_z = 0.0f; L->i = s.n_lens - 1;
+  if (s.simple_weighting) return cos4 * area / ((s.pupil0[2] - s.pupil0[0]) * (s.pupil0[3] - s.pupil0[1]));
+  return (s.shutter_close - s.shutter_open) * (cos4 * area) / rear_z * rear_z;
+}
+
+// One interface of trace_lenses_from_film (camera.rs:163-211) for an interface index that is uniform across the wave (the dense
+// kernels step all lanes together): the element is a scalar operand and stop-vs-sphere is a scalar branch. Returns false = blocked.
+RRT_DEV bool rg_step_lean(const float4 el, const float2 el2, RgLane* L) {
+  L->element_z -= el.y;
+  const V3<float> o = L->o, d = L->d;
+  if (el.x == 0.0f) {   // aperture stop
+    const float t = (L->element_z - o.z) * __builtin_amdgcn_rcpf(d.z);
+    const V3<float> p_hit = o + d * t;
+    L->o = p_hit;
+    return (d.z < 0.0f) & (t >= 0.0f) & (p_hit.x * p_hit.x + p_hit.y * p_hit.y < el.w);
+  }
+  // intersect_spherical_element camera.rs:220-253 + quadratic misc.rs:231-251
+  const V3<float> oc(o.x, o.y, o.z - (L->element_z + el.x));
+  const float a = len2(d);
+  const float b = 2.0f * dot(d, oc);
+  const float c = len2(oc) - el2.y;
+  const float disc = b * b - 4.0f * a * c;
+  const float root = __builtin_amdgcn_sqrtf(disc);
+  const float q = (b < 0.0f) ? -0.5f * (b - root) : -0.5f * (b + root);
+  const float t0 = q * __builtin_amdgcn_rcpf(a), t1 = c * __builtin_amdgcn_rcpf(q);
+  const bool use_closer = (d.z > 0.0f) ^ (el.x < 0.0f);
+  const float t = use_closer ? fminf(t0, t1) : fmaxf(t0, t1);
+  bool ok = (disc >= 0.0f) & (t >= 0.0f);   // (a NaN t fails `t >= 0` like the reference's `t < 0` / assert pair)
+  const V3<float> p_hit = o + d * t;
+  ok &= p_hit.x * p_hit.x + p_hit.y * p_hit.y < el.w;
+  L->o = p_hit;
+  V3<float> n = (oc + d * t) * el2.x;
+  const V3<float> wi = d * -__builtin_amdgcn_rsqf(a);
+  float cos_i = dot(n, wi);
+  const float sgn = cos_i < 0.0f ? -1.0f : 1.0f;   // faceforward(n, -ray.d)
+  n = n * sgn; cos_i = cos_i * sgn;
+  const float eta = el.z;
+  const float sin2_t = eta * eta * fmaxf(0.0f, 1.0f - cos_i * cos_i);   // refract reflection.rs:122-134
+  ok &= sin2_t < 1.0f;
+  const float cos_t = __builtin_amdgcn_sqrtf(1.0f - sin2_t);
+  L->d = wi * -eta + n * (eta * cos_i - cos_t);
+  return ok;
+}
+
+}  // namespace rrtd
+
+// ------------------------------------------------------------------------------------------------------------
+// Dense two-stage camera ray generation with the lean lens arithmetic (the default fp32 path).
+// With ~70 instructions per interface the persistent-thread machinery (ballots, refill, state machine: a fixed
+// cost per loop iteration, at ~6 interfaces per sample) costs more than the idle lanes it saves, so:
+//   stage A  one thread per sample: get_camerasample + the whole main trace. Lanes die on the way (69 %), the
+//            survivors are pushed - one atomic per 1024-thread block - to a staging queue of 48-byte records in
+//            queue order {world ray, p_film, p_lens, slot, weight}. Nothing is written for a dead sample.
+//   stage B  one thread per survivor: the auxiliary traces (x + 0.05 and y + 0.05 together for every lane, the
+//            rare opposite shifts in a second round), then the living samples enter q_active.
+// ------------------------------------------------------------------------------------------------------------
+namespace rrtd {
+
+constexpr int kRgDense = 1024;
+
+// staging records live in the next-queue arrays, which are free until the first shading launch:
+//   nray_o[i] = {o.xyz (world), slot}, nray_d[i] = {d.xyz (world), weight}, npath[i] = {p_film.xy, p_lens.xy}, hindex[i] = Halton index
+static __global__ void __launch_bounds__(kRgDense) k_raygen_main_f32(SceneDev<float> s, Pools<float> p, PassDesc pd, int write_samp, double* dims_out) {
+  __shared__ RgLensLds lens;
+  __shared__ uint32_t push_lds[kRgDense / 64 + 1];
+  const uint32_t tid = threadIdx.x;
+  rg_lens_to_lds(s, &lens, tid);
+  __syncthreads();
+  const uint32_t pl = blockIdx.x * blockDim.x + tid, sl = blockIdx.y;
+  bool alive = false;
+  uint32_t slot = 0, index = 0;
+  float pfx = 0, pfy = 0, lx = 0, ly = 0, w = 0;
+  RgLane L; L.i = -1; L.phase = 0; L.element_z = 0;
+  if (pl < pd.npix) {
+    slot = sl * pd.npix + pl;
+    const uint2 po = reinterpret_cast<const uint2*>(p.pix_off)[pl];
+    const uint32_t px = po.y & 0xffffu, py = po.y >> 16;
+    index = po.x + (pd.s_begin + sl) * s.stride;
+    const double d0 = halton_dim(s, index, 0), d1 = halton_dim(s, index, 1), d2 = halton_cam_dim(s, index, 0), d3 = halton_cam_dim(s, index, 1);
+    pfx = (float)px + to_real<float>(d0); pfy = (float)py + to_real<float>(d1);
+    lx = to_real<float>(d2) + 0.5f; ly = to_real<float>(d3) + 0.5f;   // Q5
+    if (write_samp) p.samp[slot] = make_float4(pfx, pfy, lx, ly);
+    if (dims_out) { double* dd = dims_out + 5 * (size_t)(pl * pd.ns + sl); dd[0] = d0; dd[1] = d1; dd[2] = d2; dd[3] = d3; dd[4] = halton_dim(s, index, 4); }
+    w = rg_begin_lean(s, pfx, pfy, lx, ly, &L);
+    alive = w != 0.0f;
+  }
+  for (int k = s.n_lens - 1; k >= 0; k--) {   // (no lane-divergent branch inside: dead lanes ride along)
+    if (__ballot(alive) == 0ull) break;
+    alive &= rg_step_lean(lens.a[k], lens.b[k], &L);
+  }
+  const uint32_t q = block_push(&p.counters[C_NEXT], alive, push_lds);
+  if (alive) {
+    // ray out of the lens = flip_z, camera_to_world, normalise (camera.rs:558-565)
+    const V3<float> wo = aff_pt(s.cam_m, V3<float>(L.o.x, L.o.y, -L.o.z));
+    const V3<float> wdu = aff_vec(s.cam_m, V3<float>(L.d.x, L.d.y, -L.d.z));
+    const V3<float> wd = wdu * __builtin_amdgcn_rsqf(len2(wdu));
+    p.nray_o[q] = make_float4(wo.x, wo.y, wo.z, __uint_as_float(slot));
+    p.nray_d[q] = make_float4(wd.x, wd.y, wd.z, w);
+    p.npath[q] = make_float4(pfx, pfy, lx, ly);
+    p.hindex[q] = index;
+  }
+}
+
+// one whole lens trace, lean; `out`: the ray itself, world space (textured scenes keep the auxiliary rays)
+RRT_DEV bool rg_trace_lean(const SceneDev<float>& s, const RgLensLds& lens, float pfx, float pfy, float lx, float ly, bool want_ray, RayT<float>& out) {
+  RgLane L; L.phase = 0;
+  const float w = rg_begin_lean(s, pfx, pfy, lx, ly, &L);
+  bool ok = w != 0.0f;
+  for (int k = s.n_lens - 1; k >= 0; k--) ok &= rg_step_lean(lens.a[k], lens.b[k], &L);
+  if (ok && want_ray) {
+    out.o = aff_pt(s.cam_m, V3<float>(L.o.x, L.o.y, -L.o.z));
+    const V3<float> wdu = aff_vec(s.cam_m, V3<float>(L.d.x, L.d.y, -L.d.z));
+    out.d = wdu * __builtin_amdgcn_rsqf(len2(wdu));
+  }
+  return ok;
+}
+
+static __global__ void __launch_bounds__(kRgDense) k_raygen_aux2_f32(SceneDev<float> s, Pools<float> p, int enqueue) {
+  __shared__ RgLensLds lens;
+  __shared__ uint32_t push_lds[kRgDense / 64 + 1];
+  const uint32_t tid = threadIdx.x;
+  const uint32_t n = p.counters[C_NEXT];
+  if (blockIdx.x * blockDim.x >= n) return;   // the grid is sized for the worst case
+  rg_lens_to_lds(s, &lens, tid);
+  __syncthreads();
+  const uint32_t i = blockIdx.x * blockDim.x + tid;
+  const bool diffs = p.rdx_o != nullptr;   // block-uniform
+  bool alive = false;
+  uint32_t slot = 0;
+  float4 ro = make_float4(0, 0, 0, 0), rd = ro, cs = ro;
+  if (i < n) {
+    ro = p.nray_o[i]; rd = p.nray_d[i];
+    slot = __float_as_uint(ro.w);
+    cs = p.npath[i];
+  }
+  // Four rounds with ONE inlined trace: x + 0.05 and y + 0.05 for every lane (nearly every survivor passes both), then the rare
+  // opposite shifts for the lanes that need them (a wave skips a round none of its lanes needs).
+  RayT<float> aux, auy;
+  float epsx = 0.05f, epsy = 0.05f;
+  bool okx = false, oky = false;
+  for (int round = 0; round < 4; round++) {
+    const bool is_x = (round & 1) == 0;
+    const bool act = i < n && (round < 2 || (round == 2 ? !okx : (okx && !oky)));
+    if (__ballot(act) == 0ull) continue;
+    const float e = round < 2 ? 0.05f : -0.05f;
+    RayT<float> out;
+    bool ok = false;
+    if (act) ok = rg_trace_lean(s, lens, cs.x + (is_x ? e : 0.0f), cs.y + (is_x ? 0.0f : e), cs.z, cs.w, diffs, out);
+    if (act && is_x) { okx = ok; epsx = e; if (diffs) aux = out; }
+    if (act && !is_x) { oky = ok; epsy = e; if (diffs) auy = out; }
+  }
+  alive = okx && oky;
+  if (i < n) {
+    if (alive && diffs) {   // rx / ry (camera.rs:597-598, 613-614), then scale_differentials (geometry.rs:1883-1888)
+      const V3<float> o(ro.x, ro.y, ro.z), d(rd.x, rd.y, rd.z);
+      V3<float> rxo = o + (aux.o - o) / epsx, rxd = d + (aux.d - d) / epsx;
+      V3<float> ryo = o + (auy.o - o) / epsy, ryd = d + (auy.d - d) / epsy;
+      rxo = o + (rxo - o) * s.diff_scale; ryo = o + (ryo - o) * s.diff_scale;
+      rxd = d + (rxd - d) * s.diff_scale; ryd = d + (ryd - d) * s.diff_scale;
+      p.rdx_o[slot] = make_float4(rxo.x, rxo.y, rxo.z, 0.0f); p.rdx_d[slot] = make_float4(rxd.x, rxd.y, rxd.z, 0.0f);
+      p.rdy_o[slot] = make_float4(ryo.x, ryo.y, ryo.z, 0.0f); p.rdy_d[slot] = make_float4(ryd.x, ryd.y, ryd.z, 0.0f);
+    }
+  }
+  const bool enq = alive && enqueue;
+  const uint32_t q = block_push(&p.counters[C_ACTIVE], enq, push_lds);
+  (void)block_push(&p.counters[C_CAMERA_RAYS], alive, push_lds);
+  if (enq) {
+    p.q_active[q] = QEnt{slot, 5u, p.hindex[i], 0u};   // five camera dimensions consumed, bounce 0
+    p.path[q] = make_float4(1.0f, 1.0f, 1.0f, 1.0f);   // beta, eta_scale
+    p.ray_o[q] = make_float4(ro.x, ro.y, ro.z, Const<float>::inf);
+    p.ray_d[q] = make_float4(rd.x, rd.y, rd.z, __uint_as_float(0xffffffffu));
+  }
+  if (alive) { p.L[slot] = make_float4(0.0f, 0.0f, 0.0f, 0.0f); p.weight[slot] = rd.w; }
+}
+
+}  // namespace rrtd

@@ -30,6 +30,9 @@ int rrt_create(int device, const rrt_scene_desc* desc, int precision, rrt_handle
   if (!desc || !out) { rrt::set_last_error("rrt_create: null argument"); return RRT_EINVAL; }
   *out = nullptr;
   if (precision != RRT_F32 && precision != RRT_F64) { rrt::set_last_error("rrt_create: bad precision"); return RRT_EINVAL; }
+  // the desc is checked before anything touches a device (and also where there is none): a caller-filled desc with a bad index or a
+  // cyclic BVH must never reach a kernel
+  { const int rc = guarded([&]() { rrtd::validate_desc(desc); }); if (rc != RRT_OK) return rc; }
   int n = rrt_device_count();
   if (n <= 0) { rrt::set_last_error("rrt_create: no HIP device visible (this library has no CPU fallback)"); return RRT_EDEVICE; }
   if (device < 0 || device >= n) { rrt::set_last_error("rrt_create: device index out of range"); return RRT_EINVAL; }

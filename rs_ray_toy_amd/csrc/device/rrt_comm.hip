@@ -1,0 +1,154 @@
+// Multi-GPU film reassembly behind the C ABI (include/rrt.h): RCCL over xGMI, one collective per frame.
+// The reference has one address space and merges tiles under a lock (Film::merge_film_tile film.rs:248-263, driven from
+// integrator/mod.rs:64-74,133); here every rank renders the interleaved 16-row bands b % world == rank of the frame into
+// its own device film (rrt_render_bands) and the films meet on `root`:
+//   box filter, radius <= 0.5  every sample lands in its own pixel, the ranks' bands are disjoint: grouped ncclSend /
+//                              ncclRecv of the band rows only - a gather; each rank ships 1/world of the film over its
+//                              direct xGMI link to root (root receives from all peers at once: no ring);
+//   wider filters              samples splat into neighbouring rows of the rank's own film: ncclReduce(sum) of the film.
+// A band is contiguous in the film (rows x W x 4 words), so no packing is needed.
+#include <rccl/rccl.h>
+
+#include <mutex>
+
+#include "rrt_impl.hpp"
+
+namespace rrt { void set_last_error(const std::string& msg); }
+struct rrt_handle { rrtd::HandleBase* impl; };
+struct rrt_comm { ncclComm_t comm; int rank, world, device; };
+
+namespace {
+constexpr int kBandRows = 16;   // tile height of integrator/mod.rs:55 (rrt_render_bands)
+
+struct NcclError : std::runtime_error { using std::runtime_error::runtime_error; };
+#define NCCL_CHECK(expr)                                                                                       \
+  do {                                                                                                         \
+    ncclResult_t _r = (expr);                                                                                  \
+    if (_r != ncclSuccess) throw NcclError(std::string("RCCL error: ") + ncclGetErrorString(_r) + " at " #expr); \
+  } while (0)
+
+template <typename F>
+int guarded(F&& fn) {
+  try { fn(); return RRT_OK; }
+  catch (const NcclError& e) { rrt::set_last_error(e.what()); return RRT_EDEVICE; }
+  catch (const rrtd::DeviceError& e) { rrt::set_last_error(e.what()); return RRT_EDEVICE; }
+  catch (const std::invalid_argument& e) { rrt::set_last_error(e.what()); return RRT_EINVAL; }
+  catch (const std::exception& e) { rrt::set_last_error(e.what()); return RRT_EINVAL; }
+}
+
+// one rank's part of the collective, inside an open ncclGroup; `films[r]` only matters on the rank that owns it
+void enqueue_gather(rrtd::HandleBase* h, ncclComm_t comm, int rank, int world, void* film, int root) {
+  int W = 0, H = 0;
+  bool splats = false;
+  h->film_geometry(&W, &H, &splats);
+  const ncclDataType_t dt = h->precision() == RRT_F32 ? ncclFloat : ncclDouble;
+  const size_t word = h->precision() == RRT_F32 ? 4 : 8;
+  hipStream_t st = h->stream();
+  if (splats) {   // overlapping films: sum (in place on root)
+    NCCL_CHECK(ncclReduce(film, film, (size_t)W * (size_t)H * 4, dt, ncclSum, root, comm, st));
+    return;
+  }
+  const int n_bands = (H + kBandRows - 1) / kBandRows;
+  for (int b = 0; b < n_bands; b++) {
+    const int owner = b % world;
+    if (owner == root) continue;                 // root's own bands are already in place
+    if (rank != root && rank != owner) continue;
+    const int y0 = b * kBandRows, y1 = std::min(H, y0 + kBandRows);
+    char* at = (char*)film + (size_t)y0 * (size_t)W * 4 * word;
+    const size_t count = (size_t)(y1 - y0) * (size_t)W * 4;
+    if (rank == root) NCCL_CHECK(ncclRecv(at, count, dt, owner, comm, st));
+    else NCCL_CHECK(ncclSend(at, count, dt, root, comm, st));
+  }
+}
+}  // namespace
+
+extern "C" {
+
+int rrt_band_rows(int yres, int rank, int world, int32_t* y0y1, int max_bands) {
+  if (yres < 0 || world < 1 || rank < 0 || rank >= world) { rrt::set_last_error("rrt_band_rows: bad argument"); return RRT_EINVAL; }
+  int n = 0;
+  for (int b = 0, y0 = 0; y0 < yres; b++, y0 += kBandRows) {
+    if (b % world != rank) continue;
+    if (y0y1 && n < max_bands) { y0y1[2 * n] = y0; y0y1[2 * n + 1] = std::min(yres, y0 + kBandRows); }
+    n++;
+  }
+  return n;
+}
+
+int rrt_comm_id(uint8_t id[RRT_COMM_ID_BYTES]) {
+  static_assert(RRT_COMM_ID_BYTES == NCCL_UNIQUE_ID_BYTES, "rrt.h mirrors ncclUniqueId");
+  if (!id) { rrt::set_last_error("rrt_comm_id: null argument"); return RRT_EINVAL; }
+  return guarded([&]() {
+    ncclUniqueId u;
+    NCCL_CHECK(ncclGetUniqueId(&u));
+    memcpy(id, u.internal, NCCL_UNIQUE_ID_BYTES);
+  });
+}
+
+int rrt_comm_create(const uint8_t id[RRT_COMM_ID_BYTES], int rank, int world, int device, rrt_comm** out) {
+  if (!id || !out || world < 1 || rank < 0 || rank >= world) { rrt::set_last_error("rrt_comm_create: bad argument"); return RRT_EINVAL; }
+  *out = nullptr;
+  int n = 0;
+  if (hipGetDeviceCount(&n) != hipSuccess || n <= 0) { (void)hipGetLastError(); rrt::set_last_error("rrt_comm_create: no HIP device visible"); return RRT_EDEVICE; }
+  if (device < 0 || device >= n) { rrt::set_last_error("rrt_comm_create: device index out of range"); return RRT_EINVAL; }
+  return guarded([&]() {
+    HIP_CHECK(hipSetDevice(device));
+    ncclUniqueId u;
+    memcpy(u.internal, id, NCCL_UNIQUE_ID_BYTES);
+    ncclComm_t c = nullptr;
+    NCCL_CHECK(ncclCommInitRank(&c, world, u, rank));
+    *out = new rrt_comm{c, rank, world, device};
+  });
+}
+
+void rrt_comm_destroy(rrt_comm* c) {
+  if (!c) return;
+  (void)hipSetDevice(c->device);
+  (void)ncclCommDestroy(c->comm);
+  delete c;
+}
+
+int rrt_film_gather(rrt_handle* h, rrt_comm* c, void* film_xyzw_device, int root) {
+  if (!h || !c || !film_xyzw_device) { rrt::set_last_error("rrt_film_gather: null argument"); return RRT_EINVAL; }
+  if (root < 0 || root >= c->world) { rrt::set_last_error("rrt_film_gather: root out of range"); return RRT_EINVAL; }
+  if (h->impl->device() != c->device) { rrt::set_last_error("rrt_film_gather: handle and communicator live on different devices"); return RRT_EINVAL; }
+  return guarded([&]() {
+    HIP_CHECK(hipSetDevice(c->device));
+    NCCL_CHECK(ncclGroupStart());
+    try { enqueue_gather(h->impl, c->comm, c->rank, c->world, film_xyzw_device, root); }
+    catch (...) { (void)ncclGroupEnd(); throw; }
+    NCCL_CHECK(ncclGroupEnd());
+  });
+}
+
+// One process that owns all GPUs of the node (what the reference's single binary becomes): communicators come from
+// ncclCommInitAll over the handles' devices and are kept for the process lifetime (keyed by the device list).
+int rrt_film_gather_all(rrt_handle* const* handles, void* const* films_device, int n, int root) {
+  if (!handles || !films_device || n < 1 || root < 0 || root >= n) { rrt::set_last_error("rrt_film_gather_all: bad argument"); return RRT_EINVAL; }
+  for (int i = 0; i < n; i++) if (!handles[i] || !films_device[i]) { rrt::set_last_error("rrt_film_gather_all: null handle / film"); return RRT_EINVAL; }
+  return guarded([&]() {
+    static std::mutex mu;
+    static std::vector<int> devs;
+    static std::vector<ncclComm_t> comms;
+    std::lock_guard<std::mutex> lock(mu);
+    std::vector<int> want(n);
+    for (int i = 0; i < n; i++) want[i] = handles[i]->impl->device();
+    for (int i = 0; i < n; i++) for (int j = 0; j < i; j++) if (want[i] == want[j]) throw std::invalid_argument("rrt_film_gather_all: two handles on one device (RCCL needs one rank per GPU)");
+    if (want != devs) {
+      for (ncclComm_t c : comms) (void)ncclCommDestroy(c);
+      comms.assign(n, nullptr); devs.clear();
+      NCCL_CHECK(ncclCommInitAll(comms.data(), n, want.data()));
+      devs = want;
+    }
+    NCCL_CHECK(ncclGroupStart());
+    try {
+      for (int i = 0; i < n; i++) {
+        HIP_CHECK(hipSetDevice(want[i]));
+        enqueue_gather(handles[i]->impl, comms[i], i, n, films_device[i], root);
+      }
+    } catch (...) { (void)ncclGroupEnd(); throw; }
+    NCCL_CHECK(ncclGroupEnd());
+  });
+}
+
+}  // extern "C"

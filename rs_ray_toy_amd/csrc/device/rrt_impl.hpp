@@ -26,13 +26,17 @@ struct PanicError : std::runtime_error { using std::runtime_error::runtime_error
   do {                                                                                                    \
     hipError_t _e = (expr);                                                                               \
     if (_e != hipSuccess)                                                                                 \
-      throw DeviceError(std::string("HIP error: ") + hipGetErrorString(_e) + " at " #expr);              \
+      throw ::rrtd::DeviceError(std::string("HIP error: ") + hipGetErrorString(_e) + " at " #expr);              \
   } while (0)
 
 struct HandleBase {
   virtual ~HandleBase() {}
   virtual int precision() const = 0;
   virtual hipStream_t stream() const = 0;
+  virtual int device() const = 0;
+  // film geometry for the multi-GPU reassembly (rrt_comm.hip): resolution, and whether samples splat across pixels (then the
+  // ranks' films overlap and the collective is a sum instead of a gather of disjoint bands)
+  virtual void film_geometry(int* xres, int* yres, bool* splats) const = 0;
   virtual void trace_closest(const rrt_rays* rays, size_t n, rrt_hits* out) = 0;
   virtual void trace_any(const rrt_rays* rays, size_t n, uint8_t* occluded) = 0;
   virtual void camera_samples(const int32_t rect[4], uint64_t s0, uint64_t s1, double* dims5, double* ray_od6, double* weight) = 0;
@@ -112,16 +116,87 @@ inline std::vector<uint32_t> plane_ids(const std::vector<double>& w, size_t n, c
   return ids;
 }
 
+// A desc normally comes from rrt_scene_load, but the ABI lets a caller fill one: every index the kernels follow is checked here once
+// (a kernel reading past an array can take the GPU down for everybody on the host)
+inline void validate_desc(const rrt_scene_desc* d) {
+  if (d->abi_version != RRT_ABI_VERSION) throw std::invalid_argument("scene desc ABI version mismatch");
+  auto bad = [](const std::string& what) { throw std::invalid_argument("scene desc: " + what); };
+  if ((d->n_positions && !d->positions) || (d->n_tris && !d->tris) || (d->n_prims && !d->prims) || (d->n_materials && !d->materials) ||
+      (d->n_bvh_nodes && !d->bvh_nodes) || (d->n_prim_order && !d->prim_order) || (d->n_lights && !d->lights) || (d->n_xforms && !d->xforms) ||
+      (d->n_spheres && !d->spheres) || (d->n_textures && !d->textures) || (d->n_images && !d->images) || (d->n_image_texels && !d->image_texels))
+    bad("null array with a non-zero count");
+  for (size_t i = 0; i < d->n_tris; i++) {
+    const rrt_tri& t = d->tris[i];
+    for (int k = 0; k < 3; k++) {
+      if (t.v[k] >= d->n_positions) bad("triangle vertex index out of range");
+      if (t.mesh_has_n && t.n[k] >= d->n_normals) bad("triangle normal index out of range");
+      if (t.mesh_has_uv && t.uv[k] >= d->n_uvs) bad("triangle uv index out of range");
+    }
+  }
+  for (size_t i = 0; i < d->n_spheres; i++)
+    if (d->spheres[i].xform < 0 || (size_t)d->spheres[i].xform >= d->n_xforms) bad("sphere transform index out of range");
+  for (size_t i = 0; i < d->n_prims; i++) {
+    const rrt_prim& p = d->prims[i];
+    if (p.type != RRT_PRIM_TRIANGLE && p.type != RRT_PRIM_SPHERE) bad("unknown primitive type");
+    if (p.shape >= (p.type == RRT_PRIM_TRIANGLE ? d->n_tris : d->n_spheres)) bad("primitive shape index out of range");
+    if (p.instance < -1 || (p.instance >= 0 && (size_t)p.instance >= d->n_xforms)) bad("primitive instance transform out of range");
+    if (p.material >= d->n_materials) bad("primitive material index out of range");
+  }
+  for (size_t i = 0; i < d->n_prim_order; i++) if (d->prim_order[i] >= d->n_prims) bad("prim_order entry out of range");
+  for (size_t i = 0; i < d->n_bvh_nodes; i++) {
+    const rrt_bvh_node& n = d->bvh_nodes[i];
+    if (n.n_primitives > 0) { if ((size_t)n.offset + n.n_primitives > d->n_prim_order) bad("BVH leaf outside prim_order"); }
+    else if (n.offset >= d->n_bvh_nodes || i + 1 >= d->n_bvh_nodes) bad("BVH interior node child out of range");
+    if (n.axis > 2) bad("BVH split axis out of range");
+  }
+  // The traversal kernels trust two more things: that the links form a tree in flattern_bvh's pre-order (bvh.rs:728-751: first child at
+  // i + 1, second child after the first child's whole subtree) - a back edge or self reference would make a ray walk for ever, i.e. hang
+  // the GPU - and that bvh_depth bounds the real depth (it sizes the private / LDS / overflow stacks, which are written unguarded).
+  if (d->n_bvh_nodes) {
+    std::vector<uint8_t> seen(d->n_bvh_nodes, 0);
+    std::vector<std::pair<uint32_t, uint32_t>> todo{{0u, 1u}};   // node, depth (root = 1, as the host builder counts)
+    uint32_t max_depth = 0;
+    while (!todo.empty()) {
+      const auto [i, depth] = todo.back();
+      todo.pop_back();
+      if (seen[i]) bad("BVH node reachable twice (the links are not a tree)");
+      seen[i] = 1;
+      max_depth = std::max(max_depth, depth);
+      const rrt_bvh_node& n = d->bvh_nodes[i];
+      if (n.n_primitives > 0) continue;
+      if (n.offset <= i + 1) bad("BVH second child does not follow the first child's subtree (back edge)");
+      todo.push_back({n.offset, depth + 1});
+      todo.push_back({i + 1, depth + 1});
+    }
+    if (d->bvh_depth < max_depth) bad("bvh_depth understates the tree's depth (" + std::to_string(d->bvh_depth) + " < " + std::to_string(max_depth) + ")");
+  }
+  for (size_t i = 0; i < d->n_lights; i++) {
+    const rrt_light& l = d->lights[i];
+    if (l.type < RRT_LIGHT_POINT || l.type > RRT_LIGHT_DISTANT) bad("unknown light type");
+    if (l.type == RRT_LIGHT_DIFFUSE && l.shape >= (l.shape_type == RRT_PRIM_SPHERE ? d->n_spheres : d->n_tris)) bad("area light shape index out of range");
+  }
+  for (size_t i = 0; i < d->n_textures; i++) {
+    const rrt_texture& t = d->textures[i];
+    if (t.type < RRT_TEX_CONSTANT || t.type > RRT_TEX_IMAGE || t.mapping < RRT_MAP_UV || t.mapping > RRT_MAP_IDENTITY3D) bad("unknown texture / mapping type");
+  }
+  if (d->camera.n_elems < 1 || d->camera.n_elems > 64 || !d->camera.elems) bad("camera lens description missing");
+  if (d->film.xres < 1 || d->film.yres < 1) bad("empty film");
+  if (d->sampler.type == RRT_SAMPLER_HALTON && d->sampler.n_perms && !d->sampler.perms) bad("Halton permutation table missing");
+}
+
+
 template <typename R>
 class Handle : public HandleBase {
  public:
   Handle(int device, const rrt_scene_desc* d) : dev_(device), desc_(*d) {
     HIP_CHECK(hipSetDevice(dev_));
-    create_streams(hipStreamDefault);
-    HIP_CHECK(hipEventCreateWithFlags(&ev_shade_, hipEventDisableTiming));
-    for (int k = 0; k < 2; k++) HIP_CHECK(hipEventCreateWithFlags(&ev_shadow_[k], hipEventDisableTiming));
-    upload_scene(d);
-    HIP_CHECK(hipStreamSynchronize(st_));
+    try {
+      create_streams(hipStreamDefault);
+      HIP_CHECK(hipEventCreateWithFlags(&ev_shade_, hipEventDisableTiming));
+      for (int k = 0; k < 2; k++) HIP_CHECK(hipEventCreateWithFlags(&ev_shadow_[k], hipEventDisableTiming));
+      upload_scene(d);
+      HIP_CHECK(hipStreamSynchronize(st_));
+    } catch (...) { release_streams(); throw; }   // a refused scene (unsupported / panic) must not leak its streams: the destructor does not run
     // Large pools matter: a launch lasts at least as long as the latency chain of its longest ray, so few big
     // launches beat many small ones (whole 1024^2 x 256 spp frame in one pass: 268 M slots x 280 B = 75 GB in fp32).
     size_t free_b = 0, total_b = 0;
@@ -131,20 +206,31 @@ class Handle : public HandleBase {
   }
   ~Handle() override {
     (void)hipSetDevice(dev_);
-    (void)hipStreamSynchronize(st_);
-    (void)hipStreamSynchronize(st2_);
-    (void)hipEventDestroy(ev_shade_); (void)hipEventDestroy(ev_shadow_[0]); (void)hipEventDestroy(ev_shadow_[1]);
-    (void)hipStreamDestroy(st2_);
-    (void)hipStreamDestroy(st_);
+    release_streams();
+  }
+  void release_streams() {
+    if (st_) (void)hipStreamSynchronize(st_);
+    if (st2_) (void)hipStreamSynchronize(st2_);
+    if (ev_shade_) (void)hipEventDestroy(ev_shade_);
+    for (int k = 0; k < 2; k++) if (ev_shadow_[k]) (void)hipEventDestroy(ev_shadow_[k]);
+    if (st2_) (void)hipStreamDestroy(st2_);
+    if (st_) (void)hipStreamDestroy(st_);
+    ev_shade_ = ev_shadow_[0] = ev_shadow_[1] = nullptr; st_ = st2_ = nullptr;
   }
   int precision() const override { return sizeof(R) == 4 ? RRT_F32 : RRT_F64; }
   hipStream_t stream() const override { return st_; }
+  int device() const override { return dev_; }
+  void film_geometry(int* xres, int* yres, bool* splats) const override {
+    const rrt_film& f = desc_.film;
+    *xres = f.xres; *yres = f.yres;
+    *splats = f.filter_type != RRT_FILTER_BOX || f.filter_radius[0] > 0.5 || f.filter_radius[1] > 0.5;
+  }
 
   void set_option(const std::string& key, double v) override {
     if (key == "max_paths") { if (v < 64) throw std::invalid_argument("max_paths must be >= 64"); max_paths_ = (size_t)v; }
     else if (key == "count_traversal") count_traversal_ = v != 0;
     else if (key == "persistent_traversal") { persistent_ = v != 0; if (v >= 1) trav_mode_ = (int)v; }
-    else if (key == "raygen_pt") raygen_pt_ = v != 0;
+    else if (key == "raygen_pt") raygen_pt_ = (int)v;   // 0: generic two-stage kernels, 1: four-kernel persistent-thread version, 2 (default): dense two-stage kernels with the lean lens arithmetic
     else if (key == "pt_split_closest") pt_split_closest_ = (uint32_t)v;
     else if (key == "pt_split_any") pt_split_any_ = (uint32_t)v;
     else if (key == "overlap_shadow") overlap_shadow_ = v != 0;
@@ -237,7 +323,7 @@ class Handle : public HandleBase {
   // rows of the interleaved 16-row bands b with b % world == rank (partition.py), as ONE pixel set
   // the main stream carries the critical path (closest-hit -> shade); shadow rays fill what it leaves idle
   void create_streams(unsigned flags) {
-    if (st_) { HIP_CHECK(hipStreamSynchronize(st_)); HIP_CHECK(hipStreamSynchronize(st2_)); (void)hipStreamDestroy(st2_); (void)hipStreamDestroy(st_); }
+    if (st_) { HIP_CHECK(hipStreamSynchronize(st_)); HIP_CHECK(hipStreamSynchronize(st2_)); (void)hipStreamDestroy(st2_); (void)hipStreamDestroy(st_); st_ = st2_ = nullptr; }
     int lo = 0, hi = 0;
     HIP_CHECK(hipDeviceGetStreamPriorityRange(&lo, &hi));
     HIP_CHECK(hipStreamCreateWithPriority(&st_, flags, hi));
@@ -295,6 +381,7 @@ class Handle : public HandleBase {
     }
     const size_t rw = (size_t)(rect[2] - rect[0]), rh = rh_all, rpix = rw * rh;
     const uint64_t s_total = nsamp > 1 ? nsamp - 1 : 0;  // samples 1 .. nsamp-1 (Q1)
+    if (rpix == 0) { if (stats) memset(stats, 0, sizeof(*stats)); return; }   // a rank that owns no band (world > yres / 16): nothing to add to the caller's film
 
     // internal full-frame film (zeroed), merged into the caller's buffer at the end
     if (film_.n != W * H * 4) film_.alloc(W * H * 4);
@@ -308,23 +395,27 @@ class Handle : public HandleBase {
     const size_t group = std::min(rpix, cap_);                           // pixels per group
     const uint64_t s_chunk = std::max<uint64_t>(1, cap_ / group);         // samples per pass
     const bool timing = stats != nullptr;
+    // timing events: destroyed on every way out of this function (a panic / HIP error thrown mid-frame included)
+    struct Events {
+      std::vector<hipEvent_t> all;
+      hipEvent_t make() { hipEvent_t e = nullptr; HIP_CHECK(hipEventCreate(&e)); all.push_back(e); return e; }
+      ~Events() { for (hipEvent_t e : all) (void)hipEventDestroy(e); }
+    } events;
     std::vector<std::pair<int, std::pair<hipEvent_t, hipEvent_t>>> evs;
     auto tick = [&](int cat, hipStream_t stream = nullptr) {
       if (!timing) return (size_t)0;
-      hipEvent_t a, b;
-      HIP_CHECK(hipEventCreate(&a)); HIP_CHECK(hipEventCreate(&b));
+      const hipEvent_t a = events.make(), b = events.make();
       HIP_CHECK(hipEventRecord(a, stream ? stream : st_));
       evs.push_back({cat, {a, b}});
       return evs.size() - 1;
     };
     auto tock = [&](size_t id, hipStream_t stream = nullptr) { if (timing) HIP_CHECK(hipEventRecord(evs[id].second.second, stream ? stream : st_)); };
     hipEvent_t ev_begin = nullptr, ev_end = nullptr;
-    if (timing) { HIP_CHECK(hipEventCreate(&ev_begin)); HIP_CHECK(hipEventCreate(&ev_end)); HIP_CHECK(hipEventRecord(ev_begin, st_)); }
+    if (timing) { ev_begin = events.make(); ev_end = events.make(); HIP_CHECK(hipEventRecord(ev_begin, st_)); }
     uint64_t n_closest_launch = 0, n_any_launch = 0;
     const int integ = desc_.integrator.type;
     const int max_depth = desc_.integrator.max_depth;
 
-    if (rpix == 0) { if (stats) memset(stats, 0, sizeof(*stats)); return; }
     for (size_t g0 = 0; g0 < rpix && s_total > 0; g0 += group) {
       const size_t npix = std::min(group, rpix - g0);
       for (uint64_t sb = 0; sb < s_total; sb += s_chunk) {
@@ -471,10 +562,8 @@ class Handle : public HandleBase {
       for (auto& ev : evs) {
         HIP_CHECK(hipEventElapsedTime(&ms, ev.second.first, ev.second.second));
         cat[ev.first] += ms;
-        (void)hipEventDestroy(ev.second.first); (void)hipEventDestroy(ev.second.second);
       }
       stats->ms_raygen = cat[0]; stats->ms_closest = cat[1]; stats->ms_any = cat[2]; stats->ms_shade = cat[3]; stats->ms_film = cat[4];
-      (void)hipEventDestroy(ev_begin); (void)hipEventDestroy(ev_end);
     }
   }
 
@@ -496,7 +585,7 @@ class Handle : public HandleBase {
   bool deep_ = false, count_traversal_ = false, persistent_ = true;
   bool pairs_ok_ = false;
   uint32_t trav_grid_ = 0, pt_grid_ = 0, rg_grid_ = 0;
-  bool raygen_pt_ = true;
+  int raygen_pt_ = 2;
   bool has_transmissive_ = false, has_translucent_ = false;
   int trav_mode_ = 3;   // 1 = LDS-treelet grid-stride kernel, 2 = persistent-thread kernel, 3 = by queue size
   uint32_t pt_split_closest_ = 100000u, pt_split_any_ = 100000u;   // re-tuned with the shadow launches overlapped (tools/band_scaling.py)
@@ -589,52 +678,6 @@ class Handle : public HandleBase {
   }
   static void xf_nrm(const double* mi, const double* n, double* o) {
     for (int r = 0; r < 3; r++) o[r] = mi[0 * 4 + r] * n[0] + mi[1 * 4 + r] * n[1] + mi[2 * 4 + r] * n[2];
-  }
-
-  // A desc normally comes from rrt_scene_load, but the ABI lets a caller fill one: every index the kernels follow is checked here once
-  // (a kernel reading past an array can take the GPU down for everybody on the host)
-  static void validate_desc(const rrt_scene_desc* d) {
-    auto bad = [](const std::string& what) { throw std::invalid_argument("scene desc: " + what); };
-    if ((d->n_positions && !d->positions) || (d->n_tris && !d->tris) || (d->n_prims && !d->prims) || (d->n_materials && !d->materials) ||
-        (d->n_bvh_nodes && !d->bvh_nodes) || (d->n_prim_order && !d->prim_order) || (d->n_lights && !d->lights) || (d->n_xforms && !d->xforms) ||
-        (d->n_spheres && !d->spheres) || (d->n_textures && !d->textures) || (d->n_images && !d->images) || (d->n_image_texels && !d->image_texels))
-      bad("null array with a non-zero count");
-    for (size_t i = 0; i < d->n_tris; i++) {
-      const rrt_tri& t = d->tris[i];
-      for (int k = 0; k < 3; k++) {
-        if (t.v[k] >= d->n_positions) bad("triangle vertex index out of range");
-        if (t.mesh_has_n && t.n[k] >= d->n_normals) bad("triangle normal index out of range");
-        if (t.mesh_has_uv && t.uv[k] >= d->n_uvs) bad("triangle uv index out of range");
-      }
-    }
-    for (size_t i = 0; i < d->n_spheres; i++)
-      if (d->spheres[i].xform < 0 || (size_t)d->spheres[i].xform >= d->n_xforms) bad("sphere transform index out of range");
-    for (size_t i = 0; i < d->n_prims; i++) {
-      const rrt_prim& p = d->prims[i];
-      if (p.type != RRT_PRIM_TRIANGLE && p.type != RRT_PRIM_SPHERE) bad("unknown primitive type");
-      if (p.shape >= (p.type == RRT_PRIM_TRIANGLE ? d->n_tris : d->n_spheres)) bad("primitive shape index out of range");
-      if (p.instance < -1 || (p.instance >= 0 && (size_t)p.instance >= d->n_xforms)) bad("primitive instance transform out of range");
-      if (p.material >= d->n_materials) bad("primitive material index out of range");
-    }
-    for (size_t i = 0; i < d->n_prim_order; i++) if (d->prim_order[i] >= d->n_prims) bad("prim_order entry out of range");
-    for (size_t i = 0; i < d->n_bvh_nodes; i++) {
-      const rrt_bvh_node& n = d->bvh_nodes[i];
-      if (n.n_primitives > 0) { if ((size_t)n.offset + n.n_primitives > d->n_prim_order) bad("BVH leaf outside prim_order"); }
-      else if (n.offset >= d->n_bvh_nodes || i + 1 >= d->n_bvh_nodes) bad("BVH interior node child out of range");
-      if (n.axis > 2) bad("BVH split axis out of range");
-    }
-    for (size_t i = 0; i < d->n_lights; i++) {
-      const rrt_light& l = d->lights[i];
-      if (l.type < RRT_LIGHT_POINT || l.type > RRT_LIGHT_DISTANT) bad("unknown light type");
-      if (l.type == RRT_LIGHT_DIFFUSE && l.shape >= (l.shape_type == RRT_PRIM_SPHERE ? d->n_spheres : d->n_tris)) bad("area light shape index out of range");
-    }
-    for (size_t i = 0; i < d->n_textures; i++) {
-      const rrt_texture& t = d->textures[i];
-      if (t.type < RRT_TEX_CONSTANT || t.type > RRT_TEX_IMAGE || t.mapping < RRT_MAP_UV || t.mapping > RRT_MAP_IDENTITY3D) bad("unknown texture / mapping type");
-    }
-    if (d->camera.n_elems < 1 || d->camera.n_elems > 64 || !d->camera.elems) bad("camera lens description missing");
-    if (d->film.xres < 1 || d->film.yres < 1) bad("empty film");
-    if (d->sampler.type == RRT_SAMPLER_HALTON && d->sampler.n_perms && !d->sampler.perms) bad("Halton permutation table missing");
   }
 
   void upload_scene(const rrt_scene_desc* d) {
@@ -977,7 +1020,24 @@ class Handle : public HandleBase {
   // camera ray generation: persistent-thread kernel in fp32, two-stage (main trace, compaction, auxiliary traces) in f64
   void launch_raygen(const PassDesc& pd, uint32_t grid, double* dims_out, int enqueue) {
     if constexpr (std::is_same<R, float>::value) {
-      if (raygen_pt_ && scene_.n_lens <= 32 && scene_.sampler_type == RRT_SAMPLER_HALTON && scene_.xres < 65536 && scene_.yres < 65536 && pd.ns <= 65535u) {
+      const bool pt_ok = scene_.n_lens <= 32 && scene_.sampler_type == RRT_SAMPLER_HALTON && scene_.xres < 65536 && scene_.yres < 65536 && pd.ns <= 65535u;
+      if (raygen_pt_ >= 2 && pt_ok) {
+        const uint32_t total = pd.npix * pd.ns;
+        if (pix_off_.n < 2 * (size_t)pd.npix) { HIP_CHECK(hipStreamSynchronize(st_)); pix_off_.alloc(2 * (size_t)pd.npix); }
+        pool_.pix_off = pix_off_.p;
+        const rrt_film& f = desc_.film;
+        const int write_samp = (f.filter_type != RRT_FILTER_BOX || f.filter_radius[0] != 0.5 || f.filter_radius[1] != 0.5) ? 1 : 0;   // only k_film_wide reads p_film
+        hipLaunchKernelGGL(k_pixel_offsets, dim3((pd.npix + kBlock - 1) / kBlock), dim3(kBlock), 0, st_, scene_, pool_, pd);
+        HIP_CHECK(hipMemsetAsync(pool_.weight, 0, (size_t)total * sizeof(R), st_));   // dead samples: weight 0 (Q2), nothing else is written for them
+        {   // dense two-stage version with the lean lens arithmetic
+          hipLaunchKernelGGL(k_raygen_main_f32, dim3((pd.npix + kRgDense - 1) / kRgDense, pd.ns), dim3(kRgDense), 0, st_, scene_, pool_, pd, write_samp, dims_out);
+          hipLaunchKernelGGL(k_raygen_aux2_f32, dim3((total + kRgDense - 1) / kRgDense), dim3(kRgDense), 0, st_, scene_, pool_, enqueue);
+          hipLaunchKernelGGL(k_rotate, dim3(1), dim3(1), 0, st_, counters_.p, 4);   // q_next was only a staging queue
+        }
+        HIP_CHECK(hipGetLastError());
+        return;
+      }
+      if (raygen_pt_ && pt_ok) {
         if (rg_grid_ == 0) {
           int per_cu = 0, cus = 0;
           HIP_CHECK(hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, dev_));

@@ -49,6 +49,81 @@ def test_no_gpu_means_device_error_not_fallback():
         Renderer(sc, 0)
 
 
+def test_create_validates_the_desc_before_touching_a_device(tmp_path):
+    """A caller-filled rrt_scene_desc is checked on the host first - also where no GPU exists: a BVH whose links are not a pre-order tree
+    (a back edge makes a ray walk for ever: a GPU hang) or whose bvh_depth understates the real depth (the traversal stacks are sized
+    from it and written unguarded: a GPU fault) is RRT_EINVAL, never a launch."""
+    from rs_ray_toy_amd import Scene, scenes
+    lib = A.lib()
+    cfg, root = scenes.cfg2(str(tmp_path), xres=16, yres=16, nsamp=3)
+    sc = Scene.loads(cfg, root)
+    d = sc.desc
+    h = C.c_void_p()
+
+    def refused(substr):
+        rc = lib.rrt_create(0, C.byref(d), A.RRT_F32, C.byref(h))
+        assert rc == A.RRT_EINVAL, (rc, lib.rrt_last_error())
+        assert substr in lib.rrt_last_error().decode(), lib.rrt_last_error()
+
+    interior = [i for i in range(d.n_bvh_nodes) if d.bvh_nodes[i].n_primitives == 0]
+    assert len(interior) >= 2 and d.bvh_depth >= 2
+    i = interior[1]
+    off = d.bvh_nodes[i].offset
+    d.bvh_nodes[i].offset = 0                       # back edge to the root
+    refused("back edge")
+    d.bvh_nodes[i].offset = i                       # self reference
+    refused("back edge")
+    d.bvh_nodes[i].offset = i + 1                   # both children the same node: reachable twice
+    refused("back edge")
+    d.bvh_nodes[i].offset = off
+    # a forward link that skips into another subtree: some node becomes reachable twice
+    r0 = d.bvh_nodes[0].offset
+    d.bvh_nodes[0].offset = d.bvh_nodes[interior[1]].offset if interior[1] == 1 else r0
+    if d.bvh_nodes[0].offset != r0:
+        refused("reachable twice")
+    d.bvh_nodes[0].offset = r0
+    depth = d.bvh_depth
+    d.bvh_depth = depth - 1
+    refused("understates")
+    d.bvh_depth = depth
+    rc = lib.rrt_create(0, C.byref(d), A.RRT_F32, C.byref(h))   # restored: only the missing device is left to complain about
+    assert rc == (A.RRT_OK if lib.rrt_device_count() > 0 else A.RRT_EDEVICE), lib.rrt_last_error()
+    if rc == A.RRT_OK:
+        lib.rrt_destroy(h)
+
+
+def test_band_rows_partition_the_film():
+    """rrt_band_rows is the one place the film partition is defined (rrt_render_bands, rrt_film_gather and partition.py use it)."""
+    lib = A.lib()
+    for H, world in ((72, 2), (1024, 8), (50, 3), (16, 4), (1, 1), (2048, 8)):
+        cover = [0] * H
+        for r in range(world):
+            n = lib.rrt_band_rows(H, r, world, None, 0)
+            buf = (C.c_int32 * (2 * max(n, 1)))()
+            assert lib.rrt_band_rows(H, r, world, buf, n) == n
+            for k in range(n):
+                y0, y1 = buf[2 * k], buf[2 * k + 1]
+                assert y0 % 16 == 0 and (y0 // 16) % world == r and 0 < y1 - y0 <= 16
+                for y in range(y0, y1):
+                    cover[y] += 1
+        assert cover == [1] * H
+    assert lib.rrt_band_rows(64, 2, 2, None, 0) == A.RRT_EINVAL
+
+
+def test_collective_entry_points_refuse_bad_arguments():
+    lib = A.lib()
+    c = C.c_void_p()
+    ident = (C.c_uint8 * A.RRT_COMM_ID_BYTES)()
+    assert lib.rrt_comm_create(ident, 2, 2, 0, C.byref(c)) == A.RRT_EINVAL       # rank out of range
+    assert lib.rrt_comm_create(None, 0, 1, 0, C.byref(c)) == A.RRT_EINVAL
+    assert lib.rrt_film_gather(None, None, None, 0) == A.RRT_EINVAL
+    assert lib.rrt_film_gather_all(None, None, 0, 0) == A.RRT_EINVAL
+    assert lib.rrt_comm_id(None) == A.RRT_EINVAL
+    if lib.rrt_device_count() == 0:
+        assert lib.rrt_comm_create(ident, 0, 1, 0, C.byref(c)) == A.RRT_EDEVICE   # no GPU: refused, not emulated
+    lib.rrt_comm_destroy(None)
+
+
 STRUCTS = {"rrt_xform": A.Xform, "rrt_tri": A.Tri, "rrt_sphere": A.Sphere, "rrt_prim": A.Prim, "rrt_material": A.Material, "rrt_texture": A.Texture, "rrt_image": A.Image, "rrt_image_level": A.ImageLevel,
            "rrt_light": A.Light, "rrt_bvh_node": A.BvhNode, "rrt_lens_elem": A.LensElem, "rrt_camera": A.Camera,
            "rrt_film": A.Film, "rrt_sampler": A.Sampler, "rrt_integrator": A.Integrator, "rrt_scene_desc": A.SceneDesc,

@@ -20,7 +20,7 @@ def _worker(rank, world, port, workdir, out):
     os.environ["MASTER_PORT"] = str(port)
     import oracle_lib as O
     from rs_ray_toy_amd import Scene, scenes
-    from rs_ray_toy_amd.partition import band_rects, reduce_film
+    from rs_ray_toy_amd.partition import band_rects, gather_film, reduce_film
     dist.init_process_group("gloo", rank=rank, world_size=world)
     cfg, root = scenes.cfg2(os.path.join(workdir, f"r{rank}"), xres=64, yres=72, nsamp=4)
     sc = Scene.loads(cfg, root)
@@ -29,11 +29,14 @@ def _worker(rank, world, port, workdir, out):
     rects = band_rects(W, H, rank, world)
     for rect in rects:
         film += O.render(sc, rect, n_threads=2)
-    t = torch.from_numpy(film)
+    t = torch.from_numpy(film.copy())
     reduce_film(t, world)
+    # the gather form of the same exchange (what rrt_film_gather does over RCCL for the box filter): only band rows travel
+    g = torch.from_numpy(film.copy())
+    gather_film(g, world)
     if rank == 0:
         full = O.render(sc, n_threads=2)
-        np.save(out, np.stack([t.numpy(), full]))
+        np.save(out, np.stack([t.numpy(), full, g.numpy()]))
     dist.barrier()
     dist.destroy_process_group()
 
@@ -56,6 +59,7 @@ def test_two_rank_gloo_reduce_reassembles_the_frame(tmp_path):
     s = socket.socket(); s.bind(("127.0.0.1", 0)); port = s.getsockname()[1]; s.close()
     out = str(tmp_path / "films.npy")
     mp.spawn(_worker, args=(2, port, str(tmp_path), out), nprocs=2, join=True)
-    got, full = np.load(out)
+    got, full, gathered = np.load(out)
     assert full[..., :3].max() > 0
     assert np.array_equal(got, full)      # bands are disjoint: the reduce is exact
+    assert np.array_equal(gathered, full)  # and so is the gather of the band rows alone

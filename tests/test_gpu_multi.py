@@ -1,0 +1,111 @@
+"""Multi-rank path on the real device code, the C-ABI collective, and the native command line (`-m gpu`).
+
+A one-GPU box cannot run RCCL between two ranks (one rank per device), so the two-rank test exchanges the films over gloo while both
+ranks render their bands with the HIP kernels on GPU 0 - each in its own fresh process with its own handle - and the RCCL entry
+points are driven with a one-rank communicator (ncclCommInitRank / ncclReduce / group of zero sends really execute)."""
+import os
+import socket
+import subprocess
+import sys
+
+import numpy as np
+import pytest
+import torch
+import torch.distributed as dist
+import torch.multiprocessing as mp
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+pytestmark = pytest.mark.gpu
+
+
+def _worker(rank, world, port, workdir, out, filt):
+    sys.path.insert(0, ROOT)
+    os.environ["MASTER_ADDR"] = "127.0.0.1"
+    os.environ["MASTER_PORT"] = str(port)
+    from rs_ray_toy_amd import RRT_F32, Renderer, Scene, scenes
+    from rs_ray_toy_amd.partition import gather_film, reduce_film
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    cfg, root = scenes.cfg2(os.path.join(workdir, f"r{rank}"), xres=96, yres=80, nsamp=9, max_depth=3)
+    if filt:
+        cfg["Film"]["Filter"] = filt
+    sc = Scene.loads(cfg, root)
+    W, H = sc.resolution
+    r = Renderer(sc, 0, RRT_F32)            # created after the spawn: this process's own HIP context, streams and pools
+    film = torch.zeros((H, W, 4), dtype=torch.float32, device="cuda:0")
+    r.render_bands_device(rank, world, film.data_ptr(), stats=False)
+    torch.cuda.synchronize()
+    mine = film.clone()
+    reduce_film(film, world)                # sum on rank 0 (any filter)
+    res = [film.cpu().numpy()]
+    if not filt:                            # box filter: the gather form (what rrt_film_gather sends over RCCL)
+        g = gather_film(mine, world)
+        res.append(g.cpu().numpy())
+    if rank == 0:
+        full = r.render()                   # the single-process frame on the same device code
+        np.save(out, np.stack(res + [full]))
+    r.close()
+    dist.barrier()
+    dist.destroy_process_group()
+
+
+@pytest.mark.parametrize("filt", [None, {"filter_type": "TriangleFilter", "radius": [2.0, 2.0]}], ids=["box", "triangle"])
+def test_two_ranks_render_their_bands_on_the_device_and_reassemble(tmp_path, filt):
+    s = socket.socket(); s.bind(("127.0.0.1", 0)); port = s.getsockname()[1]; s.close()
+    out = str(tmp_path / "films.npy")
+    mp.spawn(_worker, args=(2, port, str(tmp_path), out, filt), nprocs=2, join=True)
+    films = np.load(out)
+    full = films[-1]
+    assert full[..., :3].max() > 0
+    if filt is None:
+        assert np.array_equal(films[0], full) and np.array_equal(films[1], full)   # disjoint bands: bit for bit
+    else:
+        # splats cross band borders: a border pixel's sum is split over two ranks, i.e. added in a different order
+        assert np.array_equal(films[0][..., 3], full[..., 3])
+        np.testing.assert_allclose(films[0], full, rtol=2e-6, atol=1e-7 * full.max())
+
+
+def test_rccl_collective_through_the_c_abi(workdir):
+    """rrt_comm_* / rrt_film_gather / rrt_film_gather_all with the one rank a one-GPU box allows: the communicator is a real RCCL one
+    and the wide-filter form runs a real ncclReduce on the handle's stream; the film must come back unchanged."""
+    from rs_ray_toy_amd import RRT_F32, Renderer, Scene, scenes
+    from rs_ray_toy_amd.api import Comm
+    import ctypes as C
+    from rs_ray_toy_amd import _abi as A
+    for filt in (None, {"filter_type": "GaussianFilter", "radius": [1.5, 1.5], "alpha": 2.0}):
+        cfg, root = scenes.cfg2(workdir, xres=64, yres=48, nsamp=5, max_depth=2)
+        if filt:
+            cfg["Film"]["Filter"] = filt
+        sc = Scene.loads(cfg, root)
+        W, H = sc.resolution
+        r = Renderer(sc, 0, RRT_F32)
+        film = torch.zeros((H, W, 4), dtype=torch.float32, device="cuda:0")
+        torch.cuda.synchronize()
+        comm = Comm(Comm.new_id(), 0, 1, 0)
+        r.render_bands_begin(0, 1, film.data_ptr())
+        comm.gather(r, film.data_ptr(), 0)
+        r.render_end()
+        ref = r.render()
+        assert np.array_equal(film.cpu().numpy(), ref)
+        handles = (C.c_void_p * 1)(r._h)
+        films = (C.c_void_p * 1)(film.data_ptr())
+        assert A.lib().rrt_film_gather_all(handles, films, 1, 0) == A.RRT_OK, A.lib().rrt_last_error()
+        torch.cuda.synchronize()
+        assert np.array_equal(film.cpu().numpy(), ref)
+        comm.close()
+        r.close()
+
+
+def test_native_command_line_matches_the_python_host(tmp_path):
+    """rrt_render <scene.json> <out.png> (main.rs:55-61 / deploy_render renderprocess.rs:92-105 in C++ over the C ABI) writes the very
+    PNG the Python mirror writes, for the reference's own samples/scene.json (StratifiedSampler, Debug integrator, 640x360)."""
+    from rs_ray_toy_amd import deploy_render
+    exe = os.path.join(ROOT, "rs_ray_toy_amd", "csrc", "rrt_render")
+    scene = os.path.join(ROOT, "tests", "golden", "scene.json")
+    a, b = str(tmp_path / "cli.png"), str(tmp_path / "py.png")
+    p = subprocess.run([exe, scene, a], capture_output=True, text=True, timeout=600)
+    assert p.returncode == 0, p.stderr
+    deploy_render(scene, b)
+    assert open(a, "rb").read() == open(b, "rb").read()
+    assert subprocess.run([exe, scene], capture_output=True).returncode == 2          # usage
+    q = subprocess.run([exe, str(tmp_path / "missing.json"), a], capture_output=True, text=True)
+    assert q.returncode == 1 and "cannot open" in q.stderr
