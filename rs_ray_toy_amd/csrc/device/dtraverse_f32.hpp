@@ -716,14 +716,23 @@ RRT_DEV float rg_begin_lean(const SceneDev<float>& s, float pfx, float pfy, floa
 
 // One interface of trace_lenses_from_film (camera.rs:163-211) for an interface index that is uniform across the wave (the dense
 // kernels step all lanes together): the element is a scalar operand and stop-vs-sphere is a scalar branch. Returns false = blocked.
-RRT_DEV bool rg_step_lean(const float4 el, const float2 el2, RgLane* L) {
+// `safe` (optional): cleared unless this interface is passed with the margin within which an auxiliary ray (0.05 px beside this one)
+// cannot be blocked either: radius below aperture - 16 c_i m (safe_lim = {aperture, 16 c_i}, m = the sample's displacement scale),
+// parameter t above 4 x that margin, away from grazing incidence and from total internal reflection (rrt_impl.hpp
+// calibrate_aux_margins()).
+RRT_DEV bool rg_step_lean(const float4 el, const float2 el2, RgLane* L, const float2 safe_lim = make_float2(0.0f, 0.0f), float m = 0.0f, bool* safe = nullptr) {
   L->element_z -= el.y;
   const V3<float> o = L->o, d = L->d;
   if (el.x == 0.0f) {   // aperture stop
     const float t = (L->element_z - o.z) * __builtin_amdgcn_rcpf(d.z);
     const V3<float> p_hit = o + d * t;
     L->o = p_hit;
-    return (d.z < 0.0f) & (t >= 0.0f) & (p_hit.x * p_hit.x + p_hit.y * p_hit.y < el.w);
+    const float r2 = p_hit.x * p_hit.x + p_hit.y * p_hit.y;
+    if (safe) {
+      const float margin = safe_lim.y * m, rl = fmaxf(safe_lim.x - margin, 0.0f);
+      *safe &= (safe_lim.y > 0.0f) & (d.z < -0.05f) & (t > 4.0f * margin) & (r2 < rl * rl);
+    }
+    return (d.z < 0.0f) & (t >= 0.0f) & (r2 < el.w);
   }
   // intersect_spherical_element camera.rs:220-253 + quadratic misc.rs:231-251
   const V3<float> oc(o.x, o.y, o.z - (L->element_z + el.x));
@@ -738,7 +747,8 @@ RRT_DEV bool rg_step_lean(const float4 el, const float2 el2, RgLane* L) {
   const float t = use_closer ? fminf(t0, t1) : fmaxf(t0, t1);
   bool ok = (disc >= 0.0f) & (t >= 0.0f);   // (a NaN t fails `t >= 0` like the reference's `t < 0` / assert pair)
   const V3<float> p_hit = o + d * t;
-  ok &= p_hit.x * p_hit.x + p_hit.y * p_hit.y < el.w;
+  const float r2 = p_hit.x * p_hit.x + p_hit.y * p_hit.y;
+  ok &= r2 < el.w;
   L->o = p_hit;
   V3<float> n = (oc + d * t) * el2.x;
   const V3<float> wi = d * -__builtin_amdgcn_rsqf(a);
@@ -748,6 +758,10 @@ RRT_DEV bool rg_step_lean(const float4 el, const float2 el2, RgLane* L) {
   const float eta = el.z;
   const float sin2_t = eta * eta * fmaxf(0.0f, 1.0f - cos_i * cos_i);   // refract reflection.rs:122-134
   ok &= sin2_t < 1.0f;
+  if (safe) {
+    const float margin = safe_lim.y * m, rl = fmaxf(safe_lim.x - margin, 0.0f);
+    *safe &= (safe_lim.y > 0.0f) & (r2 < rl * rl) & (t > 4.0f * margin) & (cos_i > 0.15f) & (sin2_t < 0.98f);
+  }
   const float cos_t = __builtin_amdgcn_sqrtf(1.0f - sin2_t);
   L->d = wi * -eta + n * (eta * cos_i - cos_t);
   return ok;
@@ -771,11 +785,14 @@ constexpr int kRgDense = 1024;
 
 // staging records live in the next-queue arrays, which are free until the first shading launch:
 //   nray_o[i] = {o.xyz (world), slot}, nray_d[i] = {d.xyz (world), weight}, npath[i] = {p_film.xy, p_lens.xy}, hindex[i] = Halton index
-static __global__ void __launch_bounds__(kRgDense) k_raygen_main_f32(SceneDev<float> s, Pools<float> p, PassDesc pd, int write_samp, double* dims_out) {
+static __global__ void __launch_bounds__(kRgDense) k_raygen_main_f32(SceneDev<float> s, Pools<float> p, PassDesc pd, int write_samp, double* dims_out,
+                                                                     const float2* safe_lim, float aux_delta, float aux_pupil, int enqueue) {
   __shared__ RgLensLds lens;
+  __shared__ float2 safe_s[32];
   __shared__ uint32_t push_lds[kRgDense / 64 + 1];
   const uint32_t tid = threadIdx.x;
   rg_lens_to_lds(s, &lens, tid);
+  if (tid < (uint32_t)s.n_lens) safe_s[tid] = safe_lim ? safe_lim[tid] : make_float2(0.0f, 0.0f);   // 16 c_i = 0: never safe
   __syncthreads();
   const uint32_t pl = blockIdx.x * blockDim.x + tid, sl = blockIdx.y;
   bool alive = false;
@@ -795,20 +812,39 @@ static __global__ void __launch_bounds__(kRgDense) k_raygen_main_f32(SceneDev<fl
     w = rg_begin_lean(s, pfx, pfy, lx, ly, &L);
     alive = w != 0.0f;
   }
+  // the sample's displacement scale m = delta (1 + P / r_film) (calibrate_aux_margins()); the film point is the lens-space origin
+  const float r_film = __builtin_amdgcn_sqrtf(L.o.x * L.o.x + L.o.y * L.o.y);
+  const float m_scale = aux_delta * (1.0f + aux_pupil * __builtin_amdgcn_rcpf(r_film));
+  bool safe = safe_lim != nullptr && r_film > 0.0f;
   for (int k = s.n_lens - 1; k >= 0; k--) {   // (no lane-divergent branch inside: dead lanes ride along)
     if (__ballot(alive) == 0ull) break;
-    alive &= rg_step_lean(lens.a[k], lens.b[k], &L);
+    alive &= rg_step_lean(lens.a[k], lens.b[k], &L, safe_s[k], m_scale, &safe);
   }
-  const uint32_t q = block_push(&p.counters[C_NEXT], alive, push_lds);
+  // survivors whose auxiliary rays cannot be blocked are done: straight to q_active; the others wait in the staging queue for stage B
+  const bool done = alive & safe, staged = alive & !safe;
+  const uint32_t qa = block_push(&p.counters[C_ACTIVE], done && enqueue, push_lds);
+  const uint32_t qs = block_push(&p.counters[C_NEXT], staged, push_lds);
+  (void)block_push(&p.counters[C_CAMERA_RAYS], done, push_lds);
   if (alive) {
     // ray out of the lens = flip_z, camera_to_world, normalise (camera.rs:558-565)
     const V3<float> wo = aff_pt(s.cam_m, V3<float>(L.o.x, L.o.y, -L.o.z));
     const V3<float> wdu = aff_vec(s.cam_m, V3<float>(L.d.x, L.d.y, -L.d.z));
     const V3<float> wd = wdu * __builtin_amdgcn_rsqf(len2(wdu));
-    p.nray_o[q] = make_float4(wo.x, wo.y, wo.z, __uint_as_float(slot));
-    p.nray_d[q] = make_float4(wd.x, wd.y, wd.z, w);
-    p.npath[q] = make_float4(pfx, pfy, lx, ly);
-    p.hindex[q] = index;
+    if (staged) {
+      p.nray_o[qs] = make_float4(wo.x, wo.y, wo.z, __uint_as_float(slot));
+      p.nray_d[qs] = make_float4(wd.x, wd.y, wd.z, w);
+      p.npath[qs] = make_float4(pfx, pfy, lx, ly);
+      p.hindex[qs] = index;
+    } else {
+      if (enqueue) {
+        p.q_active[qa] = QEnt{slot, 5u, index, 0u};          // five camera dimensions consumed, bounce 0
+        p.path[qa] = make_float4(1.0f, 1.0f, 1.0f, 1.0f);    // beta, eta_scale
+        p.ray_o[qa] = make_float4(wo.x, wo.y, wo.z, Const<float>::inf);
+        p.ray_d[qa] = make_float4(wd.x, wd.y, wd.z, __uint_as_float(0xffffffffu));
+      }
+      p.L[slot] = make_float4(0.0f, 0.0f, 0.0f, 0.0f);
+      p.weight[slot] = w;
+    }
   }
 }
 

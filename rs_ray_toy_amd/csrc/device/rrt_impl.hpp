@@ -116,6 +116,120 @@ inline std::vector<uint32_t> plane_ids(const std::vector<double>& w, size_t n, c
   return ids;
 }
 
+// ---- auxiliary-ray margins of the fp32 camera kernels ---------------------------------------------------------------------
+// generate_ray_differential (camera.rs:582-628) traces the camera ray again from p_film +- 0.05 px (same lens sample); on scenes
+// without textures all those 2-4 traces decide is whether the sample keeps its weight. The auxiliary ray runs beside the main ray:
+// it can only be blocked where the main ray passed an aperture / an element's rim / the critical angle by about their distance.
+// That distance has two parts, both proportional to the film shift delta = 0.05 px: the ray starts delta away, and the exit-pupil
+// sample is rotated to the film point's polar angle (camera.rs:505-513), which turns by delta / r_film and moves the rear point by up
+// to P * delta / r_film (P = pupil extent). So per sample the scale is m = delta * (1 + P / r_film), and per interface the
+// amplification c_i = displacement / m is MEASURED on the host (f64, the reference's operation order, 16 384 random camera samples x 4
+// shifts). A main ray that clears every interface by 16 c_i m is declared safe and its auxiliary traces are not run; every other
+// survivor gets the full traces. tests/test_gpu_parity.py::test_aux_margins_change_nothing renders frames with and without the
+// shortcut: identical bit for bit.
+struct AuxMargins { std::vector<float> lim; float delta = 0.0f, pupil = 0.0f; };   // lim: per interface {aperture radius, 16 c_i}, interleaved; 16 c_i = 0: never safe
+inline AuxMargins calibrate_aux_margins(const rrt_scene_desc* d) {
+  const int n = d->camera.n_elems;
+  AuxMargins out;
+  out.lim.assign(2 * (size_t)n, 0.0f);
+  struct V { double x, y, z; };
+  auto nrm = [](V v) { const double l = std::sqrt(v.x * v.x + v.y * v.y + v.z * v.z); return l == 0.0 ? v : V{v.x / l, v.y / l, v.z / l}; };
+  const rrt_lens_elem* e = d->camera.elems;
+  const rrt_film& f = d->film;
+  // one trace, recording the xy hit point at every interface reached; returns the number of interfaces passed
+  auto trace = [&](double pfx, double pfy, double lx, double ly, std::vector<double>& hx, std::vector<double>& hy) -> int {
+    const double sx = pfx / (double)f.xres, sy = pfy / (double)f.yres;
+    const double p2x = f.physical_extent[0] * (1.0 - sx) + f.physical_extent[2] * sx, p2y = f.physical_extent[1] * (1.0 - sy) + f.physical_extent[3] * sy;
+    const V pf{-p2x, p2y, 0.0};
+    const double r_film = std::sqrt(pf.x * pf.x + pf.y * pf.y);
+    const double* pb = (r_film / (f.diagonal / 2.0) >= 1.0) ? d->camera.exit_pupil_bounds[63] : d->camera.exit_pupil_bounds[0];
+    const double plx = pb[0] * (1.0 - lx) + pb[2] * lx, ply = pb[1] * (1.0 - ly) + pb[3] * ly;
+    const double sin_t = r_film != 0.0 ? pf.y / r_film : 0.0, cos_t = r_film != 0.0 ? pf.x / r_film : 1.0;
+    const V rear{cos_t * plx - sin_t * ply, sin_t * plx + cos_t * ply, e[n - 1].thickness};
+    V o{pf.x, pf.y, 0.0};
+    V dir = nrm(V{rear.x - pf.x, rear.y - pf.y, rear.z - pf.z});
+    dir.z = -dir.z;   // flip_z
+    double element_z = 0.0;
+    int passed = 0;
+    for (int i = n - 1; i >= 0; i--) {
+      element_z -= e[i].thickness;
+      double t;
+      V nn{0, 0, 0};
+      const bool is_stop = e[i].curvature_radius == 0.0;
+      if (is_stop) {
+        if (dir.z >= 0.0) return passed;
+        t = (element_z - o.z) / dir.z;
+      } else {
+        const double radius = e[i].curvature_radius, zc = element_z + radius;
+        const V oc{o.x, o.y, o.z - zc};
+        const double a = dir.x * dir.x + dir.y * dir.y + dir.z * dir.z, b = 2.0 * (dir.x * oc.x + dir.y * oc.y + dir.z * oc.z), c = oc.x * oc.x + oc.y * oc.y + oc.z * oc.z - radius * radius;
+        const double disc = b * b - 4.0 * a * c;
+        if (disc < 0.0) return passed;
+        const double root = std::sqrt(disc), q = b < 0.0 ? -0.5 * (b - root) : -0.5 * (b + root);
+        const double t0 = q / a, t1 = c / q;
+        const bool use_closer = (dir.z > 0.0) ^ (radius < 0.0);
+        t = use_closer ? std::fmin(t0, t1) : std::fmax(t0, t1);
+        if (t < 0.0) return passed;
+        nn = nrm(V{oc.x + dir.x * t, oc.y + dir.y * t, oc.z + dir.z * t});
+        if (nn.x * -dir.x + nn.y * -dir.y + nn.z * -dir.z < 0.0) nn = V{-nn.x, -nn.y, -nn.z};
+      }
+      if (!(t >= 0.0)) return passed;
+      const V ph{o.x + dir.x * t, o.y + dir.y * t, o.z + dir.z * t};
+      if (ph.x * ph.x + ph.y * ph.y >= e[i].aperture_radius * e[i].aperture_radius) return passed;
+      hx[i] = ph.x; hy[i] = ph.y;
+      o = ph;
+      if (!is_stop) {
+        const double eta_t = (i > 0 && e[i - 1].eta != 0.0) ? e[i - 1].eta : 1.0, eta = e[i].eta / eta_t;
+        const V wi = nrm(V{-dir.x, -dir.y, -dir.z});
+        const double cos_i = nn.x * wi.x + nn.y * wi.y + nn.z * wi.z, sin2_t = eta * eta * std::fmax(0.0, 1.0 - cos_i * cos_i);
+        if (sin2_t >= 1.0) return passed;
+        const double cos_tt = std::sqrt(1.0 - sin2_t), k = eta * cos_i - cos_tt;
+        dir = V{-wi.x * eta + nn.x * k, -wi.y * eta + nn.y * k, -wi.z * eta + nn.z * k};
+      }
+      passed++;
+    }
+    return passed;
+  };
+  // film shift of 0.05 px in metres (the larger pixel pitch), pupil extent
+  const double pitch_x = std::fabs(f.physical_extent[2] - f.physical_extent[0]) / (double)f.xres, pitch_y = std::fabs(f.physical_extent[3] - f.physical_extent[1]) / (double)f.yres;
+  const double delta = 0.05 * std::max(pitch_x, pitch_y);
+  double pupil = 0.0;
+  for (int b : {0, 63}) for (int k = 0; k < 4; k++) pupil = std::max(pupil, std::fabs(d->camera.exit_pupil_bounds[b][k]));
+  pupil *= 1.5 * std::sqrt(2.0);   // lens samples reach 1.5 x the box (Q5), corner distance
+  out.delta = (float)delta; out.pupil = (float)pupil;
+  std::vector<double> disp((size_t)n, 0.0), mx(n), my(n), ax(n), ay(n);
+  std::vector<uint32_t> support((size_t)n, 0u);
+  uint64_t st = 0x9E3779B97F4A7C15ull;
+  auto rnd = [&]() { st ^= st << 13; st ^= st >> 7; st ^= st << 17; return (double)(st >> 11) * (1.0 / 9007199254740992.0); };
+  const int kSamples = 16384;
+  for (int k = 0; k < kSamples; k++) {
+    const double pfx = rnd() * f.xres, pfy = rnd() * f.yres, lx = 0.5 + rnd(), ly = 0.5 + rnd();   // p_lens in [0.5, 1.5) (Q5)
+    if (trace(pfx, pfy, lx, ly, mx, my) != n) continue;
+    double r_film;
+    {
+      const double sx = pfx / (double)f.xres, sy = pfy / (double)f.yres;
+      const double p2x = f.physical_extent[0] * (1.0 - sx) + f.physical_extent[2] * sx, p2y = f.physical_extent[1] * (1.0 - sy) + f.physical_extent[3] * sy;
+      r_film = std::sqrt(p2x * p2x + p2y * p2y);
+    }
+    if (!(r_film > 0.0)) continue;
+    const double m = delta * (1.0 + pupil / r_film);
+    const double sh[4][2] = {{0.05, 0.0}, {-0.05, 0.0}, {0.0, 0.05}, {0.0, -0.05}};
+    for (int j = 0; j < 4; j++) {
+      const int got = trace(pfx + sh[j][0], pfy + sh[j][1], lx, ly, ax, ay);
+      for (int i = n - 1, c = 0; i >= 0 && c < got; i--, c++) {
+        disp[i] = std::max(disp[i], std::hypot(ax[i] - mx[i], ay[i] - my[i]) / m);   // amplification c_i
+        support[i]++;
+      }
+    }
+  }
+  for (int i = 0; i < n; i++) {
+    if (support[i] < 1000u) continue;   // too few rays got through this lens to say anything: no shortcut
+    out.lim[2 * i] = (float)(e[i].aperture_radius * (1.0 - 1e-6));
+    out.lim[2 * i + 1] = (float)(16.0 * std::max(disp[i], 0.25));
+  }
+  return out;
+}
+
 // A desc normally comes from rrt_scene_load, but the ABI lets a caller fill one: every index the kernels follow is checked here once
 // (a kernel reading past an array can take the GPU down for everybody on the host)
 inline void validate_desc(const rrt_scene_desc* d) {
@@ -234,6 +348,7 @@ class Handle : public HandleBase {
     else if (key == "pt_split_closest") pt_split_closest_ = (uint32_t)v;
     else if (key == "pt_split_any") pt_split_any_ = (uint32_t)v;
     else if (key == "overlap_shadow") overlap_shadow_ = v != 0;
+    else if (key == "aux_margin") aux_margin_ = v != 0;
     else if (key == "nonblocking_streams") {   // see rrt.h: needed for two handles to overlap their frames
       if (pending_) throw std::invalid_argument("nonblocking_streams: a frame is in flight");
       HIP_CHECK(hipSetDevice(dev_));
@@ -606,6 +721,9 @@ class Handle : public HandleBase {
   DevBuf<Light<R>> lights_;
   DevBuf<R> light_cdf_;
   DevBuf<LensElem<R>> lens_;
+  DevBuf<float> lens_safe_;   // calibrate_aux_margins(): per interface, the squared radius inside which an auxiliary ray cannot be blocked (fp32 camera kernels)
+  bool aux_margin_ = true;
+  float aux_delta_ = 0.0f, aux_pupil_ = 0.0f;
   DevBuf<R> filter_table_;
   DevBuf<HaltonDim> hdims_;
   DevBuf<uint16_t> perms_;
@@ -891,6 +1009,7 @@ class Handle : public HandleBase {
     nodes_.upload(nodes, st_); tris_.upload(tris, st_); build_pairs(nodes, tris.size()); shades_.upload(shades, st_); spheres_.upload(spheres, st_);
     materials_.upload(mats, st_); textures_.upload(texs, st_); images_.upload(imgs, st_); image_texels_.upload(texels, st_);
     if (!spheres.empty()) pairs_ok_ = false;   // the fp32 pair-node kernels are triangle-only: sphere scenes use the generic kernels
+    { const AuxMargins am = calibrate_aux_margins(d); lens_safe_.upload(am.lim, st_); aux_delta_ = am.delta; aux_pupil_ = am.pupil; }
     lights_.upload(lights, st_); light_cdf_.upload(cdf_r, st_); lens_.upload(lens, st_); hdims_.upload(hd, st_); perms_.upload(perms, st_);
     HIP_CHECK(hipStreamSynchronize(st_));  // host vectors go out of scope below
 
@@ -1030,7 +1149,8 @@ class Handle : public HandleBase {
         hipLaunchKernelGGL(k_pixel_offsets, dim3((pd.npix + kBlock - 1) / kBlock), dim3(kBlock), 0, st_, scene_, pool_, pd);
         HIP_CHECK(hipMemsetAsync(pool_.weight, 0, (size_t)total * sizeof(R), st_));   // dead samples: weight 0 (Q2), nothing else is written for them
         {   // dense two-stage version with the lean lens arithmetic
-          hipLaunchKernelGGL(k_raygen_main_f32, dim3((pd.npix + kRgDense - 1) / kRgDense, pd.ns), dim3(kRgDense), 0, st_, scene_, pool_, pd, write_samp, dims_out);
+          const float2* safe_r2 = (aux_margin_ && tex_depth_ == 0) ? reinterpret_cast<const float2*>(lens_safe_.p) : nullptr;   // textured scenes keep the auxiliary rays themselves (ray differentials)
+          hipLaunchKernelGGL(k_raygen_main_f32, dim3((pd.npix + kRgDense - 1) / kRgDense, pd.ns), dim3(kRgDense), 0, st_, scene_, pool_, pd, write_samp, dims_out, safe_r2, aux_delta_, aux_pupil_, enqueue);
           hipLaunchKernelGGL(k_raygen_aux2_f32, dim3((total + kRgDense - 1) / kRgDense), dim3(kRgDense), 0, st_, scene_, pool_, enqueue);
           hipLaunchKernelGGL(k_rotate, dim3(1), dim3(1), 0, st_, counters_.p, 4);   // q_next was only a staging queue
         }

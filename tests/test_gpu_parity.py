@@ -173,9 +173,13 @@ RENDER_CASES = {
     "cfg4_distant": _cfg4_distant,
     "cfg2_path": lambda wd: scenes.cfg2(wd, xres=96, yres=96, nsamp=9, max_depth=4),
     "cfg3_path": lambda wd: _cfg3_tilted(wd),
+    "cfg3_literal": lambda wd: scenes.cfg3(wd, xres=96, yres=96, nsamp=9),   # BASELINE config 3 as scenes.cfg3() defines it (axis-aligned box: ties)
     "cfg4_path": lambda wd: scenes.cfg4(wd, xres=64, yres=64, nsamp=5, max_depth=8, n=48),
     "cfg5_path": lambda wd: scenes.cfg5(wd, xres=64, yres=64, nsamp=9, max_depth=16, n=48),
 }
+
+
+TIE_PRONE = ("cfg2_path", "cfg3_literal")
 
 
 @pytest.mark.parametrize("case", sorted(RENDER_CASES))
@@ -192,7 +196,7 @@ def test_render_f64_matches_oracle(case, workdir):
     diff = np.abs(film[..., :3] - ref[..., :3]).max(-1) / np.abs(ref[..., :3]).max()
     # f64 device mode: same formulas and operation order; libm vs device sin/cos/log may differ in the last
     # ulp. Bar: 1e-9 of the brightest pixel (a flipped discrete decision shows up as >= 1e-3).
-    if case == "cfg2_path":
+    if case in TIE_PRONE:
         # tie-prone geometry (axis-aligned faces coplanar with flat leaf boxes): a last-ulp difference in a
         # sampled direction can break such a tie the other way; at most 0.5 % of pixels may carry one
         assert (diff > 1e-9).mean() < 0.005, (diff > 1e-9).mean()
@@ -215,7 +219,7 @@ def test_render_f32_close_to_oracle(case, workdir):
     # brightest pixel's value (observed <= 1.1e-5). cfg2's cubes have axis-aligned faces coplanar with flat leaf
     # boxes, i.e. exact ties that any change of rounding breaks differently (the oracle's own two evaluation
     # orders differ on 0.4 % of its pixels): there 98.5 % of pixels must be within 1e-3.
-    if case == "cfg2_path":
+    if case in TIE_PRONE:
         assert (diff < 1e-3).mean() > 0.985, (diff < 1e-3).mean()
         assert np.median(diff) < 1e-5
     else:
@@ -355,6 +359,10 @@ def test_full_size_frame_properties(workdir):
     assert np.isfinite(film).all() and film[..., :3].max() > 0
     again = r.render()
     assert np.array_equal(again, film)
+    r.set_option("aux_margin", 0)   # every auxiliary lens trace run (test_aux_margins_change_nothing): the same 268 M decisions
+    full_aux, st_aux = r.render(stats=True)
+    r.set_option("aux_margin", 1)
+    assert st_aux.camera_rays == st.camera_rays and np.array_equal(full_aux, film)
     bands = r.render_bands(0, 2)
     r.render_bands(1, 2, film=bands)
     assert np.array_equal(bands, film)
@@ -381,6 +389,39 @@ def test_full_size_frame_properties(workdir):
     assert (diff < 1e-4).mean() > 0.975, (diff < 1e-4).mean()
     assert diff.max() < 3e-2, diff.max()
     assert diff.mean() < 1e-4, diff.mean()
+
+
+AUX_CASES = {
+    "cfg2_640x360": lambda wd: scenes.cfg2(wd, xres=640, yres=360, nsamp=9, max_depth=2),
+    "cfg2_tiny_film": lambda wd: scenes.cfg2(wd, xres=24, yres=16, nsamp=65, max_depth=2),     # 0.05 px is 70 um of film here
+    "cfg4_1024": lambda wd: scenes.cfg4(wd, xres=1024, yres=1024, nsamp=5, max_depth=2, n=40),
+    "cfg3_wide_filter": lambda wd: (lambda c: (c[0]["Film"].__setitem__("Filter", {"filter_type": "TriangleFilter", "radius": [2.0, 2.0]}), c)[1])(
+        scenes.cfg3(wd, xres=200, yres=120, nsamp=9)),
+}
+
+
+@pytest.mark.parametrize("which", sorted(AUX_CASES))
+def test_aux_margins_change_nothing(which, workdir):
+    """The fp32 camera kernels do not trace the auxiliary rays of generate_ray_differential (camera.rs:582-628) for a main ray that
+    clears every lens interface by 16x the measured displacement of an auxiliary ray (rrt_impl.hpp calibrate_aux_margins()); all
+    they decide on untextured scenes is whether the sample keeps its weight. Bar: with and without the shortcut every sample has
+    the same weight and the frames are identical bit for bit - and the shortcut must actually be taken for most survivors."""
+    cfg, root = AUX_CASES[which](workdir)
+    sc = Scene.loads(cfg, root, flags=RRT_FIXED_BVH)
+    W, H = sc.resolution
+    r = Renderer(sc, 0, RRT_F32)
+    film_on, st_on = r.render(stats=True)
+    rect = (0, 0, min(W, 256), min(H, 128))
+    ns = int(sc.desc.sampler.samples_per_pixel)
+    _, rays_on, w_on = r.camera_samples(rect, 1, min(ns, 9))
+    r.set_option("aux_margin", 0)
+    film_off, st_off = r.render(stats=True)
+    _, rays_off, w_off = r.camera_samples(rect, 1, min(ns, 9))
+    r.close()
+    assert st_on.camera_rays == st_off.camera_rays and st_on.camera_rays > 0
+    assert np.array_equal(w_on, w_off) and np.array_equal(rays_on, rays_off)
+    assert np.array_equal(film_on, film_off)
+    assert film_on[..., :3].max() > 0
 
 
 WIDE_FILTERS = {
