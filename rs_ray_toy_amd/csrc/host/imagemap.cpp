@@ -70,6 +70,9 @@ int decode_png_rgb8(const std::string& path, uint32_t* w, uint32_t* h, std::vect
     pos += 12 + (size_t)len;
   }
   if (!seen_ihdr || !seen_iend || width == 0 || height == 0) { *why = "missing IHDR / IEND"; return 1; }
+  // IHDR is file content: 2^32 - 1 squared wraps the buffer sizes below and a crafted file would index past them (or ask for
+  // terabytes). 65 536 texels per side is far beyond any texture the scene format is used with.
+  if (width > 65536u || height > 65536u) { *why = "image larger than 65536 x 65536"; return 2; }
   int channels;
   switch (ctype) {
     case 0: channels = 1; break;

@@ -47,6 +47,12 @@ class JsonParser {
  private:
   const std::string& s_;
   size_t i_ = 0;
+  int depth_ = 0;   // serde_json (the reference's parser) refuses nesting beyond 128 levels ("recursion limit exceeded"); so does this one
+  struct Nest {
+    JsonParser& p;
+    explicit Nest(JsonParser& q) : p(q) { if (++p.depth_ > 128) p.fail("recursion limit exceeded"); }
+    ~Nest() { p.depth_--; }
+  };
   [[noreturn]] void fail(const char* what) {
     throw ParseError("scene json: " + std::string(what) + " at byte " + std::to_string(i_));
   }
@@ -57,8 +63,8 @@ class JsonParser {
     ws();
     if (i_ >= s_.size()) fail("unexpected end");
     char c = s_[i_];
-    if (c == '{') return object();
-    if (c == '[') return array();
+    if (c == '{') { Nest n(*this); return object(); }
+    if (c == '[') { Nest n(*this); return array(); }
     if (c == '"') { Json j; j.kind = Json::Str; j.str = string(); return j; }
     if (c == 't') { lit("true"); Json j; j.kind = Json::Bool; j.b = true; return j; }
     if (c == 'f') { lit("false"); Json j; j.kind = Json::Bool; j.b = false; return j; }

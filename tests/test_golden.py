@@ -112,15 +112,23 @@ def test_device_ray_batch_matches_golden(cfg2_full):
         assert np.array_equal(got[k][hit], G[f"hit_flat_{k}"][hit])
     assert np.array_equal(np.packbits(occ), G["any_flat"])
     # against the reference-order evaluation: only rays the oracle itself marks as exact ties may differ (decision gap ~ 1e-16)
+    # (as tests/test_oracle.py shows for the two oracle evaluations: one of them sees a decision gap below 1e-12 on every such ray)
     differs = got["prim"] != G["hit_ref_prim"]
-    assert differs.mean() < 0.01 and np.all(G["hit_ref_margin"][differs] < 1e-9), (differs.mean(), G["hit_ref_margin"][differs].max(initial=0))
+    gap = np.minimum(G["hit_ref_margin"], G["hit_flat_margin"])
+    assert differs.mean() < 0.03 and np.all(gap[differs] < 1e-12), (differs.mean(), gap[differs].max(initial=0))
+    # fp32 product mode: the first half of the batch (rays from outside). The second half starts on surfaces at points rounded to fp32,
+    # i.e. ~2e-6 beside them: f64 then sees the starting triangle again at t ~ 1e-6 > 1e-7 and accepts it, while fp32 callers exclude it
+    # by plane (skip_prim, include/rrt.h) - not comparable ray by ray
+    n = len(tmax) // 2
     r32 = Renderer(cfg2_full, 0, RRT_F32)
-    g32 = r32.trace_closest(o, d, tmax, skip_prim=skip)
+    g32 = r32.trace_closest(o[:n], d[:n], tmax[:n])
+    o32 = r32.trace_any(o[:n], d[:n], tmax[:n])
     r32.close()
-    same = g32["prim"] == G["hit_ref_prim"]
+    same = g32["prim"] == G["hit_ref_prim"][:n]
     assert same.mean() > 0.97, same.mean()                      # (23 % of this scene's rays carry an exact box / face tie)
-    ok = same & (G["hit_ref_prim"] >= 0)
-    np.testing.assert_allclose(g32["t"][ok], G["hit_ref_t"][ok], rtol=2e-4, atol=1e-4)
+    ok = same & (G["hit_ref_prim"][:n] >= 0)
+    np.testing.assert_allclose(g32["t"][ok], G["hit_ref_t"][:n][ok], rtol=2e-4, atol=1e-4)
+    assert (o32 == np.unpackbits(G["any_ref"])[:n].astype(bool)).mean() > 0.97
 
 
 @pytest.mark.gpu

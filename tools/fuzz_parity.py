@@ -115,12 +115,6 @@ for case in range(n_cases):
         sc = Scene.loads(cfg, root, flags=RRT_FIXED_BVH if rng.random() < 0.5 else 0)
     except RrtError as e:
         print(f"case {case} {base}: scene refused: {str(e)[:100]}"); continue
-    if ONLY >= 0 and case != ONLY:
-        continue
-    if ONLY >= 0:
-        import json
-        with open(os.path.join(wd, "scene.json"), "w") as fjs: json.dump(cfg, fjs)
-        print("scene written to", wd)
     tag = f"case {case} {base} {cfg['Integrator']} mats={[p['material_name'] for p in cfg['Aggregate']['primitives']]} sampler={cfg['Sampler'].get('sampler_type')} filter={cfg['Film'].get('Filter', {}).get('filter_type')}"
     if os.environ.get("FUZZ_DUMP") == str(case):     # keep the random stream intact (unlike `only`) and leave the scene behind
         import json
@@ -132,6 +126,12 @@ for case in range(n_cases):
         rect = (x0, y0, x0 + int(rng.integers(4, RES // 2)), y0 + int(rng.integers(4, RES // 2)))
     max_paths = int(rng.choice([0, 0, 1 << 16, 3000]))
     tag += f" rect={rect} max_paths={max_paths}"
+    if ONLY >= 0 and case != ONLY:     # (every random draw of the case has been made: the stream stays that of the full sweep)
+        continue
+    if ONLY >= 0:
+        import json
+        with open(os.path.join(wd, "scene.json"), "w") as fjs: json.dump(cfg, fjs)
+        print("scene written to", wd, "flags", "fixed-bvh" if sc.desc.flags & 3 else "compat-bvh")
     try:
         ref = O.render(sc, rect, flat=True)
         o_err = None
