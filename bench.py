@@ -25,6 +25,20 @@ sys.path.insert(0, ROOT)
 sys.path.insert(0, os.path.join(ROOT, "tests"))
 
 HBM_PEAK_GBS = 8000.0  # MI355X_MICROARCH.md: HBM3E peak 8.0 TB/s (6.3 TB/s measured streaming copy)
+# MI355X_MICROARCH.md "Indexed rows: gather": rows served from the XCD's L2 16.8-18.8 TB/s chip-wide, from the Infinity Cache 8.6 TB/s.
+# The 11 MB BVH (pair nodes + triangles) does not fit one XCD's 4 MiB L2, so its gathered 64-B lines come from a mix of both.
+GATHER_L2_GBS, GATHER_IC_GBS = 17800.0, 8600.0
+
+
+def kernel_source_hash():
+    """Identifies the device code a PMC file was measured on (tools/pmc_traffic.py stores it): a stale file must not feed `traffic`."""
+    import glob
+    import hashlib
+    h = hashlib.sha256()
+    for f in sorted(glob.glob(os.path.join(ROOT, "rs_ray_toy_amd", "csrc", "device", "*"))):
+        if f.endswith((".hpp", ".hip")):
+            h.update(open(f, "rb").read())
+    return h.hexdigest()[:16]
 
 
 def cpu_baseline(scene, target_seconds):
@@ -125,6 +139,7 @@ def main():
         for kv in args.opt:
             k, v = kv.split("=")
             h.set_option(k, float(v))
+        h.set_option("frame_stats", 1)               # kernel timings of the frames in flight (HIP events on the handle's own streams)
         if nfl > 1:
             h.set_option("nonblocking_streams", 1)   # frames of the two handles may overlap; ordering with torch's stream is explicit below
     r = handles[0]
@@ -139,24 +154,28 @@ def main():
         reduce_film(film, world)  # disjoint bands: the sum reassembles the frame on rank 0 (RCCL over xGMI)
         return agg
 
+    frame_log = []   # per-frame statistics of the frames run_frames() completed (kernel timings: HIP events on the handle's streams)
+
     def run_frames(n):
         """n frames (steps), at most `nfl` in flight: frame i renders on handle i % nfl while frame i - 1 finishes on the other one;
         each frame ends with its film reduced to rank 0, all inside the caller's timed region."""
         if nfl == 1:
             for _ in range(n):
-                step()
+                frame_log.append(step(collect=True))
             return
+        def end(k):
+            st = handles[k].render_end(stats=True)
+            frame_log.append({kk: getattr(st, kk) for kk, _ in st._fields_})
+            reduce_film(films[k], world)
         for i in range(n):
             k = i % nfl
             if i >= nfl:
-                handles[k].render_end()
-                reduce_film(films[k], world)
+                end(k)
             films[k].zero_()                              # (ordered after that film's previous reduce on torch's stream)
             torch.cuda.current_stream().synchronize()     # the handle's streams do not wait for torch's stream
             handles[k].render_bands_begin(rank, world, films[k].data_ptr())
         for i in range(max(0, n - nfl), n):
-            handles[i % nfl].render_end()
-            reduce_film(films[i % nfl], world)
+            end(i % nfl)
 
     def sync():
         torch.cuda.synchronize()
@@ -168,14 +187,25 @@ def main():
     r.set_option("count_traversal", 1)
     counted = step(collect=True)
     r.set_option("count_traversal", 0)
-    try:
-        run_frames(max(args.warmup, nfl if nfl > 1 else 0))   # (at least one untimed frame per handle: pool allocation)
-    except RrtError as e:
-        # e.g. not enough free HBM for a second set of wavefront pools: go on with one frame at a time (every rank still reduces once
-        # per frame, in frame order, so ranks may differ in this)
-        if nfl == 1:
-            raise
-        print(f"[rank {rank}] {nfl} frames in flight not possible here ({e}); one frame at a time", file=sys.stderr)
+    # Warm-up = pool allocation: every handle renders one frame of its own, WITHOUT the collective, so that a rank that cannot hold `nfl`
+    # sets of wavefront pools (free HBM) finds out before any reduce is issued; the ranks then agree (MAX over ranks) on one frame at a
+    # time or `nfl`, and only then run the warm-up frames - every rank issues the same sequence of collectives whatever happened.
+    failed = 0
+    if nfl > 1:
+        try:
+            for k in range(nfl):
+                films[k].zero_()
+                torch.cuda.current_stream().synchronize()
+                handles[k].render_bands_begin(rank, world, films[k].data_ptr())
+                handles[k].render_end()
+        except RrtError as e:
+            print(f"[rank {rank}] {nfl} frames in flight not possible here ({e})", file=sys.stderr)
+            failed = 1
+    if world > 1:
+        flag = torch.tensor([failed], dtype=torch.int32, device="cpu" if args.dist_backend == "gloo" else f"cuda:{local_rank}")
+        dist.all_reduce(flag, op=dist.ReduceOp.MAX)
+        failed = int(flag.item())
+    if failed:
         for h in handles:
             try:
                 h.render_end()
@@ -185,15 +215,16 @@ def main():
             h.close()
         nfl = 1
         del handles[1:], films[1:]
-        run_frames(args.warmup)
+    run_frames(args.warmup)
     sync()
+    del frame_log[:]
     t0 = time.perf_counter()
     run_frames(args.steps)
     sync()
     elapsed = time.perf_counter() - t0
-    # per-kernel durations with HIP events on the handle's stream (one extra frame, after the timed region)
-    timed = step(collect=True)
-    sync()
+    # per-kernel durations: HIP events on the handles' own streams around every launch of every frame of the timed region, averaged per frame
+    assert len(frame_log) == args.steps
+    timed = {k: sum(f[k] for f in frame_log) / len(frame_log) for k in frame_log[0]}
     # the same frame with the shadow launches back on the main stream: the closest-hit kernel alone on the chip
     r.set_option("overlap_shadow", 0)
     step()
@@ -223,32 +254,47 @@ def main():
         ms_per_step = elapsed / args.steps * 1e3
         queries = tot["closest_queries"] + tot["any_queries"]
         value = queries / (ms_per_step * 1e-3) / 1e6
-        # Roofline of the dominant kernel, k_closest. ALGORITHMIC bytes per closest query:
-        # 28 B ray in + 16 B hit out + 32 B per BVH node visited + 48 B per triangle tested; node / triangle
-        # counts are exact device counters of this very frame; duration = sum of the kernel's launches on the
-        # handle's stream (HIP events), so achieved = bytes per launch / average launch duration.
+        # Roofline of the dominant kernel: closest-hit BVH traversal. ALGORITHMIC bytes per closest query: 28 B ray in +
+        # 16 B hit out + 32 B per BVH node visited + 48 B per triangle tested; node / triangle counts are exact device counters of a
+        # counting frame of this very workload; duration = the kernel's launches of every timed frame, HIP events on the stream they
+        # were launched on, as the frames really ran (two frames in flight, shadow launches beside them: what rocprofv3's kernel
+        # trace of the same command shows per dispatch, profiles/).
         n_launch = max(1.0, tot["closest_launches"])
         bytes_closest = tot["closest_queries"] * 44.0 + 32.0 * tot["closest_nodes"] + 48.0 * tot["closest_prims"]
-        # per-rank kernel time: ranks run concurrently, take the slowest rank's sum
-        ms_closest = mx_tot["ms_closest"]
-        achieved = (bytes_closest / world) / (ms_closest * 1e-3) / 1e9 if ms_closest > 0 else 0.0
-        # `traffic`: HBM bytes per launch from the committed PMC passes of this same workload (tools/profile_round.sh;
-        # separate --pmc FETCH_SIZE / WRITE_SIZE runs, x1024, reads x2 per the gfx950 note). Far BELOW the
-        # algorithmic bytes: the 11 MB BVH + triangles live in L2 / Infinity Cache, only ray/hit streams reach HBM.
-        traffic = None
-        pmc = os.path.join(ROOT, "profiles", "r1_pmc_traffic.json")
-        if os.path.exists(pmc) and args.res == 1024 and args.spp == 256 and args.depth == 8 and world == 1:
-            with open(pmc) as f:
-                traffic = round(json.load(f)["closest"]["hbm_bytes"] / n_launch, 1)
-        roofline = {"kernel": "k_trace_pt_f32<false> + k_trace_pairs_f32<false> (closest-hit BVH traversal, one pair per bounce)", "bound": "hbm", "achieved": round(achieved, 2), "peak": HBM_PEAK_GBS, "unit": "GB/s",
-                    "frac": round(achieved / HBM_PEAK_GBS, 4), "traffic": traffic,
+        ms_closest = mx_tot["ms_closest"]   # per frame; ranks run concurrently: the slowest rank's sum
+        launch_s = ms_closest * 1e-3 / (n_launch / world) if ms_closest > 0 else float("inf")
+        achieved = (bytes_closest / n_launch) / launch_s / 1e9
+        # `traffic`: fabric-side bytes per launch from the committed PMC passes of this same workload and this same device code
+        # (tools/profile_round.sh: separate --pmc FETCH_SIZE / WRITE_SIZE runs, x1024, reads x2 per the gfx950 note; Infinity-Cache hits
+        # are included). A file measured on other kernel sources is ignored (null) rather than quoted stale.
+        traffic = lane_util = None
+        if args.res == 1024 and args.spp == 256 and args.depth == 8 and world == 1:
+            import glob
+            src = kernel_source_hash()
+            for pmc in sorted(glob.glob(os.path.join(ROOT, "profiles", "r*_pmc_traffic.json")), reverse=True):
+                with open(pmc) as f:
+                    j = json.load(f)
+                if j.get("source_hash") == src:
+                    traffic = round(j["closest"]["hbm_bytes"] / n_launch, 1)
+                    lane_util = j.get("closest", {}).get("valu_lane_util")
+                    break
+        # What can actually bind this kernel: the 11 MB BVH is served by L2 / Infinity Cache, so the bytes above never reach HBM
+        # (hbm_frac); what it does is gather one 64-B pair-node line per two nodes and one 48-B triangle per test, per lane.
+        gather_bytes = 64.0 * tot["closest_nodes"] / 2.0 + 48.0 * tot["closest_prims"] + 48.0 * tot["closest_queries"]
+        gather = (gather_bytes / n_launch) / launch_s / 1e9
+        roofline = {"kernel": "k_trace_pt_f32<false> + k_trace_pairs_f32<false> (closest-hit BVH traversal, one pair per bounce)", "bound": "hbm",
+                    "achieved": round(achieved, 2), "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": round(achieved / HBM_PEAK_GBS, 4), "traffic": traffic,
                     "algorithmic_bytes_per_launch": round(bytes_closest / n_launch, 1),
-                    "avg_launch_ms": round(ms_closest * world / n_launch, 4), "launches": int(n_launch),
-                    # `achieved` is timed as the frame really runs: every closest-hit launch but the first shares the chip with the
-                    # previous bounce's shadow launch (second stream). `alone`: the same launches with that overlap switched off.
-                    "alone": {"achieved": round((bytes_closest / world) / (mx_tot["ms_closest_isolated"] * 1e-3) / 1e9, 2),
-                              "frac": round((bytes_closest / world) / (mx_tot["ms_closest_isolated"] * 1e-3) / 1e9 / HBM_PEAK_GBS, 4),
-                              "avg_launch_ms": round(mx_tot["ms_closest_isolated"] * world / n_launch, 4)},
+                    "avg_launch_ms": round(launch_s * 1e3, 4), "launches": int(n_launch),
+                    "hbm_frac": None if traffic is None else round(traffic / launch_s / 1e9 / HBM_PEAK_GBS, 4),
+                    "gather": {"achieved": round(gather, 1), "unit": "GB/s of 64-B pair-node lines + 48-B triangles + ray / hit records",
+                               "peak_l2": GATHER_L2_GBS, "peak_infinity_cache": GATHER_IC_GBS,
+                               "frac_l2": round(gather / GATHER_L2_GBS, 4), "frac_infinity_cache": round(gather / GATHER_IC_GBS, 4)},
+                    "valu_lane_util": lane_util,
+                    "note": "achieved / frac price every node and triangle a ray touches as an HBM byte (the SURVEY 8d definition); the BVH is "
+                            "cache resident, so hbm_frac (PMC bytes) and gather (line fetches against the guide's gather rates) say what binds",
+                    # the same launches with the shadow launches back on the main stream and one frame at a time: the kernel alone on the chip
+                    "alone_avg_launch_ms": round(mx_tot["ms_closest_isolated"] * world / n_launch, 4),
                     "bytes_per_query": round(bytes_closest / max(1.0, tot["closest_queries"]), 1),
                     "nodes_per_query": round(tot["closest_nodes"] / max(1.0, tot["closest_queries"]), 2),
                     "tris_per_query": round(tot["closest_prims"] / max(1.0, tot["closest_queries"]), 2)}

@@ -351,6 +351,9 @@ int rrt_render_bands(rrt_handle*, int rank, int world, void* film_xyzw, int film
  * default stream, so work the caller issued there on the film (a memset ...) must be finished before _begin. */
 int rrt_render_bands_begin(rrt_handle*, int rank, int world, void* film_xyzw_device);
 int rrt_render_end(rrt_handle*);
+/* the same, and the frame's statistics; kernel timings (HIP events on the handle's streams around every launch) are recorded for frames in
+ * flight when the option "frame_stats" is 1 */
+int rrt_render_end_stats(rrt_handle*, rrt_render_stats* stats);
 
 /* ---- multi-GPU film reassembly: RCCL over xGMI, one collective per frame ----
  * The reference has one address space: its rayon tiles merge under a lock (Film::merge_film_tile film.rs:248-263, driven from
@@ -377,7 +380,8 @@ int rrt_film_gather(rrt_handle*, rrt_comm*, void* film_xyzw_device, int root);
  * n into films_device[i] on its own device; communicators (ncclCommInitAll) are created on first use and kept */
 int rrt_film_gather_all(rrt_handle* const* handles, void* const* films_device, int n, int root);
 
-/* handle options: "max_paths" (wavefront pool slots; default 2^28 clamped to half of the free HBM), "count_traversal"
+/* handle options: "frame_stats" (see rrt_render_end_stats), "aux_margin" (fp32: 0 = trace the auxiliary camera rays of every surviving
+ * sample, 1 = default: skip them where the main ray clears every lens interface by the calibrated margin), "max_paths" (wavefront pool slots; default 2^28 clamped to half of the free HBM), "count_traversal"
  * (exact node / triangle-test counters in rrt_render_stats, generic kernels), "persistent_traversal" (fp32: 0 generic
  * kernels, 1 grid-stride pair-node kernel, 2 persistent-thread kernel, 3 = default, by queue size), "pt_split_closest" /
  * "pt_split_any" (queue sizes at which 3 switches), "raygen_pt" (fp32: 0 = the generic two-stage raygen in the reference's

@@ -119,6 +119,17 @@ inline V3 xf_nrm(const double* minv, V3 n) {  // transform.rs:506-523 (inverse t
 inline Ray xf_ray(const double* m, const Ray& r) {  // transform.rs:525-537
   return ray_new(xf_pt(m, r.o), vnormalize(xf_vec(m, r.d)), r.t_max);
 }
+// linear part orthonormal within 1e-9 and affine: what the device flattens to world space (rrt_impl.hpp is_rigid); anything else
+// (scale, shear) keeps the reference's per-primitive ray transform there too
+inline bool is_rigid(const double* m) {
+  for (int i = 0; i < 3; i++)
+    for (int j = 0; j < 3; j++) {
+      double s = 0;
+      for (int k = 0; k < 3; k++) s += m[k * 4 + i] * m[k * 4 + j];
+      if (std::fabs(s - (i == j ? 1.0 : 0.0)) > 1e-9) return false;
+    }
+  return m[12] == 0.0 && m[13] == 0.0 && m[14] == 0.0 && m[15] == 1.0;
+}
 inline bool is_identity(const double* m) {
   for (int i = 0; i < 16; i++)
     if (m[i] != ((i % 5 == 0) ? 1.0 : 0.0)) return false;
@@ -754,7 +765,7 @@ bool prim_intersect(const Scene& sc, uint32_t pi, Ray* r, SI* si, double* bu, do
   };
   if (p.instance < 0) return geometric(r);
   const rrt_xform& x = sc.d->xforms[p.instance];
-  if (sc.flat && p.type == RRT_PRIM_TRIANGLE) {
+  if (sc.flat && p.type == RRT_PRIM_TRIANGLE && is_rigid(x.m)) {
     double t_hit = 0.0;
     if (!tri_intersect(sc, sc.d->tris[p.shape], *r, &t_hit, si, bu, bv, &x)) return false;
     si->prim = (int)pi; si->valid = true;
@@ -774,7 +785,7 @@ bool prim_intersect_p(const Scene& sc, uint32_t pi, const Ray& r) {  // primitiv
     return p.type == RRT_PRIM_TRIANGLE ? tri_intersect_p(sc, sc.d->tris[p.shape], rr) : sphere_intersect_p(sphere_ref(sc, p.shape), rr);
   };
   if (p.instance < 0) return geometric(r);
-  if (sc.flat && p.type == RRT_PRIM_TRIANGLE) return tri_intersect_p(sc, sc.d->tris[p.shape], r, &sc.d->xforms[p.instance]);
+  if (sc.flat && p.type == RRT_PRIM_TRIANGLE && is_rigid(sc.d->xforms[p.instance].m)) return tri_intersect_p(sc, sc.d->tris[p.shape], r, &sc.d->xforms[p.instance]);
   return geometric(xf_ray(sc.d->xforms[p.instance].m_inv, r));
 }
 

@@ -174,6 +174,7 @@ PROTOTYPES = {
     "rrt_render_bands": (C.c_int, [C.c_void_p, C.c_int, C.c_int, C.c_void_p, C.c_int, C.POINTER(RenderStats)]),
     "rrt_render_bands_begin": (C.c_int, [C.c_void_p, C.c_int, C.c_int, C.c_void_p]),
     "rrt_render_end": (C.c_int, [C.c_void_p]),
+    "rrt_render_end_stats": (C.c_int, [C.c_void_p, C.POINTER(RenderStats)]),
     "rrt_band_rows": (C.c_int, [C.c_int, C.c_int, C.c_int, C.POINTER(C.c_int32), C.c_int]),
     "rrt_comm_id": (C.c_int, [C.c_void_p]),
     "rrt_comm_create": (C.c_int, [C.c_void_p, C.c_int, C.c_int, C.c_int, C.POINTER(C.c_void_p)]),

@@ -175,8 +175,13 @@ class Renderer:
         """Enqueue render_bands_device and return (frames in flight, see rrt_render_bands_begin); pair with render_end()."""
         _check(A.lib().rrt_render_bands_begin(self._h, rank, world, film_ptr))
 
-    def render_end(self):
-        _check(A.lib().rrt_render_end(self._h))
+    def render_end(self, stats=False):
+        if not stats:
+            _check(A.lib().rrt_render_end(self._h))
+            return None
+        st = A.RenderStats()
+        _check(A.lib().rrt_render_end_stats(self._h, C.byref(st)))
+        return st
 
     def render_bands(self, rank, world, film=None):
         W, H = self.scene.resolution

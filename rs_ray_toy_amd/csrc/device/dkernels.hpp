@@ -290,6 +290,16 @@ RRT_DEV void sphere_surface(const SphereDev<R>& S, V3<R> wo_, V3<R> wd_, R th, R
   }
 }
 
+// triangle of a non-rigid instance (dtypes.hpp kInstBase): the ray as TransformedPrimitive hands it to the triangle
+template <typename R> RRT_DEV bool is_inst_tri(const Tri<R>& t) { return (t.material & kInstFlag) != 0u; }
+template <typename R> RRT_DEV uint32_t inst_of(const Tri<R>& t) { return (t.material >> 16) & 0x7fffu; }
+template <typename R>
+RRT_DEV RayCtx<R> inst_ray(const InstDev<R>& I, const RayCtx<R>& r) {   // world_to_prim.t(r): xf_ray + Ray::new (direction normalised twice)
+  RayCtx<R> o;
+  o.o = aff_pt(I.mi, r.o); o.d = vnormalize(vnormalize(aff_vec(I.mi, r.d))); o.lo = V3<R>(); o.tmax = r.tmax;
+  return o;
+}
+
 template <typename R, typename Stack>
 RRT_DEV int traverse_closest(const SceneDev<R>& s, RayCtx<R>& r, Stack& st, int skip, R* hu, R* hv, uint32_t* nn, uint32_t* np) {
   int hit = -1;
@@ -311,6 +321,11 @@ RRT_DEV int traverse_closest(const SceneDev<R>& s, RayCtx<R>& r, Stack& st, int 
             continue;
           }
           if (tr.plane == skip_plane) continue;
+          if (is_inst_tri(tr)) {   // object-space test, object-space t copied to the world ray (Q15)
+            const RayCtx<R> ro = inst_ray(s.insts[inst_of(tr)], r);
+            if (tri_closest(tr, ro, &t, &u, &v)) { r.tmax = t; hit = (int)(nd.offset + i); *hu = u; *hv = v; }
+            continue;
+          }
           if (tri_closest(tr, r, &t, &u, &v)) { r.tmax = t; hit = (int)(nd.offset + i); *hu = u; *hv = v; }
         }
         if (to_visit == 0) break;
@@ -348,6 +363,10 @@ RRT_DEV bool traverse_any(const SceneDev<R>& s, const RayCtx<R>& r, Stack& st, i
             continue;
           }
           if (tr.plane == skip_plane) continue;
+          if (is_inst_tri(tr)) {
+            if (tri_any(tr, inst_ray(s.insts[inst_of(tr)], r))) { found = true; break; }
+            continue;
+          }
           if (tri_any(tr, r)) { found = true; break; }
         }
         if (found) break;
@@ -639,6 +658,11 @@ RRT_DEV Surf<R> build_surface(const SceneDev<R>& s, int prim, V3<R> o, V3<R> d, 
     if (!(dot(si.n, si.sn) >= R(0))) si.ok = false;   // primitives.rs:66
     return si;
   }
+  const bool inst = is_inst_tri(tr);
+  if (inst) {   // the triangle works with the ray TransformedPrimitive::intersect handed it (primitives.rs:124-127)
+    const InstDev<R>& I = s.insts[inst_of(tr)];
+    o = aff_pt(I.mi, o); d = vnormalize(vnormalize(aff_vec(I.mi, d)));
+  }
   V3<R> p0(tr.p0), p1(tr.p1), p2(tr.p2);
   R uv[3][2] = {{R(0), R(0)}, {R(1), R(0)}, {R(1), R(1)}};  // get_uvs :113-128
   uint32_t has_n = 0;
@@ -668,7 +692,7 @@ RRT_DEV Surf<R> build_surface(const SceneDev<R>& s, int prim, V3<R> o, V3<R> d, 
   si.n = vnormalize(cross(dp02, dp12));
   si.sn = si.n;
   si.sdpdu = dpdu;
-  si.material = tr.material;
+  si.material = inst ? (tr.material & 0xffffu) : tr.material;
   si.ok = true;
   if (ext) {
     ext->u = uv[0][0] * (R(1) - u - v) + uv[1][0] * u + uv[2][0] * v;
@@ -702,6 +726,21 @@ RRT_DEV Surf<R> build_surface(const SceneDev<R>& s, int prim, V3<R> o, V3<R> d, 
     if (ext) ext->sdpdv = ts;
     // ... and primitives.rs:66 asserts dot(ist.n, shading.n) >= 0, i.e. panics when vn opposes the winding.
     if (!(dot(si.n, si.sn) >= R(0))) si.ok = false;
+  }
+  if (inst) {   // `*si = primitive_to_world.t(si)` primitives.rs:131-136 + SurfaceInteraction::t_by transform.rs:628-655
+    const InstDev<R>& I = s.insts[inst_of(tr)];
+    if (!I.identity) {
+      si.p = aff_pt(I.m, si.p + si.p_lo); si.p_lo = V3<R>();
+      si.wo = aff_vec(I.m, si.wo);                       // (not re-normalised: its length is the instance's scale along the ray)
+      const V3<R> n2 = aff_nrm(I.mi, si.n);              // BaseInteraction::t_by: not re-normalised either
+      si.sn = faceforward(nnormalize(aff_nrm(I.mi, si.sn)), n2);
+      si.n = n2;
+      si.sdpdu = aff_vec(I.m, si.sdpdu);
+      if (ext) {
+        ext->dpdu = aff_vec(I.m, ext->dpdu); ext->dpdv = aff_vec(I.m, ext->dpdv); ext->sdpdv = aff_vec(I.m, ext->sdpdv);
+        ext->sdndu = aff_nrm(I.mi, ext->sdndu); ext->sdndv = aff_nrm(I.mi, ext->sdndv);
+      }
+    }
   }
   return si;
 }

@@ -31,6 +31,19 @@ struct alignas(16) Tri {
 // order): plane == kSphereMark, shade = index into SceneDev::spheres, material as usual.
 constexpr uint32_t kSphereMark = 0xfffffffeu;
 
+// A triangle of a NON-RIGID instance (scale / shear) is not flattened either: the reference transforms the ray into the instance's space,
+// re-normalises its direction there and copies the object-space t back to the world ray (TransformedPrimitive::intersect
+// primitives.rs:115-139, transform.rs:525-537: Q15), which no world-space triangle reproduces. Such a Tri keeps the mesh's raw vertices
+// and carries its instance in the material word: kInstFlag | instance index (15 bits) << 16 | material (16 bits). Its plane id is
+// computed from the world-space vertices like everybody's (coplanarity is the same in both spaces).
+constexpr uint32_t kInstFlag = 0x80000000u;
+template <typename R>
+struct InstDev {
+  R m[12], mi[12];      // primitive_to_world / its inverse, rows 0..2
+  uint32_t identity;    // Transform::is_identity (value compare): the interaction is not transformed then
+  uint32_t pad[3];
+};
+
 // Sphere (shape/sphere.rs:14-49) + the TransformedPrimitive around it (primitives.rs:100-139). Spheres are not
 // flattened: the reference's own sequence of ray transforms is replayed, including its quirks (Q15, Q16).
 template <typename R>
@@ -115,6 +128,7 @@ struct SceneDev {
   const Tri<R>* tris;
   const TriShade<R>* shades;
   const SphereDev<R>* spheres;
+  const InstDev<R>* insts;     // non-rigid triangle instances (kInstBase)
   const Material<R>* materials;
   const TexDev<R>* textures;   // texture graph nodes (children before parents)
   const ImageDev<R>* images;

@@ -95,7 +95,12 @@ int rrt_render_bands_begin(rrt_handle* h, int rank, int world, void* film_xyzw_d
 
 int rrt_render_end(rrt_handle* h) {
   if (!h) { rrt::set_last_error("rrt_render_end: null argument"); return RRT_EINVAL; }
-  return guarded([&]() { h->impl->render_end(); });
+  return guarded([&]() { h->impl->render_end(nullptr); });
+}
+
+int rrt_render_end_stats(rrt_handle* h, rrt_render_stats* stats) {
+  if (!h || !stats) { rrt::set_last_error("rrt_render_end_stats: null argument"); return RRT_EINVAL; }
+  return guarded([&]() { h->impl->render_end(stats); });
 }
 
 int rrt_set_option(rrt_handle* h, const char* key, double value) {

@@ -5,6 +5,7 @@
 #include <cmath>
 #include <cstdio>
 #include <cstring>
+#include <memory>
 #include <stdexcept>
 #include <string>
 #include <unordered_map>
@@ -43,7 +44,7 @@ struct HandleBase {
   virtual void render_rect(const int32_t rect[4], void* film, int film_mem, rrt_render_stats* stats) = 0;
   virtual void render_bands(int rank, int world, void* film, int film_mem, rrt_render_stats* stats) = 0;
   virtual void render_bands_begin(int rank, int world, void* film_device) = 0;
-  virtual void render_end() = 0;
+  virtual void render_end(rrt_render_stats* stats) = 0;
   virtual void set_option(const std::string& key, double v) = 0;
 };
 
@@ -299,6 +300,20 @@ inline void validate_desc(const rrt_scene_desc* d) {
 }
 
 
+// what a frame leaves behind for its statistics: HIP events around every launch (on the stream the launch went to), launch counts
+struct FrameRec {
+  std::vector<hipEvent_t> all;
+  std::vector<std::pair<int, std::pair<hipEvent_t, hipEvent_t>>> evs;   // category, begin, end
+  hipEvent_t ev_begin = nullptr, ev_end = nullptr;
+  uint64_t n_closest_launch = 0, n_any_launch = 0, camera_samples = 0;
+  bool timing = false;
+  hipEvent_t make() { hipEvent_t e = nullptr; HIP_CHECK(hipEventCreate(&e)); all.push_back(e); return e; }
+  ~FrameRec() { for (hipEvent_t e : all) (void)hipEventDestroy(e); }   // on every way out (a panic / HIP error thrown mid-frame included)
+  FrameRec() = default;
+  FrameRec(const FrameRec&) = delete;
+  FrameRec& operator=(const FrameRec&) = delete;
+};
+
 template <typename R>
 class Handle : public HandleBase {
  public:
@@ -349,6 +364,7 @@ class Handle : public HandleBase {
     else if (key == "pt_split_any") pt_split_any_ = (uint32_t)v;
     else if (key == "overlap_shadow") overlap_shadow_ = v != 0;
     else if (key == "aux_margin") aux_margin_ = v != 0;
+    else if (key == "frame_stats") frame_stats_ = v != 0;
     else if (key == "nonblocking_streams") {   // see rrt.h: needed for two handles to overlap their frames
       if (pending_) throw std::invalid_argument("nonblocking_streams: a frame is in flight");
       HIP_CHECK(hipSetDevice(dev_));
@@ -453,12 +469,15 @@ class Handle : public HandleBase {
     defer_ = false;
     pending_ = true;
   }
-  void render_end() override {
-    if (!pending_) return;
+  void render_end(rrt_render_stats* stats) override {
+    if (!pending_) { if (stats) memset(stats, 0, sizeof(*stats)); return; }
     pending_ = false;
+    std::unique_ptr<FrameRec> fr = std::move(frame_);
     HIP_CHECK(hipSetDevice(dev_));
     HIP_CHECK(hipStreamSynchronize(st_));
+    HIP_CHECK(hipStreamSynchronize(st2_));
     check_device_errors();
+    if (stats) { if (fr) frame_stats(*fr, stats); else memset(stats, 0, sizeof(*stats)); }
   }
   void check_device_errors() {
     uint32_t err = 0;
@@ -509,25 +528,21 @@ class Handle : public HandleBase {
     ensure_pools(P);
     const size_t group = std::min(rpix, cap_);                           // pixels per group
     const uint64_t s_chunk = std::max<uint64_t>(1, cap_ / group);         // samples per pass
-    const bool timing = stats != nullptr;
-    // timing events: destroyed on every way out of this function (a panic / HIP error thrown mid-frame included)
-    struct Events {
-      std::vector<hipEvent_t> all;
-      hipEvent_t make() { hipEvent_t e = nullptr; HIP_CHECK(hipEventCreate(&e)); all.push_back(e); return e; }
-      ~Events() { for (hipEvent_t e : all) (void)hipEventDestroy(e); }
-    } events;
-    std::vector<std::pair<int, std::pair<hipEvent_t, hipEvent_t>>> evs;
+    const bool timing = stats != nullptr || (defer_ && frame_stats_);
+    auto fr = std::make_unique<FrameRec>();
+    fr->timing = timing; fr->camera_samples = (uint64_t)rpix * s_total;
+    auto& evs = fr->evs;
     auto tick = [&](int cat, hipStream_t stream = nullptr) {
       if (!timing) return (size_t)0;
-      const hipEvent_t a = events.make(), b = events.make();
+      const hipEvent_t a = fr->make(), b = fr->make();
       HIP_CHECK(hipEventRecord(a, stream ? stream : st_));
       evs.push_back({cat, {a, b}});
       return evs.size() - 1;
     };
     auto tock = [&](size_t id, hipStream_t stream = nullptr) { if (timing) HIP_CHECK(hipEventRecord(evs[id].second.second, stream ? stream : st_)); };
-    hipEvent_t ev_begin = nullptr, ev_end = nullptr;
-    if (timing) { ev_begin = events.make(); ev_end = events.make(); HIP_CHECK(hipEventRecord(ev_begin, st_)); }
-    uint64_t n_closest_launch = 0, n_any_launch = 0;
+    if (timing) { fr->ev_begin = fr->make(); fr->ev_end = fr->make(); HIP_CHECK(hipEventRecord(fr->ev_begin, st_)); }
+    uint64_t& n_closest_launch = fr->n_closest_launch;
+    uint64_t& n_any_launch = fr->n_any_launch;
     const int integ = desc_.integrator.type;
     const int max_depth = desc_.integrator.max_depth;
 
@@ -639,13 +654,13 @@ class Handle : public HandleBase {
         HIP_CHECK(hipGetLastError());
       }
     }
-    if (timing) HIP_CHECK(hipEventRecord(ev_end, st_));
+    if (timing) HIP_CHECK(hipEventRecord(fr->ev_end, st_));
     // merge into the caller's film (+=)
     const size_t nfilm = W * H * 4;
     if (film_mem == RRT_MEM_DEVICE) {
       hipLaunchKernelGGL((k_film_add<R>), dim3((uint32_t)((nfilm + kBlock - 1) / kBlock)), dim3(kBlock), 0, st_, (const R*)film_.p, (R*)film_user, nfilm);
       HIP_CHECK(hipGetLastError());
-      if (defer_) return;   // render_end() synchronises and checks the error flags
+      if (defer_) { frame_ = std::move(fr); return; }   // render_end() synchronises, checks the error flags and reads the statistics
       HIP_CHECK(hipStreamSynchronize(st_));
     } else {
       std::vector<R> tmp(nfilm);
@@ -654,32 +669,32 @@ class Handle : public HandleBase {
       R* dst = (R*)film_user;
       for (size_t i = 0; i < nfilm; i++) dst[i] += tmp[i];
     }
-    uint32_t hc[C_COUNT];
-    unsigned long long ht[8];
-    HIP_CHECK(hipMemcpy(hc, counters_.p, sizeof(hc), hipMemcpyDeviceToHost));
-    HIP_CHECK(hipMemcpy(ht, totals_.p, sizeof(ht), hipMemcpyDeviceToHost));
     check_device_errors();
-    if (stats) {
-      memset(stats, 0, sizeof(*stats));
-      stats->camera_samples = (uint64_t)rpix * s_total;
-      stats->camera_rays = ht[4];
-      stats->closest_queries = ht[2];
-      stats->any_queries = ht[3];
-      stats->nodes_visited = ht[0] + ht[5];
-      stats->prims_tested = ht[1] + ht[6];
-      stats->closest_nodes = ht[0]; stats->closest_prims = ht[1]; stats->any_nodes = ht[5]; stats->any_prims = ht[6];
-      stats->closest_launches = n_closest_launch;
-      stats->any_launches = n_any_launch;
-      float ms = 0;
-      HIP_CHECK(hipEventElapsedTime(&ms, ev_begin, ev_end));
-      stats->ms_total = ms;
-      double cat[5] = {0, 0, 0, 0, 0};
-      for (auto& ev : evs) {
-        HIP_CHECK(hipEventElapsedTime(&ms, ev.second.first, ev.second.second));
-        cat[ev.first] += ms;
-      }
-      stats->ms_raygen = cat[0]; stats->ms_closest = cat[1]; stats->ms_any = cat[2]; stats->ms_shade = cat[3]; stats->ms_film = cat[4];
+    if (stats) frame_stats(*fr, stats);
+  }
+  void frame_stats(const FrameRec& fr, rrt_render_stats* stats) {
+    unsigned long long ht[8];
+    HIP_CHECK(hipMemcpy(ht, totals_.p, sizeof(ht), hipMemcpyDeviceToHost));
+    memset(stats, 0, sizeof(*stats));
+    stats->camera_samples = fr.camera_samples;
+    stats->camera_rays = ht[4];
+    stats->closest_queries = ht[2];
+    stats->any_queries = ht[3];
+    stats->nodes_visited = ht[0] + ht[5];
+    stats->prims_tested = ht[1] + ht[6];
+    stats->closest_nodes = ht[0]; stats->closest_prims = ht[1]; stats->any_nodes = ht[5]; stats->any_prims = ht[6];
+    stats->closest_launches = fr.n_closest_launch;
+    stats->any_launches = fr.n_any_launch;
+    if (!fr.timing) return;
+    float ms = 0;
+    HIP_CHECK(hipEventElapsedTime(&ms, fr.ev_begin, fr.ev_end));
+    stats->ms_total = ms;
+    double cat[5] = {0, 0, 0, 0, 0};
+    for (auto& ev : fr.evs) {
+      HIP_CHECK(hipEventElapsedTime(&ms, ev.second.first, ev.second.second));
+      cat[ev.first] += ms;
     }
+    stats->ms_raygen = cat[0]; stats->ms_closest = cat[1]; stats->ms_any = cat[2]; stats->ms_shade = cat[3]; stats->ms_film = cat[4];
   }
 
  private:
@@ -693,6 +708,8 @@ class Handle : public HandleBase {
   typename Vec4T<R>::type* shadow_buf_[2][3] = {{nullptr, nullptr, nullptr}, {nullptr, nullptr, nullptr}};
   bool overlap_shadow_ = true;
   bool defer_ = false, pending_ = false;   // render_bands_begin / render_end
+  bool frame_stats_ = false;               // option "frame_stats": deferred frames record their kernel timings too (rrt_render_end_stats)
+  std::unique_ptr<FrameRec> frame_;        // the frame in flight
   SceneDev<R> scene_{};
   Pools<R> pool_{};
   size_t cap_ = 0;
@@ -713,6 +730,7 @@ class Handle : public HandleBase {
   DevBuf<Tri<R>> tris_;
   DevBuf<TriShade<R>> shades_;
   DevBuf<SphereDev<R>> spheres_;
+  DevBuf<InstDev<R>> insts_;
   DevBuf<Material<R>> materials_;
   DevBuf<TexDev<R>> textures_;
   DevBuf<ImageDev<R>> images_;
@@ -814,6 +832,9 @@ class Handle : public HandleBase {
     std::vector<TriShade<R>> shades;
     std::vector<SphereDev<R>> spheres;
     std::vector<double> world(9 * d->n_prim_order);
+    std::vector<InstDev<R>> insts;
+    std::unordered_map<int32_t, uint32_t> inst_of;
+    uint32_t inst_index = 0;
     for (size_t i = 0; i < d->n_prim_order; i++) {
       const uint32_t pi = d->prim_order[i];
       const rrt_prim& pr = d->prims[pi];
@@ -843,9 +864,22 @@ class Handle : public HandleBase {
       const rrt_tri& t = d->tris[pr.shape];
       const double* m = nullptr;
       const double* mi = nullptr;
+      bool kept = false;   // non-rigid instance: not flattened, the ray is transformed per test like the reference does (Q15)
       if (pr.instance >= 0) {
         m = d->xforms[pr.instance].m; mi = d->xforms[pr.instance].m_inv;
-        if (!is_rigid(m)) throw UnsupportedError("instance transform with scale/shear: the reference mixes object- and world-space t there (Q15); only rigid instances are flattened on the device");
+        if (!is_rigid(m)) {
+          auto it = inst_of.find(pr.instance);
+          if (it == inst_of.end()) {
+            InstDev<R> I{};
+            affine_rows(m, I.m, "instance transform"); affine_rows(mi, I.mi, "instance transform");
+            I.identity = 1u;
+            for (int k = 0; k < 16; k++) if (m[k] != ((k % 5 == 0) ? 1.0 : 0.0)) I.identity = 0u;
+            it = inst_of.emplace(pr.instance, (uint32_t)insts.size()).first;
+            insts.push_back(I);
+          }
+          if (it->second >= 0x8000u || pr.material >= 0x10000u) throw UnsupportedError("more than 32 768 non-rigid instances / 65 536 materials");
+          kept = true; inst_index = it->second;
+        }
       }
       Tri<R>& o = tris[i];
       double wv[3][3];
@@ -854,10 +888,10 @@ class Handle : public HandleBase {
         double w[3] = {p[0], p[1], p[2]};
         if (m) xf_pt(m, p, w);
         R* dst = k == 0 ? o.p0 : (k == 1 ? o.p1 : o.p2);
-        for (int c = 0; c < 3; c++) { dst[c] = (R)w[c]; wv[k][c] = w[c]; }
+        for (int c = 0; c < 3; c++) { dst[c] = kept ? (R)p[c] : (R)w[c]; wv[k][c] = w[c]; }   // (kept: the raw mesh vertex; wv, world space, feeds the plane ids)
       }
-      o.material = pr.material;
-      o.plane = 0;
+      o.material = kept ? (kInstFlag | (inst_index << 16) | pr.material) : pr.material;
+      o.plane = 0u;
       o.shade = 0xffffffffu;
       for (int c = 0; c < 3; c++) { world[9 * i + c] = wv[0][c]; world[9 * i + 3 + c] = wv[1][c]; world[9 * i + 6 + c] = wv[2][c]; }
       if (t.mesh_has_n == 1 || t.mesh_has_uv) {
@@ -867,7 +901,7 @@ class Handle : public HandleBase {
           for (int k = 0; k < 3; k++) {
             const double* nn = &d->normals[3 * (size_t)t.n[k]];
             double w[3] = {nn[0], nn[1], nn[2]};
-            if (mi) xf_nrm(mi, nn, w);
+            if (mi && !kept) xf_nrm(mi, nn, w);   // (kept: object-space normals, the interaction is transformed after the hit)
             for (int c = 0; c < 3; c++) sh.n[k][c] = (R)w[c];
           }
         if (t.mesh_has_uv)
@@ -1008,13 +1042,14 @@ class Handle : public HandleBase {
 
     nodes_.upload(nodes, st_); tris_.upload(tris, st_); build_pairs(nodes, tris.size()); shades_.upload(shades, st_); spheres_.upload(spheres, st_);
     materials_.upload(mats, st_); textures_.upload(texs, st_); images_.upload(imgs, st_); image_texels_.upload(texels, st_);
-    if (!spheres.empty()) pairs_ok_ = false;   // the fp32 pair-node kernels are triangle-only: sphere scenes use the generic kernels
+    if (!spheres.empty() || !insts.empty()) pairs_ok_ = false;   // the fp32 pair-node kernels test world-space triangles only: scenes with spheres or non-rigid instances use the generic kernels
+    insts_.upload(insts, st_);
     { const AuxMargins am = calibrate_aux_margins(d); lens_safe_.upload(am.lim, st_); aux_delta_ = am.delta; aux_pupil_ = am.pupil; }
     lights_.upload(lights, st_); light_cdf_.upload(cdf_r, st_); lens_.upload(lens, st_); hdims_.upload(hd, st_); perms_.upload(perms, st_);
     HIP_CHECK(hipStreamSynchronize(st_));  // host vectors go out of scope below
 
     SceneDev<R>& s = scene_;
-    s.nodes = nodes_.p; s.tris = tris_.p; s.shades = shades_.p; s.spheres = spheres_.p; s.materials = materials_.p; s.textures = textures_.p; s.images = images_.p; s.image_texels = image_texels_.p; s.lights = lights_.p; s.light_cdf = light_cdf_.p;
+    s.nodes = nodes_.p; s.tris = tris_.p; s.shades = shades_.p; s.spheres = spheres_.p; s.insts = insts_.p; s.materials = materials_.p; s.textures = textures_.p; s.images = images_.p; s.image_texels = image_texels_.p; s.lights = lights_.p; s.light_cdf = light_cdf_.p;
     s.n_nodes = (uint32_t)d->n_bvh_nodes; s.n_tris = (uint32_t)d->n_prim_order; s.n_lights = (uint32_t)nl;
     s.light_pick_pdf = (nl && func_int > 0.0) ? (R)(1.0 / (func_int * (double)nl)) : (R)0;
     s.stack_depth = d->bvh_depth + 1;

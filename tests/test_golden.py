@@ -170,12 +170,15 @@ def test_device_crops_match_golden(name):
         # (DESIGN.md section 4): device libm vs host libm may flip a few
         assert (d_ref < 1e-9).mean() > 0.99, (d_ref < 1e-9).mean()
     else:
-        d_flat = np.abs(f64[..., :3] - G[f"crop_{name}_flat"][..., :3]).max(-1) / scale
-        # axis-aligned cube faces coplanar with flat leaf boxes: exact ties. The flattened evaluation is the device's own order
-        # (a last-ulp difference of a sampled direction can still break a tie the other way); against the reference's
-        # per-primitive order at most 1 % of the pixels may hold a tie broken differently
+        flat = G[f"crop_{name}_flat"]
+        d_flat = np.abs(f64[..., :3] - flat[..., :3]).max(-1) / scale
+        # Axis-aligned cube faces coplanar with flat leaf boxes: exact ties (23 % of cfg2's rays carry one), which the reference's
+        # per-primitive evaluation and the world-space flattened one break differently by their last-bit rounding - the two ORACLE
+        # evaluations stored in the file agree on only 90 % of cfg2's crop pixels at 64 spp (99.9 % of cfg3's). The f64 device mode is the
+        # flattened evaluation: held to that one tightly, and to the reference-order one as closely as the oracle agrees with itself.
+        self_1e9 = (np.abs(ref[..., :3] - flat[..., :3]).max(-1) / scale < 1e-9).mean()
         assert (d_flat < 1e-9).mean() > 0.995, (d_flat < 1e-9).mean()
-        assert (d_ref < 1e-9).mean() > 0.99, (d_ref < 1e-9).mean()
+        assert (d_ref < 1e-9).mean() > self_1e9 - 0.01, ((d_ref < 1e-9).mean(), self_1e9)
     r = Renderer(sc, 0, RRT_F32)
     f32 = r.render(CROPS[name])[y0:y1, x0:x1].astype(np.float64)
     r.close()
@@ -186,5 +189,10 @@ def test_device_crops_match_golden(name):
         # 1 spp on spheres = one coin per pixel (see above): the fp32 product is held to the mean here, sphere pixels to RRT_F64
         assert abs(f32[..., :3].mean() - ref[..., :3].mean()) < 0.15 * ref[..., :3].mean()
     else:
-        assert (d32 < 1e-3).mean() > 0.985, (d32 < 1e-3).mean()     # tie-prone geometry: the bar of test_render_f32_close_to_oracle[cfg2_path]
+        # fp32 rounding breaks the ties a third way: per pixel it can agree with the reference order no better than the two oracle orders
+        # agree with each other; apart from ties it is within the stated 1e-4 (median far below), and the mean radiance is unaffected
+        flat = G[f"crop_{name}_flat"]
+        self_1e3 = (np.abs(ref[..., :3] - flat[..., :3]).max(-1) / scale < 1e-3).mean()
+        assert (d32 < 1e-3).mean() > self_1e3 - 0.05, ((d32 < 1e-3).mean(), self_1e3)
         assert np.median(d32) < 1e-5
+        assert abs(f32[..., :3].mean() / ref[..., :3].mean() - 1.0) < 0.01

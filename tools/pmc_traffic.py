@@ -5,11 +5,18 @@ MI355X_MICROARCH.md (HBM section) FETCH_SIZE on gfx950 tallies 128-B requests at
 The profiled command is `bench.py --steps 1 --warmup 0 --frames-in-flight 1`; its first frame is the counting frame (generic
 counting kernels), the product kernels appear in the others (their number is derived from the dispatch count).
 """
-import collections, csv, glob, json, re, sys
+import collections, csv, glob, hashlib, json, os, re, sys
 root = sys.argv[1]
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+def kernel_source_hash():   # = bench.py kernel_source_hash(): ties the file to the device code it was measured on
+    h = hashlib.sha256()
+    for f in sorted(glob.glob(os.path.join(ROOT, "rs_ray_toy_amd", "csrc", "device", "*"))):
+        if f.endswith((".hpp", ".hip")):
+            h.update(open(f, "rb").read())
+    return h.hexdigest()[:16]
 fam = collections.OrderedDict([
     ("closest", r"k_trace_(pt|pairs)_f32<false>"), ("any", r"k_trace_(pt|pairs)_f32<true>"),
-    ("raygen", r"k_raygen|k_compact_alive|k_sample_f32"), ("shade", r"k_shade"), ("film", r"k_film|k_accumulate")])
+    ("raygen", r"k_raygen|k_compact_alive|k_sample_f32|k_pixel_offsets"), ("shade", r"k_shade"), ("film", r"k_film|k_accumulate")])
 tot = {k: collections.defaultdict(float) for k in fam}
 disp = {k: collections.defaultdict(int) for k in fam}
 for f in glob.glob(f"{root}/pass*/**/*counter_collection.csv", recursive=True):
@@ -19,10 +26,15 @@ for f in glob.glob(f"{root}/pass*/**/*counter_collection.csv", recursive=True):
                 tot[k][r["Counter_Name"]] += float(r["Counter_Value"]); disp[k][r["Counter_Name"]] += 1
 # product frames in the profiled run = closest-hit dispatches / 16 (8 bounces x the two regime kernels; the counting frame uses the generic kernels)
 FRAMES = max(1, round(disp["closest"]["FETCH_SIZE"] / 16))
-out = {"units": "bytes per frame; FETCH_SIZE x1024 x2 (gfx950 correction), WRITE_SIZE x1024", "frames_profiled": FRAMES}
+out = {"units": "bytes per frame; FETCH_SIZE x1024 x2 (gfx950 correction), WRITE_SIZE x1024", "frames_profiled": FRAMES, "source_hash": kernel_source_hash()}
 for k in fam:
     nf = FRAMES if k in ("closest", "any") else FRAMES + 1     # raygen / shading / film kernels also run in the counting frame
     rd = tot[k]["FETCH_SIZE"] * 1024 * 2 / nf
     wr = tot[k]["WRITE_SIZE"] * 1024 / nf
     out[k] = {"read_bytes": rd, "write_bytes": wr, "hbm_bytes": rd + wr, "dispatches_per_frame": disp[k]["FETCH_SIZE"] / nf}
+# VALU lane utilisation of the traversal kernels where the SQ pass was collected too (tools/pmc.sh pass 1)
+for k in ("closest", "any"):
+    tc, ai = tot[k].get("SQ_THREAD_CYCLES_VALU", 0.0), tot[k].get("SQ_ACTIVE_INST_VALU", 0.0)
+    if ai > 0:
+        out[k]["valu_lane_util"] = round(tc / (ai * 16.0) / 4.0, 4)   # thread-cycles per active VALU cycle, of 64 lanes (16 lanes x 4 cycles)
 print(json.dumps(out, indent=1))
