@@ -313,6 +313,7 @@ def main():
             "camera_mrays_per_s": round(tot["camera_rays"] / (ms_per_step * 1e-3) / 1e6, 3),
             "camera_samples": int(tot["camera_samples"]), "camera_rays": int(tot["camera_rays"]),
             "closest_queries": int(tot["closest_queries"]), "any_queries": int(tot["any_queries"]),
+            "any_nodes_per_query": round(tot["any_nodes"] / max(1.0, tot["any_queries"]), 2), "any_tris_per_query": round(tot["any_prims"] / max(1.0, tot["any_queries"]), 2),
             "kernel_ms_per_frame": {k: round(mx_tot[k], 3) for k in ("ms_raygen", "ms_closest", "ms_any", "ms_shade", "ms_film", "ms_total")},
             "host_scene_build_s": round(t_build, 3),
         }

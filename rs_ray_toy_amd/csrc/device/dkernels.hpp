@@ -9,7 +9,9 @@ namespace rrtd {
 
 constexpr int kBlock = 256;
 // device counters, one 128-byte line each (atomics on different queues must not share an L2 line)
-enum { C_ACTIVE = 0, C_NEXT = 32, C_SHADOW = 64, C_CAMERA_RAYS = 96, C_ERROR = 128, C_WORK_CLOSEST = 160, C_WORK_SHADOW = 192, C_WORK_AUX = 224, C_SHADOW2 = 256, C_COUNT = 288 };
+enum { C_ACTIVE = 0, C_NEXT = 32, C_SHADOW = 64, C_CAMERA_RAYS = 96, C_ERROR = 128, C_WORK_CLOSEST = 160, C_WORK_SHADOW = 192, C_WORK_AUX = 224, C_SHADOW2 = 256,
+       // per-XCD work cursors of the persistent traversal kernels: 8 lines each (one cursor per eighth of the queue)
+       C_WORK8_CLOSEST = 288, C_WORK8_SHADOW = 544, C_COUNT = 800 };
 // shading kernels push to their queues once per block (measured: 256 <= 512 <= 1024 threads by 5 %: smaller blocks retire
 // and refill a CU sooner, and one atomic per 256 paths no longer serialises)
 template <typename R> struct ShadeBlock { static constexpr int n = 256; };
@@ -183,7 +185,9 @@ template <typename R> RRT_DEV uint32_t skip_plane_of(const SceneDev<R>& s, int s
 // sign and re-hits its own sphere at t ~ 0 whenever the stored hit point landed inside, i.e. for about half of the
 // spawned rays. The reference's pixels on spheres are that rounding noise. The f64 mode replays it bit for bit; the
 // fp32 mode deliberately keeps the same test (no self exclusion, unlike triangles), so it shows the same noise in
-// distribution (mean radiance within a few % of the oracle) though not pixel by pixel.
+// distribution (mean radiance within a few % of the oracle) though not pixel by pixel. (Tried in round 2 and dropped: solving the
+// quadric in double from a double-float hit point inside the fp32 mode. The means did not come closer - a point's coin is not one flip
+// but a chain over all later bounces at that point, which a 4e-9 origin does not replay - see DESIGN.md section 4.)
 template <typename R>
 struct SphereSI { V3<R> p, n, wo, sn, sdpdu; };
 // the parts of SurfaceInteraction only textured scenes read: uv, geometric dpdu / dpdv (compute_differentials),
@@ -1331,11 +1335,12 @@ static __global__ void k_rotate(uint32_t* c, int what) {
   else if (what == 3) { /* only the work counters */ }
   else if (what == 4) { c[C_NEXT] = 0; }
   // 5 / 6: the two halves of `0` when the shadow launch runs on its own stream beside the next closest-hit launch
-  else if (what == 5) { c[C_ACTIVE] = c[C_NEXT]; c[C_NEXT] = 0; c[C_WORK_CLOSEST] = 0; c[C_WORK_AUX] = 0; return; }
-  else if (what == 6) { c[C_SHADOW] = 0; c[C_WORK_SHADOW] = 0; return; }
-  else if (what == 7) { c[C_SHADOW2] = 0; c[C_WORK_SHADOW] = 0; return; }
+  else if (what == 5) { c[C_ACTIVE] = c[C_NEXT]; c[C_NEXT] = 0; c[C_WORK_CLOSEST] = 0; c[C_WORK_AUX] = 0; for (int k = 0; k < 8; k++) c[C_WORK8_CLOSEST + 32 * k] = 0; return; }
+  else if (what == 6) { c[C_SHADOW] = 0; c[C_WORK_SHADOW] = 0; for (int k = 0; k < 8; k++) c[C_WORK8_SHADOW + 32 * k] = 0; return; }
+  else if (what == 7) { c[C_SHADOW2] = 0; c[C_WORK_SHADOW] = 0; for (int k = 0; k < 8; k++) c[C_WORK8_SHADOW + 32 * k] = 0; return; }
   else { c[C_ACTIVE] = 0; c[C_NEXT] = 0; c[C_SHADOW] = 0; }
   c[C_WORK_CLOSEST] = 0; c[C_WORK_SHADOW] = 0; c[C_WORK_AUX] = 0;
+  for (int k = 0; k < 8; k++) { c[C_WORK8_CLOSEST + 32 * k] = 0; c[C_WORK8_SHADOW + 32 * k] = 0; }
 }
 static __global__ void k_accumulate_counts(uint32_t* c, unsigned long long* totals) {
   // totals[2] closest queries, totals[3] shadow queries, totals[4] camera rays

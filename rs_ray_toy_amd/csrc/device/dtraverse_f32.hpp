@@ -261,6 +261,10 @@ __global__ void __launch_bounds__(kTravBlock) k_trace_pairs_f32(TravScene ts, Po
 #ifndef RRT_PT_TREELET
 #define RRT_PT_TREELET 0
 #endif
+#ifndef RRT_XCD_WORK
+#define RRT_XCD_WORK 1
+#endif
+constexpr uint32_t kXcdParts = RRT_XCD_WORK ? 8u : 1u;   // parts of a queue with their own work cursor (8 XCDs)
 constexpr int kPtBlock = RRT_PT_BLOCK;
 constexpr int kPtStack = RRT_PT_STACK;
 constexpr int kPtTreelet = RRT_PT_TREELET;   // pair nodes of the BFS top of the tree kept in LDS by the persistent kernel (0 = none)
@@ -294,6 +298,8 @@ __global__ void __launch_bounds__(kPtBlock) k_trace_pt_f32(TravScene ts, Pools<f
   bool found = false;
   uint32_t lo = 0, hi = 0;      // wave-private range of reserved rays
   bool exhausted = false;       // wave-uniform
+  const uint32_t home = RRT_XCD_WORK ? (blockIdx.x & (kXcdParts - 1u)) : 0u;
+  uint32_t parts_done = 0;      // parts of the queue this wave has found empty
   // reservation grain: large enough to amortise the atomic, small enough that a short queue still spreads over
   // every resident wave (a wave that reserves 256 rays of a 100k-ray queue would serialise four ray chains)
   const uint32_t n_waves = gridDim.x * (kPtBlock / 64);
@@ -335,11 +341,20 @@ __global__ void __launch_bounds__(kPtBlock) k_trace_pt_f32(TravScene ts, Pools<f
     const uint32_t n_idle = (uint32_t)__popcll(idle);
     if (!exhausted && (n_idle >= RRT_TR_REFILL)) {
       if (lo == hi) {
-        uint32_t base = 0;
-        if (lane == 0) base = atomicAdd(work, grain);
-        base = __shfl(base, 0);
-        lo = base; hi = base + grain < n ? base + grain : n;
-        if (base >= n) { exhausted = true; lo = hi = 0; }
+        // XCD-aware work distribution (RRT_XCD_WORK): the queue is cut into 8 contiguous parts, one per group of workgroups that share an XCD
+        // (blockIdx % 8, MI355X_MICROARCH.md: blocks are dealt round-robin over the XCDs). The queues are roughly in image order (the camera
+        // kernel emits pixel block by pixel block, shading preserves the order), so a part's rays walk one region of the BVH, which then
+        // fits that XCD's 4 MiB L2 instead of all 8 L2s each holding a third of the 11 MB tree. A group that runs dry helps with the next part.
+        while (!exhausted) {
+          const uint32_t part = (home + parts_done) & (kXcdParts - 1u);
+          const uint32_t p_lo = (uint32_t)(((uint64_t)n * part) / kXcdParts), p_hi = (uint32_t)(((uint64_t)n * (part + 1u)) / kXcdParts);
+          uint32_t base = 0;
+          if (lane == 0) base = atomicAdd(work + 32u * part, grain);
+          base = __shfl(base, 0);
+          if (base < p_hi - p_lo) { lo = p_lo + base; hi = (p_hi - p_lo) - base < grain ? p_hi : lo + grain; break; }
+          parts_done++;
+          if (parts_done >= kXcdParts) { exhausted = true; lo = hi = 0; }
+        }
       }
       if (!exhausted) {
         const uint32_t take = (hi - lo) < n_idle ? (hi - lo) : n_idle;
@@ -818,7 +833,9 @@ static __global__ void __launch_bounds__(kRgDense) k_raygen_main_f32(SceneDev<fl
   rg_lens_to_lds(s, &lens, tid);
   if (tid < (uint32_t)s.n_lens) safe_s[tid] = safe_lim ? safe_lim[tid] : make_float2(0.0f, 0.0f);   // 16 c_i = 0: never safe
   __syncthreads();
-  const uint32_t pl = blockIdx.x * blockDim.x + tid, sl = blockIdx.y;
+  // grid: x = sample of the pass, y = pixel block - blocks are dispatched x first, so the survivors reach the queue pixel block by pixel
+  // block (all samples of 1 024 neighbouring pixels together): the queue is in image order, which the XCD-aware traversal relies on
+  const uint32_t pl = blockIdx.y * blockDim.x + tid, sl = blockIdx.x;
   bool alive = false;
   uint32_t slot = 0, index = 0;
   float pfx = 0, pfy = 0, lx = 0, ly = 0, w = 0;

@@ -1175,7 +1175,7 @@ class Handle : public HandleBase {
   void launch_raygen(const PassDesc& pd, uint32_t grid, double* dims_out, int enqueue) {
     if constexpr (std::is_same<R, float>::value) {
       const bool pt_ok = scene_.n_lens <= 32 && scene_.sampler_type == RRT_SAMPLER_HALTON && scene_.xres < 65536 && scene_.yres < 65536 && pd.ns <= 65535u;
-      if (raygen_pt_ >= 2 && pt_ok) {
+      if (raygen_pt_ >= 2 && pt_ok && (pd.npix + kRgDense - 1) / kRgDense <= 65535u) {
         const uint32_t total = pd.npix * pd.ns;
         if (pix_off_.n < 2 * (size_t)pd.npix) { HIP_CHECK(hipStreamSynchronize(st_)); pix_off_.alloc(2 * (size_t)pd.npix); }
         pool_.pix_off = pix_off_.p;
@@ -1185,7 +1185,7 @@ class Handle : public HandleBase {
         HIP_CHECK(hipMemsetAsync(pool_.weight, 0, (size_t)total * sizeof(R), st_));   // dead samples: weight 0 (Q2), nothing else is written for them
         {   // dense two-stage version with the lean lens arithmetic
           const float2* safe_r2 = (aux_margin_ && tex_depth_ == 0) ? reinterpret_cast<const float2*>(lens_safe_.p) : nullptr;   // textured scenes keep the auxiliary rays themselves (ray differentials)
-          hipLaunchKernelGGL(k_raygen_main_f32, dim3((pd.npix + kRgDense - 1) / kRgDense, pd.ns), dim3(kRgDense), 0, st_, scene_, pool_, pd, write_samp, dims_out, safe_r2, aux_delta_, aux_pupil_, enqueue);
+          hipLaunchKernelGGL(k_raygen_main_f32, dim3(pd.ns, (pd.npix + kRgDense - 1) / kRgDense), dim3(kRgDense), 0, st_, scene_, pool_, pd, write_samp, dims_out, safe_r2, aux_delta_, aux_pupil_, enqueue);
           hipLaunchKernelGGL(k_raygen_aux2_f32, dim3((total + kRgDense - 1) / kRgDense), dim3(kRgDense), 0, st_, scene_, pool_, enqueue);
           hipLaunchKernelGGL(k_rotate, dim3(1), dim3(1), 0, st_, counters_.p, 4);   // q_next was only a staging queue
         }
@@ -1262,7 +1262,7 @@ class Handle : public HandleBase {
         t2.overflow = any ? pt_overflow_any_.p : pt_overflow_.p;
         t2.overflow_stride = pt_grid_ * kPtBlock;
         const uint32_t g2 = std::max(1u, std::min(grid_in, pt_grid_));
-        uint32_t* work = &counters_.p[any ? C_WORK_SHADOW : C_WORK_CLOSEST];
+        uint32_t* work = &counters_.p[any ? C_WORK8_SHADOW : C_WORK8_CLOSEST];   // 8 cursors, one 128-B line each
         if (any) hipLaunchKernelGGL((k_trace_pt_f32<true>), dim3(g2), dim3(kPtBlock), 0, stream, t2, pool_, queue, count, n_fixed, work, occluded, lo_pt, 0xffffffffu);
         else hipLaunchKernelGGL((k_trace_pt_f32<false>), dim3(g2), dim3(kPtBlock), 0, stream, t2, pool_, queue, count, n_fixed, work, occluded, lo_pt, 0xffffffffu);
       }

@@ -734,6 +734,7 @@ def test_sphere_primitives_render(which, workdir):
     r.close()
     assert np.array_equal(film32[..., 3].astype(np.float64), ref[..., 3])
     ratio = film32[..., :3].mean() / ref[..., :3].mean()
+    print(f"spheres {which}: fp32 mean / oracle mean = {ratio:.4f}")
     assert abs(ratio - 1.0) < (0.15 if which == "cfg1" else 0.05), ratio
 
 
