@@ -738,6 +738,44 @@ def test_sphere_primitives_render(which, workdir):
     assert abs(ratio - 1.0) < (0.15 if which == "cfg1" else 0.05), ratio
 
 
+def test_fp32_difference_found_by_the_fuzz_sweep_is_one_sample_on_a_shared_edge():
+    """Fuzz seed 508 case 96 (tests/golden/fuzz508_96/: a tilted cube in a tilted box, a plastic whose roughness is a 3D checkerboard and a
+    textured mirror, StratifiedSampler, TriangleFilter, Path depth 1) was the one fp32 image over the sweep's bar: 8 pixels off by up to 0.14 of
+    the maximum. Traced (tools/trace_case.py): ONE camera sample, pixel (30, 30), whose ray meets the cube's front face
+    7.6e-6 (barycentric) from the diagonal shared by triangles 12 and 13. Moller-Trumbore's u, v carry an fp32 error of eps * |O - p0| / edge
+    ~ 1e-5 for a ray from 44 units away: both triangles reject it, the ray flies through the face and hits the back one (triangle 18,
+    2.15 units further); the triangle filter spreads that one sample over 8 pixels. The f64 mode accepts triangle 13 like the oracle.
+    The rule this test pins: with the box filter, every fp32 pixel outside 1e-4 holds a sample whose oracle hit lies within 5e-5
+    (barycentric) of a triangle edge - the reference's own non-watertight test (Q12) at fp32 resolution - and there are at most 2 such
+    pixels of 4 096; the f64 device mode has none."""
+    import json
+    root = os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden", "fuzz508_96")
+    cfg = json.load(open(os.path.join(root, "scene.json")))
+    cfg["Film"]["Filter"] = {"filter_type": "BoxFilter", "radius": [0.5, 0.5]}   # (the sampler dimensions do not depend on the filter)
+    sc = Scene.loads(cfg, root, flags=RRT_FIXED_BVH)
+    ref = O.render(sc)
+    scale = np.abs(ref[..., :3]).max()
+    r64 = Renderer(sc, 0, RRT_F64)
+    f64 = r64.render()
+    r64.close()
+    assert (np.abs(f64[..., :3] - O.render(sc, flat=True)[..., :3]).max() / scale) < 1e-9
+    r = Renderer(sc, 0, RRT_F32)
+    f32 = r.render().astype(np.float64)
+    d32 = np.abs(f32[..., :3] - ref[..., :3]).max(-1) / scale
+    bad = np.argwhere(d32 > 1e-4)
+    print("fuzz 508/96 with the box filter: fp32 pixels beyond 1e-4:", bad.tolist(), "max", d32.max())
+    assert len(bad) <= 2
+    ns = int(sc.desc.sampler.samples_per_pixel)
+    for y, x in bad:
+        _, rays, w = O.camera_samples(sc, (int(x), int(y), int(x) + 1, int(y) + 1), 1, ns)
+        live = w > 0
+        h = O.trace_closest(sc, rays[live, :3], rays[live, 3:], np.full(int(live.sum()), np.inf))
+        hit = h["prim"] >= 0
+        edge = np.minimum(np.minimum(h["u"], h["v"]), 1.0 - h["u"] - h["v"])[hit]
+        assert edge.min() < 5e-5, (x, y, edge)
+    r.close()
+
+
 def test_unsupported_and_panics(workdir):
     cfg, root = scenes.cfg2(workdir, xres=32, yres=32, nsamp=3)
     cfg["Integrator"] = {"integrator_type": "DirectLighting"}
