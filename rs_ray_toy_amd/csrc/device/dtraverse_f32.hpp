@@ -138,6 +138,12 @@ struct TravScene {
   uint32_t n_treelet;        // pair nodes [0, n_treelet) are the BFS top of the tree (host renumbering)
   uint32_t* overflow;        // stack entries >= kStackLds: [entry][thread of the launch], 2 words each
   uint32_t overflow_stride;
+  // Shadow rays (any-hit, t_max = 1 - 1e-4, unit direction: Q9) of the pool start ON a triangle and reach less than one unit far. Every
+  // ancestor of that triangle's leaf contains the origin, so its box test passes whatever the direction, and a sibling subtree whose box is
+  // more than a unit away from the leaf's box fails whatever the direction: the walk from the root down to the first ancestor with a NEAR
+  // sibling - half of the 47 box tests of an average shadow ray on the 100k-triangle mesh - decides nothing. any_entry[triangle] is that
+  // ancestor's pair node (host: build_pairs()); an occlusion query is order independent, so starting there changes no result. Null = off.
+  const uint32_t* any_entry;
 };
 
 // ANY = false: closest hit for rays in the pool's ray arrays -> pool hit arrays (through `queue` if given).
@@ -212,7 +218,8 @@ __global__ void __launch_bounds__(kTravBlock) k_trace_pairs_f32(TravScene ts, Po
       return;
     }
   };
-  {
+  if (ANY && !occluded && ts.any_entry && sk >= 0) { cur = ts.any_entry[sk]; state = ST_NODE; }   // (see TravScene::any_entry)
+  else {
     float tmin;
     if (ts.n_nodes != 0 && box_slabs_f32(ts.root_box[0], ts.root_box[1], ts.root_box[2], ts.root_box[3], ts.root_box[4], ts.root_box[5], r, &tmin) && tmin < r.tmax) {
       if (ts.root_n) { lf = ts.root_ref; ln = ts.root_n; state = ST_LEAF; }
@@ -394,7 +401,8 @@ __global__ void __launch_bounds__(kPtBlock) k_trace_pt_f32(TravScene ts, Pools<f
           r.neg = (r.ix < 0.0f ? 1u : 0u) | (r.iy < 0.0f ? 2u : 0u) | (r.iz < 0.0f ? 4u : 0u);
           sp = 0; hit = -1; hu = 0.0f; hv = 0.0f; found = false;
           float tmin;
-          if (ts.n_nodes != 0 && box_slabs_f32(ts.root_box[0], ts.root_box[1], ts.root_box[2], ts.root_box[3], ts.root_box[4], ts.root_box[5], r, &tmin) && tmin < r.tmax) {
+          if (ANY && !occluded && ts.any_entry && sk >= 0) { cur = ts.any_entry[sk]; state = ST_NODE; }   // (see TravScene::any_entry)
+          else if (ts.n_nodes != 0 && box_slabs_f32(ts.root_box[0], ts.root_box[1], ts.root_box[2], ts.root_box[3], ts.root_box[4], ts.root_box[5], r, &tmin) && tmin < r.tmax) {
             if (ts.root_n) { lf = ts.root_ref; ln = ts.root_n; state = ST_TRI; }
             else { cur = ts.root_ref; state = ST_NODE; }
           } else finish();

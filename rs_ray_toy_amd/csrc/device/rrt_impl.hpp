@@ -365,6 +365,7 @@ class Handle : public HandleBase {
     else if (key == "overlap_shadow") overlap_shadow_ = v != 0;
     else if (key == "aux_margin") aux_margin_ = v != 0;
     else if (key == "frame_stats") frame_stats_ = v != 0;
+    else if (key == "any_entry") { any_entry_on_ = v != 0; trav_.any_entry = (any_entry_on_ && any_entry_.n) ? any_entry_.p : nullptr; }
     else if (key == "nonblocking_streams") {   // see rrt.h: needed for two handles to overlap their frames
       if (pending_) throw std::invalid_argument("nonblocking_streams: a frame is in flight");
       HIP_CHECK(hipSetDevice(dev_));
@@ -722,6 +723,9 @@ class Handle : public HandleBase {
   int trav_mode_ = 3;   // 1 = LDS-treelet grid-stride kernel, 2 = persistent-thread kernel, 3 = by queue size
   uint32_t pt_split_closest_ = 100000u, pt_split_any_ = 100000u;   // re-tuned with the shadow launches overlapped (tools/band_scaling.py)
   DevBuf<uint32_t> pt_overflow_, pt_overflow_any_;
+  DevBuf<uint32_t> any_entry_;             // TravScene::any_entry
+  bool any_entry_on_ = true;
+  std::vector<uint32_t> newidx_keep_;      // build_pairs(): BFS renumbering of the pair nodes
   DevBuf<uint32_t> pix_off_;
   TravScene trav_{};
   DevBuf<PairNode> pairs_;
@@ -1317,6 +1321,7 @@ class Handle : public HandleBase {
         for (uint32_t k = 0; k < n_int; k++) if (!taken[k]) order.push_back(k);
         std::vector<uint32_t> newidx(n_int);
         for (uint32_t i = 0; i < n_int; i++) newidx[order[i]] = i;
+        newidx_keep_ = newidx;
         std::vector<PairNode> re(n_int);
         for (uint32_t i = 0; i < n_int; i++) {
           PairNode pn = pairs[order[i]];
@@ -1326,8 +1331,55 @@ class Handle : public HandleBase {
         }
         pairs.swap(re);
       } else trav_.n_treelet = 0;
+      // any-hit entry nodes (TravScene::any_entry): per leaf, the first ancestor on the way down from the root whose OTHER child's box is
+      // within reach of a shadow ray (1 - 1e-4 long, Q9; 1.02 with room for the fp32 box rounding, the test's widening and |d| = 1 +- 1e-6)
+      std::vector<uint32_t> entry(n_tris, 0u);
+      if (n_int > 0 && (nodes[0].meta >> 2) == 0) {
+        std::vector<uint32_t> pair_of(nodes.size(), 0xffffffffu);   // linear interior node -> pair node id as the kernels index them
+        {
+          std::vector<uint32_t> renum(n_int);
+          bool renumbered = trav_.n_treelet > 0;
+          for (uint32_t k = 0; k < n_int; k++) renum[k] = k;
+          if (renumbered) renum = newidx_keep_;
+          for (size_t i = 0; i < nodes.size(); i++) if ((nodes[i].meta >> 2) == 0) pair_of[i] = renum[compact[i]];
+        }
+        auto box_dist2 = [&](const Node<R>& a, const Node<R>& b) {
+          double d2 = 0;
+          for (int k = 0; k < 3; k++) { const double g = std::max(0.0, std::max((double)a.bmin[k] - (double)b.bmax[k], (double)b.bmin[k] - (double)a.bmax[k])); d2 += g * g; }
+          return d2;
+        };
+        const double reach2 = 1.02 * 1.02;
+        // iterative pre-order walk carrying the path of (interior node, on-path child is its second child)
+        struct Step { uint32_t node; uint32_t depth; };
+        std::vector<uint32_t> path;   // interior nodes from the root to the current node's parent
+        std::vector<Step> todo{{0u, 0u}};
+        while (!todo.empty()) {
+          const Step st = todo.back(); todo.pop_back();
+          path.resize(st.depth);
+          const Node<R>& nd = nodes[st.node];
+          const uint32_t np = nd.meta >> 2;
+          if (np == 0) {
+            path.push_back(st.node);
+            todo.push_back({nd.offset, st.depth + 1});
+            todo.push_back({st.node + 1, st.depth + 1});
+            continue;
+          }
+          // leaf: first ancestor (from the root) whose off-path child is near; its parent if none is
+          uint32_t e = path.empty() ? 0u : path.back();
+          for (size_t k = 0; k < path.size(); k++) {
+            const uint32_t a = path[k];
+            const uint32_t on = (k + 1 < path.size()) ? path[k + 1] : st.node;
+            const uint32_t c0 = a + 1, c1 = nodes[a].offset;
+            const uint32_t off = on == c0 ? c1 : c0;
+            if (box_dist2(nodes[off], nd) <= reach2) { e = a; break; }
+          }
+          for (uint32_t t = 0; t < np; t++) if ((size_t)nd.offset + t < n_tris) entry[nd.offset + t] = pair_of[e];
+        }
+        any_entry_.upload(entry, st_);
+      }
       pairs_.upload(pairs, st_);
       HIP_CHECK(hipStreamSynchronize(st_));
+      trav_.any_entry = (any_entry_on_ && any_entry_.n) ? any_entry_.p : nullptr;
       trav_.pairs = pairs_.p;
       trav_.tris = reinterpret_cast<const float*>(tris_.p);
       for (int k = 0; k < 3; k++) { trav_.root_box[k] = nodes[0].bmin[k]; trav_.root_box[3 + k] = nodes[0].bmax[k]; }

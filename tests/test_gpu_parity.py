@@ -446,6 +446,34 @@ def test_non_rigid_triangle_instances(which, workdir):
     assert (d32 < 1e-3).mean() > 0.97 and abs(f32[..., :3].mean() / ref_o[..., :3].mean() - 1.0) < 0.02
 
 
+@pytest.mark.parametrize("which", ["cfg4", "cfg5", "cfg2", "cfg3_direct"])
+def test_any_hit_entry_nodes_change_nothing(which, workdir):
+    """Shadow rays are 1 - 1e-4 long (Q9) and start on a triangle: the fp32 any-hit kernels start them at the first ancestor of that
+    triangle's leaf whose other child is within reach, instead of at the root (TravScene::any_entry) - every ancestor contains the origin
+    and passes its box test, every skipped sibling is more than a unit away and fails it, and an occlusion query does not depend on the
+    order. Bar: frames with and without the shortcut are identical bit for bit, query counts included."""
+    if which == "cfg4": cfg, root = scenes.cfg4(workdir, xres=128, yres=128, nsamp=9, max_depth=6, n=96)
+    elif which == "cfg5": cfg, root = scenes.cfg5(workdir, xres=96, yres=96, nsamp=9, max_depth=6, n=64)
+    elif which == "cfg2": cfg, root = scenes.cfg2(workdir, xres=128, yres=128, nsamp=9, max_depth=4)
+    else:
+        cfg, root = scenes.cfg3(workdir, xres=128, yres=128, nsamp=9)
+        cfg["Integrator"] = {"integrator_type": "DirectLighting", "light_strategy": "all", "max_depth": 3}
+    sc = Scene.loads(cfg, root, flags=RRT_FIXED_BVH)
+    r = Renderer(sc, 0, RRT_F32)
+    r.set_option("persistent_traversal", 2)            # the persistent-thread kernel whatever the queue size ...
+    a, st_a = r.render(stats=True)
+    r.set_option("any_entry", 0)
+    b, st_b = r.render(stats=True)
+    r.set_option("persistent_traversal", 1)            # ... and the grid-stride one
+    c = r.render()
+    r.set_option("any_entry", 1)
+    d = r.render()
+    r.close()
+    assert st_a.any_queries == st_b.any_queries and st_a.any_queries > 1000
+    assert np.array_equal(a, b) and np.array_equal(c, d)
+    assert a[..., :3].max() > 0
+
+
 AUX_CASES = {
     "cfg2_640x360": lambda wd: scenes.cfg2(wd, xres=640, yres=360, nsamp=9, max_depth=2),
     "cfg2_tiny_film": lambda wd: scenes.cfg2(wd, xres=24, yres=16, nsamp=65, max_depth=2),     # 0.05 px is 70 um of film here
