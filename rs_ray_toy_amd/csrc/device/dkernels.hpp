@@ -1358,10 +1358,15 @@ template <typename R>
 __global__ void __launch_bounds__(kBlock) k_film_box(SceneDev<R> s, Pools<R> p, PassDesc pd, R* film) {
   const uint32_t pl = blockIdx.x * blockDim.x + threadIdx.x;
   if (pl >= pd.npix) return;
-  R cr = R(0), cg = R(0), cb = R(0), wsum = R(0);
   uint32_t px_, py_;
   pass_pixel(pd, pd.pix_begin + pl, &px_, &py_);
   const uint32_t pix = py_ * (uint32_t)s.xres + px_;
+  // The handle's internal film holds the pixel's running contribution sum as RGB + weight (FilmTilePixel film.rs:22-27): the samples of every
+  // pool pass are added to it one by one, in sample order, so the sum does not depend on how the samples were cut into passes (a frame and
+  // its band partition agree bit for bit also when they need different numbers of passes); k_film_add converts to XYZ once, as
+  // merge_film_tile does (film.rs:248-263).
+  R* px = film + 4 * (size_t)pix;
+  R cr = px[0], cg = px[1], cb = px[2], wsum = px[3];
   constexpr uint32_t kBatch = 8;   // independent loads in flight per thread: a band of a frame has too few pixels to hide the latency otherwise
   auto add = [&](R w, const typename Vec4T<R>::type& l) {
     Rgb<R> L;
@@ -1392,12 +1397,7 @@ __global__ void __launch_bounds__(kBlock) k_film_box(SceneDev<R> s, Pools<R> p, 
     if (w > R(0)) l = p.L[sl * pd.npix + pl];
     add(w, l);
   }
-  // rgb_to_xyz spectrum.rs:2084-2090; filter_weight_sum is added three times per merged tile pixel (Q3)
-  R* px = film + 4 * (size_t)pix;
-  px[0] += R(0.412453) * cr + R(0.357580) * cg + R(0.180423) * cb;
-  px[1] += R(0.212671) * cr + R(0.715160) * cg + R(0.072169) * cb;
-  px[2] += R(0.019334) * cr + R(0.119193) * cg + R(0.950227) * cb;
-  px[3] += wsum; px[3] += wsum; px[3] += wsum;
+  px[0] = cr; px[1] = cg; px[2] = cb; px[3] = wsum;
 }
 
 // Filters wider than one pixel (TriangleFilter / GaussianFilter / wide BoxFilter, film.rs:77-130 with the 16x16
@@ -1420,7 +1420,8 @@ __global__ void __launch_bounds__(kBlock) k_film_wide(SceneDev<R> s, Pools<R> p,
   const uint32_t t = blockIdx.x * blockDim.x + threadIdx.x;
   if (t >= (uint32_t)ew * (uint32_t)eh) return;
   const int x = ex0 + (int)(t % (uint32_t)ew), y = ey0 + (int)(t / (uint32_t)ew);
-  R cr = R(0), cg = R(0), cb = R(0), wsum = R(0);
+  R* px = film + 4 * ((size_t)y * (size_t)s.xres + (size_t)x);
+  R cr = px[0], cg = px[1], cb = px[2], wsum = px[3];   // running RGB + weight sums (see k_film_box)
   const R inv_rx = s.filter_inv_rx, inv_ry = s.filter_inv_ry;
   for (int sy = y - reach_y; sy <= y + reach_y; sy++) {
     if (sy < 0 || sy >= ymax) continue;
@@ -1450,17 +1451,21 @@ __global__ void __launch_bounds__(kBlock) k_film_wide(SceneDev<R> s, Pools<R> p,
       }
     }
   }
-  R* px = film + 4 * ((size_t)y * (size_t)s.xres + (size_t)x);
+  px[0] = cr; px[1] = cg; px[2] = cb; px[3] = wsum;
+}
+
+// Film::merge_film_tile (film.rs:248-263): the pixel's RGB contribution sum -> XYZ (rgb_to_xyz spectrum.rs:2084-2090), added to the
+// caller's film; filter_weight_sum is added three times per merged pixel (Q3). `n` = pixels.
+template <typename R>
+__global__ void k_film_add(const R* src, R* dst, size_t n) {
+  const size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+  if (i >= n) return;
+  const R cr = src[4 * i], cg = src[4 * i + 1], cb = src[4 * i + 2], wsum = src[4 * i + 3];
+  R* px = dst + 4 * i;
   px[0] += R(0.412453) * cr + R(0.357580) * cg + R(0.180423) * cb;
   px[1] += R(0.212671) * cr + R(0.715160) * cg + R(0.072169) * cb;
   px[2] += R(0.019334) * cr + R(0.119193) * cg + R(0.950227) * cb;
   px[3] += wsum; px[3] += wsum; px[3] += wsum;
-}
-
-template <typename R>
-__global__ void k_film_add(const R* src, R* dst, size_t n) {
-  size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
-  if (i < n) dst[i] += src[i];
 }
 
 }  // namespace rrtd

@@ -162,16 +162,13 @@ RRT_DEV uint32_t block_rank(bool pred, uint32_t* lds, uint32_t* total) {
 }
 
 // ---- Halton (samplers/halton.rs, lowdiscrepancy.rs); values are produced in f64 in both modes ---------
-// a / base, exact. The sample index exceeds 2^26 on the headline config (stride 2^10 * 3^7, 257 samples), where a
-// hardware-less 32-bit division costs ~40 instructions per digit of every dimension: a double-precision reciprocal
-// (relative error 2^-53 against the 2^-45 needed) plus a one-step correction is exact and 5 instructions.
-RRT_DEV uint32_t div_base(uint32_t a, const HaltonDim& hd, uint32_t fast) {
-  if (fast || a < (1u << 26)) return (uint32_t)(((uint64_t)a * hd.magic) >> 40);   // (every digit after the first: a has shrunk below 2^26)
-  uint32_t q = (uint32_t)((double)a * hd.inv);
-  const uint32_t r = a - q * hd.base;          // wraps when q is one too large
-  if ((int32_t)r < 0) q -= 1;
-  else if (r >= hd.base) q += 1;
-  return q;
+// a / base, exact for every 32-bit a: division by an invariant integer with a 33-bit magic number (Granlund & Montgomery 1994, fig. 4.1):
+// l = ceil(log2 base), m' = floor(2^32 (2^l - base) / base) + 1, t = mulhi(m', a), q = (t + ((a - t) >> 1)) >> (l - 1). One multiply-high
+// and four cheap operations per digit; the first version multiplied by a 41-bit magic in 64 bits (five quarter-rate multiplies) and
+// needed an f64 reciprocal for a >= 2^26. hd.magic = m' | (l - 1) << 32, built on the host.
+RRT_DEV uint32_t div_base(uint32_t a, const HaltonDim& hd, uint32_t /*fast*/) {
+  const uint32_t t = __umulhi((uint32_t)hd.magic, a);
+  return (t + ((a - t) >> 1)) >> (uint32_t)(hd.magic >> 32);
 }
 // radical_inverse_specialized lowdiscrepancy.rs:188-202
 RRT_DEV double radical_inverse_dev(uint32_t a, const HaltonDim& hd, uint32_t fast) {
@@ -234,6 +231,39 @@ RRT_DEV double halton_cam_dim(const SceneDev<R>& s, uint32_t index, int which) {
     k++;
   }
   return fmin(s.cam_invpow[which][k] * ((double)reversed + s.cam_tail[which]), 0.99999999999999989);
+}
+// The four camera dimensions of a Halton sample for the fp32 camera kernel: the bases are the first primes (2, 3, 5, 7) whatever the scene,
+// so a / base is a multiply-high by a constant plus shifts, exact for every 32-bit a (Granlund-Montgomery), and q * base a shift-add -
+// a third of the instructions of the general digit loop (64-bit magic products / an f64 reciprocal per digit). Digits, permutations and
+// the f64 values are those of halton_dim() / halton_cam_dim(): the products inv_base^k come from tables built with the same
+// multiplications (SceneDev::cam_invpow, inv3pow).
+RRT_DEV uint32_t div3(uint32_t a) { return __umulhi(a, 0xAAAAAAABu) >> 1; }
+RRT_DEV uint32_t div5(uint32_t a) { return __umulhi(a, 0xCCCCCCCDu) >> 2; }
+RRT_DEV uint32_t div7(uint32_t a) { const uint32_t q = __umulhi(a, 0x24924925u); return (((a - q) >> 1) + q) >> 2; }
+template <typename R>
+RRT_DEV void halton_cam4(const SceneDev<R>& s, uint32_t index, double* d0, double* d1, double* d2, double* d3) {
+  if (s.sample_at_center) { *d0 = 0.5; *d1 = 0.5; }
+  else {
+    *d0 = (double)__brev(index >> s.base_exp0) * 2.3283064365386963e-10;
+    uint32_t a = (uint32_t)((double)index * s.inv_base_scale1), rev = 0, k = 0;   // index / 3^base_exponents[1], exact after the fix-up (cf. div_base())
+    { const uint32_t r = index - a * s.base_scale1; if ((int32_t)r < 0) a -= 1u; else if (r >= s.base_scale1) a += 1u; }
+    while (a != 0) { const uint32_t q = div3(a); rev = rev * 3u + (a - q * 3u); a = q; k++; }
+    *d1 = fmin((double)rev * s.inv3pow[k], 0.99999999999999989);
+  }
+  {
+    const uint32_t packed = s.cam_perm[0];
+    uint64_t reversed = 0;
+    uint32_t a = index, k = 0;
+    while (a != 0) { const uint32_t q = div5(a), digit = a - q * 5u; reversed = reversed * 5u + ((packed >> (3u * digit)) & 7u); a = q; k++; }
+    *d2 = fmin(s.cam_invpow[0][k] * ((double)reversed + s.cam_tail[0]), 0.99999999999999989);
+  }
+  {
+    const uint32_t packed = s.cam_perm[1];
+    uint64_t reversed = 0;
+    uint32_t a = index, k = 0;
+    while (a != 0) { const uint32_t q = div7(a), digit = a - q * 7u; reversed = reversed * 7u + ((packed >> (3u * digit)) & 7u); a = q; k++; }
+    *d3 = fmin(s.cam_invpow[1][k] * ((double)reversed + s.cam_tail[1]), 0.99999999999999989);
+  }
 }
 // ---- StratifiedSampler (samplers/stratified.rs, samplers/mod.rs:191-227) ---------------------------------------------
 // The reference fills, per pixel and per sampled dimension, an array of jittered strata and Fisher-Yates-shuffles it,

@@ -873,7 +873,8 @@ static __global__ void __launch_bounds__(kRgDense) k_raygen_main_f32(SceneDev<fl
     const uint2 po = reinterpret_cast<const uint2*>(p.pix_off)[pl];
     const uint32_t px = po.y & 0xffffu, py = po.y >> 16;
     index = po.x + (pd.s_begin + sl) * s.stride;
-    const double d0 = halton_dim(s, index, 0), d1 = halton_dim(s, index, 1), d2 = halton_cam_dim(s, index, 0), d3 = halton_cam_dim(s, index, 1);
+    double d0, d1, d2, d3;
+    halton_cam4(s, index, &d0, &d1, &d2, &d3);
     pfx = (float)px + to_real<float>(d0); pfy = (float)py + to_real<float>(d1);
     lx = to_real<float>(d2) + 0.5f; ly = to_real<float>(d3) + 0.5f;   // Q5
     if (write_samp) p.samp[slot] = make_float4(pfx, pfy, lx, ly);

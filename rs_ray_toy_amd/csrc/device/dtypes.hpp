@@ -117,7 +117,7 @@ struct LensElem { R curvature_radius, thickness, eta, aperture_radius; };
 struct HaltonDim {   // one entry per sampler dimension >= 2
   uint32_t base;
   uint32_t perm_offset;   // PRIME_SUMS[dim]
-  uint64_t magic;         // floor(2^40 / base) + 1 : exact a / base for a < 2^26, base <= 8192
+  uint64_t magic;         // m' | (l - 1) << 32 of div_base(): exact a / base for every 32-bit a
   double inv;             // 1 / base: a / base for any 32-bit a = (uint32_t)(a * inv) with a +-1 fix-up (div_base())
   double tail;            // inv * perm[0] / (1 - inv): the infinitely many trailing zero digits of the scrambled radical inverse
 };
@@ -170,6 +170,8 @@ struct SceneDev {
   uint32_t cam_perm[2];
   double cam_invpow[2][16];
   double cam_tail[2];          // inv_base * perm[0] / (1 - inv_base)
+  double inv_base_scale1;      // 1 / base_scale1
+  double inv3pow[24];          // (1/3)^k by the reference's running product (radical_inverse of dimension 1, lowdiscrepancy.rs:188-202)
   // integrator
   int32_t integrator, max_depth, light_strategy;
   R rr_threshold;

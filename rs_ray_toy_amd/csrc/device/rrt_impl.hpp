@@ -657,15 +657,19 @@ class Handle : public HandleBase {
     }
     if (timing) HIP_CHECK(hipEventRecord(fr->ev_end, st_));
     // merge into the caller's film (+=)
-    const size_t nfilm = W * H * 4;
+    const size_t nfilm = W * H * 4, npx = W * H;
     if (film_mem == RRT_MEM_DEVICE) {
-      hipLaunchKernelGGL((k_film_add<R>), dim3((uint32_t)((nfilm + kBlock - 1) / kBlock)), dim3(kBlock), 0, st_, (const R*)film_.p, (R*)film_user, nfilm);
+      hipLaunchKernelGGL((k_film_add<R>), dim3((uint32_t)((npx + kBlock - 1) / kBlock)), dim3(kBlock), 0, st_, (const R*)film_.p, (R*)film_user, npx);
       HIP_CHECK(hipGetLastError());
       if (defer_) { frame_ = std::move(fr); return; }   // render_end() synchronises, checks the error flags and reads the statistics
       HIP_CHECK(hipStreamSynchronize(st_));
     } else {
+      if (film_xyz_.n != nfilm) film_xyz_.alloc(nfilm);
+      HIP_CHECK(hipMemsetAsync(film_xyz_.p, 0, nfilm * sizeof(R), st_));
+      hipLaunchKernelGGL((k_film_add<R>), dim3((uint32_t)((npx + kBlock - 1) / kBlock)), dim3(kBlock), 0, st_, (const R*)film_.p, film_xyz_.p, npx);
+      HIP_CHECK(hipGetLastError());
       std::vector<R> tmp(nfilm);
-      HIP_CHECK(hipMemcpyAsync(tmp.data(), film_.p, nfilm * sizeof(R), hipMemcpyDeviceToHost, st_));
+      HIP_CHECK(hipMemcpyAsync(tmp.data(), film_xyz_.p, nfilm * sizeof(R), hipMemcpyDeviceToHost, st_));
       HIP_CHECK(hipStreamSynchronize(st_));
       R* dst = (R*)film_user;
       for (size_t i = 0; i < nfilm; i++) dst[i] += tmp[i];
@@ -753,7 +757,8 @@ class Handle : public HandleBase {
   DevBuf<R> rpool_;
   DevBuf<uint32_t> upool_, counters_, deep_stack_;
   DevBuf<unsigned long long> totals_;
-  DevBuf<R> film_;
+  DevBuf<R> film_;       // per pixel: running RGB contribution sum + filter weight sum of the frame being rendered
+  DevBuf<R> film_xyz_;   // the same merged to XYZ, staging for a host film
 
   // which materials the aggregate really uses (declared-but-unused ones never reach a kernel)
   void scan_materials(const rrt_scene_desc* d) {
@@ -1030,7 +1035,7 @@ class Handle : public HandleBase {
       for (uint32_t c = 2; n < 1000; c++) {
         bool prime = true;
         for (uint32_t q = 2; q * q <= c; q++) if (c % q == 0) { prime = false; break; }
-        if (prime) { hd[n].base = c; hd[n].perm_offset = acc; hd[n].magic = ((1ull << 40) / c) + 1ull; hd[n].inv = 1.0 / (double)c; acc += c; n++; }
+        if (prime) { hd[n].base = c; hd[n].perm_offset = acc; { uint32_t l = 0; while ((1ull << l) < c) l++; const uint64_t mp = ((1ull << 32) * ((1ull << l) - c)) / c + 1ull; hd[n].magic = (mp & 0xffffffffull) | ((uint64_t)(l - 1) << 32); } hd[n].inv = 1.0 / (double)c; acc += c; n++; }
       }
     }
     std::vector<uint16_t> perms;
@@ -1073,6 +1078,8 @@ class Handle : public HandleBase {
     s.base_scale0 = (uint32_t)d->sampler.base_scales[0]; s.base_scale1 = (uint32_t)d->sampler.base_scales[1];
     s.stride = (uint32_t)d->sampler.sample_stride; s.mult_inv0 = (uint32_t)d->sampler.mult_inverse[0]; s.mult_inv1 = (uint32_t)d->sampler.mult_inverse[1];
     s.fast_div = (d->sampler.sample_stride * (d->sampler.samples_per_pixel + 1) < (1ull << 26)) ? 1u : 0u;
+    s.inv_base_scale1 = 1.0 / (double)std::max<uint32_t>(1u, s.base_scale1);
+    { double v = 1.0; const double inv3 = hd[1].inv; for (int k = 0; k < 24; k++) { s.inv3pow[k] = v; v *= inv3; } }
     for (int w = 0; w < 2; w++) {   // lens dims 2, 3: bases hd[2].base = 5, hd[3].base = 7
       const uint32_t base = hd[2 + w].base;
       uint32_t packed = 0;

@@ -507,6 +507,39 @@ def test_aux_margins_change_nothing(which, workdir):
     assert film_on[..., :3].max() > 0
 
 
+def test_full_size_cfg5_frame_properties(workdir):
+    """BASELINE config 5 at its full size (100 352 + 6 272 triangles, Plastic + Metal microfacets, 4 sphere area lights, 2048^2, 1024 spp,
+    depth 16: 4.29 G camera samples in 16 pool passes, ~1 s per frame), fp32 product path, through size-independent properties: the
+    closed-form filter weight sum 3 * (nsamp - 1) in every pixel (Q1, Q2, Q3), finite non-negative values, idempotence (bitwise), a 2-rank
+    band partition that reassembles the frame exactly, and a 16-row slice at full spp against the f64 oracle."""
+    cfg, root = scenes.cfg5(workdir)
+    sc = Scene.loads(cfg, root, flags=RRT_FIXED_BVH)
+    assert sc.resolution == (2048, 2048) and int(sc.desc.sampler.samples_per_pixel) == 1025 and sc.desc.integrator.max_depth == 16
+    r = Renderer(sc, 0, RRT_F32)
+    film, st = r.render(stats=True)
+    assert st.camera_samples == 2048 * 2048 * 1024
+    assert 0.25 < st.camera_rays / st.camera_samples < 0.36
+    assert np.all(film[..., 3] == 3.0 * 1024.0)
+    assert np.isfinite(film).all() and film[..., :3].max() > 0 and film[..., 1].min() >= 0
+    again = r.render()
+    assert np.array_equal(again, film)
+    bands = r.render_bands(0, 2)
+    r.render_bands(1, 2, film=bands)
+    assert np.array_equal(bands, film)
+    rect = (768, 1024, 1280, 1040)      # 512 x 16 pixels at 1 024 spp: 8.4 M camera samples for the oracle
+    ref = O.render(sc, rect)
+    part = r.render(rect)
+    r.close()
+    y0, y1, x0, x1 = rect[1], rect[3], rect[0], rect[2]
+    scale = np.abs(ref[y0:y1, x0:x1, :3]).max()
+    diff = np.abs(part[y0:y1, x0:x1, :3].astype(np.float64) - ref[y0:y1, x0:x1, :3]).max(-1) / scale
+    assert np.array_equal(part[y0:y1, x0:x1, 3], ref[y0:y1, x0:x1, 3])
+    print("full-size cfg5 fp32 vs oracle: within 1e-4: %.4f, max %.3e, mean %.3e" % ((diff < 1e-4).mean(), diff.max(), diff.mean()))
+    # 1 024 samples per pixel, depth 16, glossy lobes: a flipped discrete decision moves a pixel by one sample's share (1e-3 of a bright
+    # sample); the bar is the one of the config-4 frame, scaled to the deeper paths
+    assert (diff < 1e-3).mean() > 0.97 and diff.mean() < 2e-4, ((diff < 1e-3).mean(), diff.mean())
+
+
 WIDE_FILTERS = {
     "triangle": {"filter_type": "TriangleFilter", "radius": [2.0, 2.0]},
     "gaussian": {"filter_type": "GaussianFilter", "radius": [2.0, 2.0], "alpha": 2.0},
