@@ -188,10 +188,6 @@ template <typename R> RRT_DEV uint32_t skip_plane_of(const SceneDev<R>& s, int s
 // distribution (mean radiance within a few % of the oracle) though not pixel by pixel. (Tried in round 2 and dropped: solving the
 // quadric in double from a double-float hit point inside the fp32 mode. The means did not come closer - a point's coin is not one flip
 // but a chain over all later bounces at that point, which a 4e-9 origin does not replay - see DESIGN.md section 4.)
-#ifndef RRT_SPHERE_F64
-#define RRT_SPHERE_F64 0
-#endif
-constexpr bool kSphereF64 = RRT_SPHERE_F64 != 0;   // experiment: sphere code of the fp32 mode in double (see the note above)
 template <typename R>
 struct SphereSI { V3<R> p, n, wo, sn, sdpdu; };
 // the parts of SurfaceInteraction only textured scenes read: uv, geometric dpdu / dpdv (compute_differentials),
@@ -250,12 +246,6 @@ RRT_DEV void sphere_surface(const SphereDev<R>& S, V3<R> wo_, V3<R> wd_, R th, R
   V3<R> ro, rd, oo, od;
   sphere_rays(S, wo_, wd_, &ro, &rd, &oo, &od);
   V3<R> ph;
-#ifdef RRT_SPHERE_KEEP_POINT
-  // fp32 mode: a re-hit of the sphere the ray starts on lies 1e-15 along the ray in the reference - o + d * t is the origin again, bit for bit,
-  // so the point keeps its side of the surface (the coin above) for every later bounce. In fp32 the re-hit lies ~1e-6 away, o + d * t rounds
-  // to a NEW point with a new coin: paths that need several good coins in a row (through rough glass) escape far too often. Keep the point.
-  if (sizeof(R) == 4 && branch == R(0) && th < R(1e-4) * S.radius) th = R(0);
-#endif
   if (branch == R(0)) ph = ro + rd * th;
   else { ph = oo + od * th; ph = ph * (S.radius / len(ph)); }
   if (ph.x == R(0) && ph.y == R(0)) ph.x = R(1e-5) * S.radius;
@@ -331,14 +321,6 @@ RRT_DEV int traverse_closest(const SceneDev<R>& s, RayCtx<R>& r, Stack& st, int 
           R t, u, v;
           const Tri<R> tr = s.tris[nd.offset + i];
           if (tr.plane == kSphereMark) {
-            if (sizeof(R) == 4 && kSphereF64) {   // the sphere in double; the hit record keeps t as t_hi (in t) + t_lo (in v)
-              double td, bd;
-              const V3<double> od((double)r.o.x + (double)r.lo.x, (double)r.o.y + (double)r.lo.y, (double)r.o.z + (double)r.lo.z), dd((double)r.d.x, (double)r.d.y, (double)r.d.z);
-              if (sphere_prim_hit<double, false>(s.spheres_d[tr.shade], od, dd, &td, &bd)) {
-                r.tmax = (R)td; hit = (int)(nd.offset + i); *hu = (R)bd; *hv = (R)(td - (double)(R)td);
-              }
-              continue;
-            }
             if (sphere_prim_hit<R, false>(s.spheres[tr.shade], r.o, r.d, &t, &u)) { r.tmax = t; hit = (int)(nd.offset + i); *hu = u; *hv = R(0); }   // u carries the root branch
             continue;
           }
@@ -380,12 +362,6 @@ RRT_DEV bool traverse_any(const SceneDev<R>& s, const RayCtx<R>& r, Stack& st, i
           cp++;
           const Tri<R> tr = s.tris[nd.offset + i];
           if (tr.plane == kSphereMark) {
-            if (sizeof(R) == 4 && kSphereF64) {
-              double td, bd;
-              const V3<double> od((double)r.o.x + (double)r.lo.x, (double)r.o.y + (double)r.lo.y, (double)r.o.z + (double)r.lo.z), dd((double)r.d.x, (double)r.d.y, (double)r.d.z);
-              if (sphere_prim_hit<double, true>(s.spheres_d[tr.shade], od, dd, &td, &bd)) { found = true; break; }
-              continue;
-            }
             R t, br;
             if (sphere_prim_hit<R, true>(s.spheres[tr.shade], r.o, r.d, &t, &br)) { found = true; break; }
             continue;
@@ -486,7 +462,7 @@ __global__ void __launch_bounds__(kBlock) k_unpack_hits(Pools<R> p, const Tri<R>
   const int32_t pr = (int32_t)real_to_bits(h.y);
   t[i] = h.x; prim[i] = pr;
   if (u) u[i] = (pr >= 0 && tris[pr].plane == kSphereMark) ? R(0) : h.z;   // sphere hits keep their root branch there internally
-  if (v) v[i] = (pr >= 0 && tris[pr].plane == kSphereMark) ? R(0) : h.w;   // (the sphere experiment keeps the low word of t there)
+  if (v) v[i] = h.w;
 }
 
 // Public any-hit on caller rays (rrt_trace_any): rays live in the closest-ray arrays of the pool.
@@ -674,29 +650,9 @@ RRT_DEV void spawn_point(V3<R> o, V3<R> d, R t, R u, R v, V3<R> p0, V3<R> p1, V3
 
 // Triangle::intersect's SurfaceInteraction (shape/triangle.rs:267-390) rebuilt from (triangle, t, u, v)
 template <typename R>
-RRT_DEV Surf<R> build_surface(const SceneDev<R>& s, int prim, V3<R> o, V3<R> d, R t, R u, R v, SurfExt<R>* ext = nullptr, V3<R> o_lo = V3<R>()) {
+RRT_DEV Surf<R> build_surface(const SceneDev<R>& s, int prim, V3<R> o, V3<R> d, R t, R u, R v, SurfExt<R>* ext = nullptr) {
   Surf<R> si;
   const Tri<R> tr = s.tris[prim];
-  if (tr.plane == kSphereMark && sizeof(R) == 4 && kSphereF64) {   // experiment: the sphere in double; t = t + v, origin = o + o_lo
-    auto f3 = [](V3<double> a) { return V3<R>((R)a.x, (R)a.y, (R)a.z); };
-    SphereSI<double> ss;
-    SurfExt<double> ed;
-    const V3<double> od((double)o.x + (double)o_lo.x, (double)o.y + (double)o_lo.y, (double)o.z + (double)o_lo.z), dd((double)d.x, (double)d.y, (double)d.z);
-    double t_hit = (double)t + (double)v;
-    if (t_hit < 1e-4 * s.spheres_d[tr.shade].radius) t_hit = 0.0;   // a re-hit of the starting sphere keeps its point (and its coin)
-    sphere_surface<double>(s.spheres_d[tr.shade], od, dd, t_hit, (double)u, &ss, ext ? &ed : nullptr);
-    si.ok = true;
-    si.p = f3(ss.p);
-    si.p_lo = V3<R>((R)(ss.p.x - (double)si.p.x), (R)(ss.p.y - (double)si.p.y), (R)(ss.p.z - (double)si.p.z));
-    si.n = f3(ss.n); si.wo = f3(ss.wo); si.sn = f3(ss.sn); si.sdpdu = f3(ss.sdpdu);
-    if (ext) {
-      ext->u = (R)ed.u; ext->v = (R)ed.v; ext->dpdu = f3(ed.dpdu); ext->dpdv = f3(ed.dpdv); ext->sdpdv = f3(ed.sdpdv);
-      ext->sdndu = f3(ed.sdndu); ext->sdndv = f3(ed.sdndv);
-    }
-    si.material = tr.material;
-    if (!(ss.n.x * ss.sn.x + ss.n.y * ss.sn.y + ss.n.z * ss.sn.z >= 0.0)) si.ok = false;   // primitives.rs:66
-    return si;
-  }
   if (tr.plane == kSphereMark) {   // u = root branch recorded by the traversal (public API reports 0, 0 for spheres)
     SphereSI<R> ss;
     sphere_surface(s.spheres[tr.shade], o, d, t, u, &ss, ext);
@@ -1001,10 +957,9 @@ __global__ void __launch_bounds__(ShadeBlock<R>::n) __attribute__((amdgpu_waves_
     // `if !found_intersection || bounces >= max_depth { break }` (:91); emitted light is 0 (Q18)
     if (prim >= 0 && (int)bounces < s.max_depth) {
       const V4 ro = p.ray_o[i], rd = p.ray_d[i];
-      V3<R> o(ro.x, ro.y, ro.z), d(rd.x, rd.y, rd.z), ray_lo;
-      { R tm; ray_tail(ro, Const<R>::inf, &tm, &ray_lo); }
+      V3<R> o(ro.x, ro.y, ro.z), d(rd.x, rd.y, rd.z);
       SurfExt<R> ext;
-      Surf<R> si = build_surface(s, prim, o, d, h.x, h.z, h.w, TEX ? &ext : nullptr, ray_lo);
+      Surf<R> si = build_surface(s, prim, o, d, h.x, h.z, h.w, TEX ? &ext : nullptr);
       if (!si.ok) { atomicOr(&p.counters[C_ERROR], (uint32_t)ERR_SHADING_NORMAL); }
       else {
         Bsdf<R, NL> bsdf;
@@ -1117,9 +1072,8 @@ __global__ void __launch_bounds__(ShadeBlock<R>::n) k_shade_nee(SceneDev<R> s, P
     prim = (int)real_to_bits(h.y);
     if (prim >= 0) {
       const V4 ro = p.ray_o[i], rd = p.ray_d[i];
-      V3<R> o(ro.x, ro.y, ro.z), d(rd.x, rd.y, rd.z), ray_lo;
-      { R tm; ray_tail(ro, Const<R>::inf, &tm, &ray_lo); }
-      Surf<R> si = build_surface(s, prim, o, d, h.x, h.z, h.w, (SurfExt<R>*)nullptr, ray_lo);
+      V3<R> o(ro.x, ro.y, ro.z), d(rd.x, rd.y, rd.z);
+      Surf<R> si = build_surface(s, prim, o, d, h.x, h.z, h.w);
       if (!si.ok) atomicOr(&p.counters[C_ERROR], (uint32_t)ERR_SHADING_NORMAL);
       else {
         Bsdf<R> bsdf;
@@ -1205,9 +1159,8 @@ __global__ void __launch_bounds__(ShadeBlock<R>::n) k_shade_specular(SceneDev<R>
       }
       if ((int)(depth + 1) < s.max_depth) {
         const V4 ro = p.ray_o[i], rd = p.ray_d[i];
-        V3<R> o(ro.x, ro.y, ro.z), d(rd.x, rd.y, rd.z), ray_lo;
-        { R tm; ray_tail(ro, Const<R>::inf, &tm, &ray_lo); }
-        Surf<R> si = build_surface(s, prim, o, d, h.x, h.z, h.w, (SurfExt<R>*)nullptr, ray_lo);
+        V3<R> o(ro.x, ro.y, ro.z), d(rd.x, rd.y, rd.z);
+        Surf<R> si = build_surface(s, prim, o, d, h.x, h.z, h.w);
         if (si.ok) {
           Bsdf<R> bsdf;
           build_bsdf(s, si, &bsdf, false);
@@ -1283,7 +1236,7 @@ __global__ void __launch_bounds__(kBlock) k_direct_tree(SceneDev<R> s, Pools<R> 
       sp--; continue;
     }
     SurfExt<R> ext;
-    Surf<R> si = build_surface(s, hit, f.o, f.d, r.tmax, hu, hv, TEX ? &ext : nullptr, f.lo);
+    Surf<R> si = build_surface(s, hit, f.o, f.d, r.tmax, hu, hv, TEX ? &ext : nullptr);
     if (!si.ok) { atomicOr(&p.counters[C_ERROR], (uint32_t)ERR_SHADING_NORMAL); sp--; continue; }
     Bsdf<R, 4> bsdf;
     TexCtx<R> tc;

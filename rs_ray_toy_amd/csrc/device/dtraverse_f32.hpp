@@ -5,13 +5,16 @@
 // walk costs one dependent 64 B fetch instead of two dependent 32 B fetches. The reference tests the second
 // child's box later, with the t_max left by the first subtree; here it is tested together with the first one
 // and pushed with its entry distance, and the one t_max-dependent comparison (`t_min < ray.t_max`,
-// geometry.rs:1799) is repeated at pop time. t_max only shrinks, and every other part of the box test does not
-// depend on it, so each ray makes exactly the decisions BVHAccel::intersect / intersect_p make, in the same
-// order (near child by split-axis sign, leaf triangles in ordered_prims order, every accepted hit overwrites the
-// previous one: Q10) — results are bit-identical to the generic kernels in dkernels.hpp (tests compare them).
+// geometry.rs:1799) is repeated at pop time - with the t_max of THAT moment: a closest-hit t_max can grow as well as shrink (each
+// accepted triangle overwrites it, Q10), so a far child is pushed whenever its slabs are hit and judged only when popped; every other
+// part of the box test does not depend on t_max. Each ray therefore makes exactly the decisions BVHAccel::intersect / intersect_p make,
+// in the same order (near child by split-axis sign, leaf triangles in ordered_prims order, every accepted hit overwrites the
+// previous one: Q10) — the same winners, t, u, v as the generic kernels in dkernels.hpp (tests compare them; the slab test below treats a
+// NaN plane distance differently, see box_slabs_f32).
 //
 // What bounds these kernels on MI355X is the vector L1 (TCP): every lane's 16 B fetch of its own node touches a
-// different cache line, and the TCP retires about one line per clock per CU, so time ~ (lines touched) / (CUs x clk).
+// different cache line, and the TCP retires about one line per clock per CU, so time ~ (lines touched) / (CUs x clk). (Round 2's counters
+// say the persistent kernel below is VALU-issue bound, with 87 % of its node fetches served by that L1: DESIGN.md section 3.)
 // Hence (a) the top kTreeletNodes pair nodes (BFS order: the levels every ray walks) are staged in LDS once per
 // workgroup and read with ds_read_b128 — no TCP traffic for them; (b) the traversal stack lives in LDS
 // ([entry][thread], conflict-free), entries beyond kStackLds spill to a strided global array; (c) workgroups are

@@ -128,7 +128,6 @@ struct SceneDev {
   const Tri<R>* tris;
   const TriShade<R>* shades;
   const SphereDev<R>* spheres;
-  const SphereDev<double>* spheres_d;   // fp32 handles: the same records in double (experiment RRT_SPHERE_F64, dkernels.hpp)
   const InstDev<R>* insts;     // non-rigid triangle instances (kInstBase)
   const Material<R>* materials;
   const TexDev<R>* textures;   // texture graph nodes (children before parents)

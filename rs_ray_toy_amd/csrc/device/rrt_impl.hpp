@@ -738,7 +738,6 @@ class Handle : public HandleBase {
   DevBuf<Tri<R>> tris_;
   DevBuf<TriShade<R>> shades_;
   DevBuf<SphereDev<R>> spheres_;
-  DevBuf<SphereDev<double>> spheres_d_;   // experiment RRT_SPHERE_F64
   DevBuf<InstDev<R>> insts_;
   DevBuf<Material<R>> materials_;
   DevBuf<TexDev<R>> textures_;
@@ -841,7 +840,6 @@ class Handle : public HandleBase {
     std::vector<Tri<R>> tris(d->n_prim_order);
     std::vector<TriShade<R>> shades;
     std::vector<SphereDev<R>> spheres;
-    std::vector<SphereDev<double>> spheres_d;
     std::vector<double> world(9 * d->n_prim_order);
     std::vector<InstDev<R>> insts;
     std::unordered_map<int32_t, uint32_t> inst_of;
@@ -870,14 +868,6 @@ class Handle : public HandleBase {
         o.shade = (uint32_t)spheres.size();
         o.plane = kSphereMark;
         spheres.push_back(sd);
-        if (sizeof(R) == 4 && kSphereF64) {
-          SphereDev<double> dd{};
-          auto rows = [](const double* m16, double* out12) { for (int i = 0; i < 12; i++) out12[i] = m16[i]; };
-          rows(d->xforms[sp.xform].m, dd.m); rows(d->xforms[sp.xform].m_inv, dd.mi); rows(im, dd.im); rows(imi, dd.imi);
-          dd.has_inst = sd.has_inst; dd.inst_identity = sd.inst_identity;
-          dd.radius = sp.radius; dd.z_min = sp.z_min; dd.z_max = sp.z_max; dd.theta_min = sp.theta_min; dd.theta_max = sp.theta_max; dd.phi_max = sp.phi_max;
-          spheres_d.push_back(dd);
-        }
         continue;
       }
       const rrt_tri& t = d->tris[pr.shape];
@@ -1059,7 +1049,7 @@ class Handle : public HandleBase {
       }
     }
 
-    nodes_.upload(nodes, st_); tris_.upload(tris, st_); build_pairs(nodes, tris.size()); shades_.upload(shades, st_); spheres_.upload(spheres, st_); spheres_d_.upload(spheres_d, st_);
+    nodes_.upload(nodes, st_); tris_.upload(tris, st_); build_pairs(nodes, tris.size()); shades_.upload(shades, st_); spheres_.upload(spheres, st_);
     materials_.upload(mats, st_); textures_.upload(texs, st_); images_.upload(imgs, st_); image_texels_.upload(texels, st_);
     if (!spheres.empty() || !insts.empty()) pairs_ok_ = false;   // the fp32 pair-node kernels test world-space triangles only: scenes with spheres or non-rigid instances use the generic kernels
     insts_.upload(insts, st_);
@@ -1068,7 +1058,7 @@ class Handle : public HandleBase {
     HIP_CHECK(hipStreamSynchronize(st_));  // host vectors go out of scope below
 
     SceneDev<R>& s = scene_;
-    s.nodes = nodes_.p; s.tris = tris_.p; s.shades = shades_.p; s.spheres = spheres_.p; s.spheres_d = spheres_d_.p; s.insts = insts_.p; s.materials = materials_.p; s.textures = textures_.p; s.images = images_.p; s.image_texels = image_texels_.p; s.lights = lights_.p; s.light_cdf = light_cdf_.p;
+    s.nodes = nodes_.p; s.tris = tris_.p; s.shades = shades_.p; s.spheres = spheres_.p; s.insts = insts_.p; s.materials = materials_.p; s.textures = textures_.p; s.images = images_.p; s.image_texels = image_texels_.p; s.lights = lights_.p; s.light_cdf = light_cdf_.p;
     s.n_nodes = (uint32_t)d->n_bvh_nodes; s.n_tris = (uint32_t)d->n_prim_order; s.n_lights = (uint32_t)nl;
     s.light_pick_pdf = (nl && func_int > 0.0) ? (R)(1.0 / (func_int * (double)nl)) : (R)0;
     s.stack_depth = d->bvh_depth + 1;

@@ -799,6 +799,39 @@ def test_sphere_primitives_render(which, workdir):
     assert abs(ratio - 1.0) < (0.15 if which == "cfg1" else 0.05), ratio
 
 
+SPHERE_MATERIALS = {
+    "matte": (("MatteMaterial", {"kd": [0.6, 0.5, 0.4]}, {}, {}), 5, 0.03),
+    "rough_metal": (("MetalMaterial", {}, {"roughness": 0.2}, {}), 5, 0.03),
+    "rough_glass_depth2": (("GlassMaterial", {"kr": [1.0, 1.0, 1.0], "kt": [0.9, 0.9, 0.9]}, {"eta": 1.5, "u_roughness": 0.2, "v_roughness": 0.1}, {}), 2, 0.08),
+}
+
+
+@pytest.mark.parametrize("which", sorted(SPHERE_MATERIALS))
+def test_fp32_spheres_at_a_converged_sample_count(which, workdir):
+    """Sphere pixels of the reference are decided by coin flips (a spawned ray re-tests its own sphere with c = |o|^2 - r^2 of one ulp of
+    either sign, no epsilon in sphere.rs), which fp32 cannot replay coin for coin: the product mode is held to the f64 mode - itself held
+    to the oracle pixel for pixel - in the mean, at a converged sample count (config 1's 24 spheres, 64 spp, every sphere the same
+    material). Measured (tools/sphere_debug.py): matte 1.016, rough metal 1.007 at depth 5, rough glass 0.99 at depth 2. Deep paths
+    through rough-glass spheres are the known exception (2.2x at depth 5): such scenes belong in RRT_F64."""
+    spec, depth, bar = SPHERE_MATERIALS[which]
+    cfg, root = scenes.cfg1(workdir, xres=64, yres=64, nsamp=65)
+    _with_material(cfg, "sph", spec)
+    for prim in cfg["Aggregate"]["primitives"]:
+        prim["material_name"] = "sph"
+    cfg["Integrator"] = {"integrator_type": "Path", "max_depth": depth}
+    sc = Scene.loads(cfg, root)
+    means = {}
+    for prec in (RRT_F64, RRT_F32):
+        r = Renderer(sc, 0, prec)
+        film = r.render().astype(np.float64)
+        r.close()
+        assert np.all(film[..., 3] == 3.0 * 64.0)
+        means[prec] = film[..., :3].mean()
+    ratio = means[RRT_F32] / means[RRT_F64]
+    print(f"spheres, {which}: fp32 mean / f64 mean = {ratio:.4f}")
+    assert means[RRT_F64] > 0 and abs(ratio - 1.0) < bar, ratio
+
+
 def test_fp32_difference_found_by_the_fuzz_sweep_is_one_sample_on_a_shared_edge():
     """Fuzz seed 508 case 96 (tests/golden/fuzz508_96/: a tilted cube in a tilted box, a plastic whose roughness is a 3D checkerboard and a
     textured mirror, StratifiedSampler, TriangleFilter, Path depth 1) was the one fp32 image over the sweep's bar: 8 pixels off by up to 0.14 of
