@@ -9,7 +9,8 @@ import oracle_lib as O
 from rs_ray_toy_amd import RRT_F32, RRT_F64, RRT_FIXED_BVH, Renderer, RrtError, Scene, scenes
 
 n_cases = int(sys.argv[1]) if len(sys.argv) > 1 else 40
-rng = np.random.default_rng(int(sys.argv[2]) if len(sys.argv) > 2 else 1)
+SEED = int(sys.argv[2]) if len(sys.argv) > 2 else 1
+rng = np.random.default_rng(SEED)
 F32 = len(sys.argv) > 3 and sys.argv[3] == "f32"
 ONLY = int(sys.argv[4]) if len(sys.argv) > 4 else -1      # render only this case (the others still consume the random stream)
 RES = int(os.environ.get("FUZZ_RES", "40")); NS = int(os.environ.get("FUZZ_NSAMP", "5"))
@@ -87,6 +88,14 @@ for case in range(n_cases):
         else: cfg, root = scenes.cfg1(wd, xres=RES, yres=RES, nsamp=NS)
         if base == "cfg2":      # generic axes (exact box / face ties otherwise, tests/test_gpu_parity.py)
             for inst in cfg["Aggregate"]["primitives"][0]["instances"]: inst["rotation_axis"] = [1.0, 2.0, 3.0]
+        # non-rigid instances (scale): drawn from a second generator so that the main stream - and with it every scene of the earlier sweeps -
+        # stays what it was
+        rng2 = np.random.default_rng([SEED, case])
+        if base in ("cfg2", "cfg3") and rng2.random() < 0.35:
+            for prim in cfg["Aggregate"]["primitives"]:
+                for inst in prim.get("instances", []):
+                    if rng2.random() < 0.6:
+                        inst["scale"] = [float(x) for x in rng2.choice([0.5, 0.8, 1.0, 1.5, 2.0], size=3)]
         cfg["_wd"] = wd
         names = palette(cfg)
         del cfg["_wd"]
