@@ -42,19 +42,28 @@ constexpr int kTravBlock = 512;     // 8 waves share one LDS copy of the treelet
 constexpr int kStackLds = 8;        // LDS stack entries per thread (8 B each); deeper entries spill to global
 constexpr int kTreeletNodes = 512;  // top of the tree (BFS order) staged in LDS: 512 pair nodes = 32 KB
 
+// Field order chosen for the packed fp32 VALU forms (v_pk_add_f32 / v_pk_mul_f32 work on aligned register pairs, and a 128-bit load
+// lands in four consecutive registers): every 64-bit half of the three box words pairs two plane coordinates with the SAME ray
+// constants - (x, y) against (o.x, o.y) / (inv.x, inv.y), (z, z) against o.z / inv.z - so the 24 subtract / multiply operations of the two
+// slab tests are 12 packed instructions. The child words are what the traversal stack holds, ready made.
 struct alignas(64) PairNode {
-  float b0min[3], b0max[3];   // first child's box (linear index + 1)
-  float b1min[3], b1max[3];   // second child's box
-  uint32_t ref0, ref1;        // interior child: PairNode index; leaf child: first triangle
-  uint32_t meta;              // bits 0-1 split axis, bits 2-13 n_prims of child 0 (0 = interior), bits 14-25 of child 1
+  float xy0[4];               // first child (linear index + 1):  bmin.x, bmin.y, bmax.x, bmax.y
+  float xy1[4];               // second child:                    bmin.x, bmin.y, bmax.x, bmax.y
+  float zz[4];                // first child bmin.z, bmax.z, second child bmin.z, bmax.z
+  uint32_t id0, id1;          // child words: interior = byte offset of its PairNode (bit 31 clear); leaf = kLeafBit | n_prims << 19 | first triangle
+  uint32_t axis;              // split axis (bvh.rs:183-236: dir_is_neg[axis] visits the second child first)
   uint32_t pad;
 };
+constexpr uint32_t kLeafBit = 0x80000000u;
+typedef float v2f __attribute__((ext_vector_type(2)));
 
 struct F4 { float x, y, z, w; };
 RRT_DEV F4 ld4(const float* p) { const float4 v = *reinterpret_cast<const float4*>(p); return {v.x, v.y, v.z, v.w}; }
 
 struct LaneRay {
-  float ox, oy, oz, dx, dy, dz, ix, iy, iz, tmax;
+  v2f oxy, ixy;       // origin and inverse direction, x and y as a register pair (operands of the packed slab arithmetic)
+  v2f ozz, izz;       // z twice
+  float dx, dy, dz, tmax;
   float lx, ly, lz;   // low word of the double-float origin (dkernels.hpp spawn_point())
   uint32_t neg;       // bit k: inv_dir[k] < 0
   uint32_t skip_plane;
@@ -64,12 +73,8 @@ struct LaneRay {
 // Returns false when the slabs miss or t_max <= 0; *tmin_out is the entry distance compared against ray.t_max.
 // Straight-line form of the reference's sequence of ifs: the same comparisons on the same values (a comparison
 // with NaN is false in both), evaluated unconditionally instead of returning early.
-#ifndef RRT_BOX_MINMAX
-#define RRT_BOX_MINMAX 1
-#endif
 RRT_DEV bool box_slabs_f32(float bminx, float bminy, float bminz, float bmaxx, float bmaxy, float bmaxz, const LaneRay& r, float* tmin_out) {
   const float g = 1.0f + 2.0f * ((3.0f * 5.9604645e-8f) / (1.0f - 3.0f * 5.9604645e-8f));
-#if RRT_BOX_MINMAX
   // The same decisions with a third fewer instructions (the kernel is VALU-issue bound). Per axis the reference picks the near / far plane
   // by the sign of inv_dir, i.e. near = min, far = max of the two plane distances; its chain of pairwise rejections
   //   t_min > ty_max || ty_min > t_max, then the same against z, with the far values widened by g, and finally t_max > 0
@@ -77,33 +82,32 @@ RRT_DEV bool box_slabs_f32(float bminx, float bminy, float bminz, float bmaxx, f
   // that all reach beyond 0 intersect pairwise iff they share a point, and multiplying by g > 0 commutes with min (rounding is monotone).
   // Only a NaN plane distance is treated differently (0 * inf: a ray exactly parallel to a slab AND starting exactly on its plane - the
   // reference lets such an x slab reject and ignores such a y / z slab, v_min / v_max ignore it on every axis).
-  const float x0 = (bminx - r.ox) * r.ix, x1 = (bmaxx - r.ox) * r.ix;
-  const float y0 = (bminy - r.oy) * r.iy, y1 = (bmaxy - r.oy) * r.iy;
-  const float z0 = (bminz - r.oz) * r.iz, z1 = (bmaxz - r.oz) * r.iz;
+  const float x0 = (bminx - r.oxy.x) * r.ixy.x, x1 = (bmaxx - r.oxy.x) * r.ixy.x;
+  const float y0 = (bminy - r.oxy.y) * r.ixy.y, y1 = (bmaxy - r.oxy.y) * r.ixy.y;
+  const float z0 = (bminz - r.ozz.x) * r.izz.x, z1 = (bmaxz - r.ozz.x) * r.izz.x;
   const float t_min = fmaxf(fmaxf(fminf(x0, x1), fminf(y0, y1)), fminf(z0, z1));
   const float t_max = fminf(fminf(fmaxf(x0, x1), fmaxf(y0, y1)), fmaxf(z0, z1)) * g;
   *tmin_out = t_min;
   return (t_min <= t_max) & (t_max > 0.0f);
-#else
-  const bool nx = r.neg & 1u, ny = r.neg & 2u, nz = r.neg & 4u;
-  float t_min = ((nx ? bmaxx : bminx) - r.ox) * r.ix;
-  float t_max = ((nx ? bminx : bmaxx) - r.ox) * r.ix;
-  const float ty_min = ((ny ? bmaxy : bminy) - r.oy) * r.iy;
-  float ty_max = ((ny ? bminy : bmaxy) - r.oy) * r.iy;
-  t_max *= g;
-  ty_max *= g;
-  const bool miss_xy = (t_min > ty_max) | (ty_min > t_max);
-  t_min = (ty_min > t_min) ? ty_min : t_min;
-  t_max = (ty_max < t_max) ? ty_max : t_max;
-  const float tz_min = ((nz ? bmaxz : bminz) - r.oz) * r.iz;
-  float tz_max = ((nz ? bminz : bmaxz) - r.oz) * r.iz;
-  tz_max *= g;
-  const bool miss_z = (t_min > tz_max) | (tz_min > t_max);
-  t_min = (tz_min > t_min) ? tz_min : t_min;
-  t_max = (tz_max < t_max) ? tz_max : t_max;
-  *tmin_out = t_min;
-  return !(miss_xy | miss_z) & (t_max > 0.0f);
-#endif
+}
+
+// The two slab tests of one pair node: box_slabs_f32 for both children, bit for bit, with the subtractions and multiplications packed
+// two to an instruction (PairNode's field order). t[k] = entry distance of child k, the return bits k = "slabs hit and t_max > 0".
+// Results as lane masks (scalar registers): what follows is logic on conditions, which belongs on the scalar unit.
+struct PairHit { float t0, t1; uint64_t s0, s1; };
+RRT_DEV PairHit pair_slabs_f32(const float4 a, const float4 b, const float4 c, const LaneRay& r) {
+  const float g = 1.0f + 2.0f * ((3.0f * 5.9604645e-8f) / (1.0f - 3.0f * 5.9604645e-8f));
+  const v2f lo0 = (v2f{a.x, a.y} - r.oxy) * r.ixy, hi0 = (v2f{a.z, a.w} - r.oxy) * r.ixy;   // child 0: (x, y) plane distances of bmin, bmax
+  const v2f lo1 = (v2f{b.x, b.y} - r.oxy) * r.ixy, hi1 = (v2f{b.z, b.w} - r.oxy) * r.ixy;
+  const v2f z0 = (v2f{c.x, c.y} - r.ozz) * r.izz, z1 = (v2f{c.z, c.w} - r.ozz) * r.izz;     // (bmin.z, bmax.z) of child 0, of child 1
+  PairHit h;
+  h.t0 = fmaxf(fmaxf(fminf(lo0.x, hi0.x), fminf(lo0.y, hi0.y)), fminf(z0.x, z0.y));
+  h.t1 = fmaxf(fmaxf(fminf(lo1.x, hi1.x), fminf(lo1.y, hi1.y)), fminf(z1.x, z1.y));
+  const float f0 = fminf(fminf(fmaxf(lo0.x, hi0.x), fmaxf(lo0.y, hi0.y)), fmaxf(z0.x, z0.y)) * g;
+  const float f1 = fminf(fminf(fmaxf(lo1.x, hi1.x), fmaxf(lo1.y, hi1.y)), fmaxf(z1.x, z1.y)) * g;
+  h.s0 = __builtin_amdgcn_ballot_w64(h.t0 <= f0) & __builtin_amdgcn_ballot_w64(f0 > 0.0f);
+  h.s1 = __builtin_amdgcn_ballot_w64(h.t1 <= f1) & __builtin_amdgcn_ballot_w64(f1 > 0.0f);
+  return h;
 }
 
 // Moller-Trumbore of Triangle::intersect (ANY = false, E2 = p2 - p0) / intersect_p (ANY = true, E2 = p2 - p1: Q11)
@@ -115,7 +119,7 @@ template <bool ANY>
 RRT_DEV bool tri_test_f32(const float* tp, const LaneRay& r, float* th, float* uh, float* vh) {
   const F4 q0 = ld4(tp), q1 = ld4(tp + 4), q2 = ld4(tp + 8);
   const V3<float> p0(q0.x, q0.y, q0.z), p1(q0.w, q1.x, q1.y), p2(q1.z, q1.w, q2.x);
-  const V3<float> D(r.dx, r.dy, r.dz), O(r.ox, r.oy, r.oz);
+  const V3<float> D(r.dx, r.dy, r.dz), O(r.oxy.x, r.oxy.y, r.ozz.x);
   const V3<float> E1 = p1 - p0, E2 = ANY ? (p2 - p1) : (p2 - p0);
   const V3<float> P = cross(D, E2);
   const float a = dot(E1, P);
@@ -136,22 +140,87 @@ struct TravScene {
   const PairNode* pairs;     // interior nodes, pre-order
   const float* tris;         // Tri<float> array viewed as 12 floats per triangle
   float root_box[6];
-  uint32_t root_ref, root_n; // root_n > 0: the root itself is a leaf
+  uint32_t root_id;          // the root's child word (a leaf word when the whole tree is one leaf)
   uint32_t n_nodes;
   uint32_t n_treelet;        // pair nodes [0, n_treelet) are the BFS top of the tree (host renumbering)
-  uint32_t* overflow;        // stack entries >= kStackLds: [entry][thread of the launch], 2 words each
+  uint32_t* overflow;        // stack entries beyond the LDS ones: [entry][thread of the launch], 2 words each
   uint32_t overflow_stride;
   // Shadow rays (any-hit, t_max = 1 - 1e-4, unit direction: Q9) of the pool start ON a triangle and reach less than one unit far. Every
   // ancestor of that triangle's leaf contains the origin, so its box test passes whatever the direction, and a sibling subtree whose box is
   // more than a unit away from the leaf's box fails whatever the direction: the walk from the root down to the first ancestor with a NEAR
   // sibling - half of the 47 box tests of an average shadow ray on the 100k-triangle mesh - decides nothing. any_entry[triangle] is that
-  // ancestor's pair node (host: build_pairs()); an occlusion query is order independent, so starting there changes no result. Null = off.
+  // ancestor's child word (host: build_pairs()); an occlusion query is order independent, so starting there changes no result. Null = off.
   const uint32_t* any_entry;
 };
 
-// ANY = false: closest hit for rays in the pool's ray arrays -> pool hit arrays (through `queue` if given).
+// A lane's position in the walk is one child word: an interior node to visit (byte offset of its PairNode, < kIdle), a leaf to test
+// (kLeafBit set), or kIdle. The traversal stack holds the same words with the child's entry distance.
+constexpr uint32_t kIdle = 0x7fffffffu;
+RRT_DEV bool is_node(uint32_t w) { return w < kIdle; }
+RRT_DEV bool is_leaf(uint32_t w) { return (int32_t)w < 0; }
+
+// Ray `idx` of the queue this launch serves (POOL_SHADOW: the pool's shadow rays, t_max = 1 - 1e-4; otherwise the closest-ray arrays
+// with their own t_max) -> lane registers; returns the word the walk starts with (kIdle: the ray misses the root box).
+template <bool POOL_SHADOW>
+RRT_DEV uint32_t lane_ray_begin(const TravScene& ts, const Pools<float>& p, bool pool_shadow, uint32_t idx, LaneRay& r) {
+  const float4 ro = (POOL_SHADOW && pool_shadow) ? p.sray_o[idx] : p.ray_o[idx], rd = (POOL_SHADOW && pool_shadow) ? p.sray_d[idx] : p.ray_d[idx];
+  V3<float> lo;
+  ray_tail(ro, (POOL_SHADOW && pool_shadow) ? 1.0f - 0.0001f : Const<float>::inf, &r.tmax, &lo);
+  const int sk = (int)__float_as_uint(rd.w);
+  r.oxy = v2f{ro.x, ro.y}; r.ozz = v2f{ro.z, ro.z}; r.dx = rd.x; r.dy = rd.y; r.dz = rd.z;
+  r.lx = lo.x; r.ly = lo.y; r.lz = lo.z;
+  r.skip_plane = sk >= 0 ? __float_as_uint(ts.tris[(size_t)sk * 12 + 11]) : 0xffffffffu;
+  r.ixy = v2f{1.0f / r.dx, 1.0f / r.dy}; r.izz.x = 1.0f / r.dz; r.izz.y = r.izz.x;
+  r.neg = (r.ixy.x < 0.0f ? 1u : 0u) | (r.ixy.y < 0.0f ? 2u : 0u) | (r.izz.x < 0.0f ? 4u : 0u);
+  if (POOL_SHADOW && pool_shadow && ts.any_entry && sk >= 0) return ts.any_entry[sk];   // (see TravScene::any_entry)
+  float tmin;
+  if (ts.n_nodes != 0 && box_slabs_f32(ts.root_box[0], ts.root_box[1], ts.root_box[2], ts.root_box[3], ts.root_box[4], ts.root_box[5], r, &tmin) && tmin < r.tmax)
+    return ts.root_id;
+  return kIdle;
+}
+
+// One pair node: both slab tests, then the reference's order (bvh.rs:183-236: the second child first when dir_is_neg[axis]). The near
+// child is judged now, like the reference does. The far child's `t_min < t_max` belongs to the moment it is popped: a closest-hit t_max
+// can also GROW in between (each accepted hit overwrites it, Q10), so it is pushed whenever its slabs are hit and judged at pop time.
+// Shadow rays never change t_max: they prune at once. The selections are written on lane masks (scalar unit), not on 0 / 1 values.
+struct PairStep { uint32_t id_near, id_far; float t_far; bool go_near, push_far; };
+template <bool ANY>
+RRT_DEV PairStep pair_step_f32(const float4 a, const float4 b, const float4 c, const uint4 d, const LaneRay& r) {
+  const PairHit h = pair_slabs_f32(a, b, c, r);
+  // lane masks and scalar logic: the compiler turns a select between two conditions into 0 / 1 values and five vector instructions
+  const uint64_t m_sf = __builtin_amdgcn_ballot_w64(((r.neg >> d.z) & 1u) != 0u);
+  const uint64_t m_s0 = h.s0, m_s1 = h.s1;
+  const uint64_t m_h0 = m_s0 & __builtin_amdgcn_ballot_w64(h.t0 < r.tmax), m_h1 = m_s1 & __builtin_amdgcn_ballot_w64(h.t1 < r.tmax);
+  const bool sf = __builtin_amdgcn_inverse_ballot_w64(m_sf);
+  PairStep st;
+  st.go_near = __builtin_amdgcn_inverse_ballot_w64((m_sf & m_h1) | (~m_sf & m_h0));
+  st.push_far = __builtin_amdgcn_inverse_ballot_w64(ANY ? ((m_sf & m_h0) | (~m_sf & m_h1)) : ((m_sf & m_s0) | (~m_sf & m_s1)));
+  st.id_near = sf ? d.y : d.x;
+  st.id_far = sf ? d.x : d.y;
+  st.t_far = sf ? h.t0 : h.t1;
+  return st;
+}
+
+// Every triangle of a leaf in ordered_prims order; each accepted hit overwrites the previous one and t_max (Q10). ANY: true at the first hit.
+template <bool ANY>
+RRT_DEV bool leaf_step_f32(const TravScene& ts, uint32_t word, LaneRay& r, int* hit, float* hu, float* hv) {
+  uint32_t lf = word & 0x7ffffu, ln = (word >> 19) & 0xfffu;
+  do {
+    float t, u, v;
+    if (tri_test_f32<ANY>(ts.tris + (size_t)lf * 12, r, &t, &u, &v)) {
+      if (ANY) return true;
+      r.tmax = t; *hit = (int)lf; *hu = u; *hv = v;
+    }
+    lf++; ln--;
+  } while (ln != 0);
+  return false;
+}
+
+// ANY = false: closest hit for rays in the pool's ray arrays -> pool hit arrays.
 // ANY = true : shadow rays (pool shadow arrays) -> L += Ld when unoccluded; with `occluded` != nullptr the rays
 //              are the pool's closest-ray arrays and the verdict is written to occluded[i] (public rrt_trace_any).
+// Grid-stride form for small queues: the wave alternates between "every lane walks interior nodes until it holds a leaf" and "every lane
+// tests its leaf" (while-while); the BFS top of the tree is read from LDS.
 template <bool ANY>
 __global__ void __launch_bounds__(kTravBlock) k_trace_pairs_f32(TravScene ts, Pools<float> p, const uint32_t* queue, const uint32_t* count,
                                                                  uint32_t n_fixed, uint8_t* occluded, uint32_t n_lo, uint32_t n_hi) {
@@ -160,116 +229,64 @@ __global__ void __launch_bounds__(kTravBlock) k_trace_pairs_f32(TravScene ts, Po
     if (nn < n_lo || nn >= n_hi) return;
   }
   __shared__ float4 treelet[kTreeletNodes * 4];
-  __shared__ uint32_t stk_id[kStackLds * kTravBlock];
-  __shared__ float stk_t[kStackLds * kTravBlock];
+  __shared__ uint2 stk[kStackLds * kTravBlock];
   const uint32_t tid = threadIdx.x;
   for (uint32_t i = tid; i < ts.n_treelet * 4u; i += kTravBlock) treelet[i] = reinterpret_cast<const float4*>(ts.pairs)[i];
   __syncthreads();
   const uint32_t n = count ? *count : n_fixed;
   const uint32_t col = blockIdx.x * kTravBlock + tid;   // overflow-stack column of this resident thread
+  const uint32_t treelet_bytes = ts.n_treelet * 64u;
   for (uint32_t gid = col; gid < n; gid += gridDim.x * kTravBlock) {
-  LaneRay r;
-  int sk;
-  {
-    const float4 ro = (ANY && !occluded) ? p.sray_o[gid] : p.ray_o[gid], rd = (ANY && !occluded) ? p.sray_d[gid] : p.ray_d[gid];
-    V3<float> lo;
-    ray_tail(ro, (ANY && !occluded) ? 1.0f - 0.0001f : Const<float>::inf, &r.tmax, &lo);
-    r.ox = ro.x; r.oy = ro.y; r.oz = ro.z; r.dx = rd.x; r.dy = rd.y; r.dz = rd.z; sk = (int)__float_as_uint(rd.w);
-    r.lx = lo.x; r.ly = lo.y; r.lz = lo.z;
-  }
-  r.skip_plane = sk >= 0 ? __float_as_uint(ts.tris[(size_t)sk * 12 + 11]) : 0xffffffffu;
-  r.ix = 1.0f / r.dx; r.iy = 1.0f / r.dy; r.iz = 1.0f / r.dz;
-  r.neg = (r.ix < 0.0f ? 1u : 0u) | (r.iy < 0.0f ? 2u : 0u) | (r.iz < 0.0f ? 4u : 0u);
-
-  int hit = -1;
-  float hu = 0.0f, hv = 0.0f;
-  bool found = false;
-  uint32_t sp = 0;
-
-  auto push = [&](uint32_t ref, uint32_t nprims, float tmin) {   // id word: ref | leaf flag; leaf count in the low bits of a second use
-    const uint32_t id = nprims ? (0x80000000u | (nprims << 19) | ref) : ref;   // ref < 2^19 checked on the host when n_prims is packed
-    if (sp < (uint32_t)kStackLds) { stk_id[sp * kTravBlock + tid] = id; stk_t[sp * kTravBlock + tid] = tmin; }
-    else { uint32_t* o = ts.overflow + ((size_t)(sp - kStackLds) * ts.overflow_stride + col) * 2; o[0] = id; o[1] = __float_as_uint(tmin); }
-    sp++;
-  };
-  auto leaf = [&](uint32_t first, uint32_t cnt) {   // every triangle, in order; each accepted hit overwrites (Q10)
-    for (uint32_t i = 0; i < cnt; i++) {
-      float t, u, v;
-      if (tri_test_f32<ANY>(ts.tris + (size_t)(first + i) * 12, r, &t, &u, &v)) {
-        if (ANY) { found = true; return; }
-        r.tmax = t; hit = (int)(first + i); hu = u; hv = v;
+    LaneRay r;
+    uint32_t cur = lane_ray_begin<ANY>(ts, p, !occluded, gid, r);
+    int hit = -1;
+    float hu = 0.0f, hv = 0.0f;
+    bool found = false;
+    uint32_t sp = 0;
+    auto pop = [&]() {   // re-checks the one comparison that depends on the current t_max
+      cur = kIdle;
+      while (sp > 0) {
+        sp--;
+        uint2 e;
+        if (sp < (uint32_t)kStackLds) e = stk[sp * kTravBlock + tid];
+        else e = *reinterpret_cast<const uint2*>(ts.overflow + ((size_t)(sp - kStackLds) * ts.overflow_stride + col) * 2);
+        if (__uint_as_float(e.y) < r.tmax) { cur = e.x; return; }
+      }
+    };
+    while (__ballot(cur != kIdle) != 0ull) {
+      while (is_node(cur)) {
+        float4 a, b, c; uint4 d;
+        if (cur < treelet_bytes) {
+          const float4* tp = treelet + (cur >> 4);
+          a = tp[0]; b = tp[1]; c = tp[2]; const float4 dd = tp[3];
+          d = make_uint4(__float_as_uint(dd.x), __float_as_uint(dd.y), __float_as_uint(dd.z), 0u);
+        } else {
+          const char* np = reinterpret_cast<const char*>(ts.pairs) + cur;
+          a = *reinterpret_cast<const float4*>(np); b = *reinterpret_cast<const float4*>(np + 16); c = *reinterpret_cast<const float4*>(np + 32);
+          d = *reinterpret_cast<const uint4*>(np + 48);
+        }
+        const PairStep st = pair_step_f32<ANY>(a, b, c, d, r);
+        if (st.push_far) {
+          const uint2 e = make_uint2(st.id_far, __float_as_uint(st.t_far));
+          if (sp < (uint32_t)kStackLds) stk[sp * kTravBlock + tid] = e;
+          else *reinterpret_cast<uint2*>(ts.overflow + ((size_t)(sp - kStackLds) * ts.overflow_stride + col) * 2) = e;
+          sp++;
+        }
+        if (st.go_near) cur = st.id_near;
+        else pop();
+      }
+      if (is_leaf(cur)) {
+        found = leaf_step_f32<ANY>(ts, cur, r, &hit, &hu, &hv);
+        if (ANY && found) cur = kIdle;
+        else pop();
       }
     }
-  };
-
-  // Per-lane state machine: NODE(cur) -> walk; LEAF(lf, ln) -> triangle tests; DONE. The wave alternates between
-  // "every lane walks interior nodes until it holds a leaf" and "every lane tests its leaf" (while-while), so the
-  // long triangle-test path is executed once per round instead of in almost every iteration.
-  enum { ST_NODE = 0, ST_LEAF = 1, ST_DONE = 2 };
-  uint32_t cur = 0, lf = 0, ln = 0;
-  int state = ST_DONE;
-  auto pop = [&]() {   // re-checks the one comparison that depends on the current t_max
-    state = ST_DONE;
-    while (sp > 0) {
-      sp--;
-      uint32_t id; float tmin;
-      if (sp < (uint32_t)kStackLds) { id = stk_id[sp * kTravBlock + tid]; tmin = stk_t[sp * kTravBlock + tid]; }
-      else { const uint32_t* o = ts.overflow + ((size_t)(sp - kStackLds) * ts.overflow_stride + col) * 2; id = o[0]; tmin = __uint_as_float(o[1]); }
-      if (!(tmin < r.tmax)) continue;
-      if (id & 0x80000000u) { lf = id & 0x7ffffu; ln = (id >> 19) & 0xfffu; state = ST_LEAF; }
-      else { cur = id; state = ST_NODE; }
-      return;
+    if (ANY) {
+      if (occluded) occluded[gid] = found ? 1 : 0;
+      else if (!found) add_pending(p, gid);
+    } else {
+      p.hit[gid] = make_float4(r.tmax, __uint_as_float((uint32_t)hit), hu, hv);
     }
-  };
-  if (ANY && !occluded && ts.any_entry && sk >= 0) { cur = ts.any_entry[sk]; state = ST_NODE; }   // (see TravScene::any_entry)
-  else {
-    float tmin;
-    if (ts.n_nodes != 0 && box_slabs_f32(ts.root_box[0], ts.root_box[1], ts.root_box[2], ts.root_box[3], ts.root_box[4], ts.root_box[5], r, &tmin) && tmin < r.tmax) {
-      if (ts.root_n) { lf = ts.root_ref; ln = ts.root_n; state = ST_LEAF; }
-      else { cur = ts.root_ref; state = ST_NODE; }
-    }
-  }
-  while (__ballot(state != ST_DONE) != 0ull) {
-    while (state == ST_NODE) {
-      F4 a, b, c, d;
-      if (cur < ts.n_treelet) {
-        const float4 v0 = treelet[cur * 4], v1 = treelet[cur * 4 + 1], v2 = treelet[cur * 4 + 2], v3 = treelet[cur * 4 + 3];
-        a = {v0.x, v0.y, v0.z, v0.w}; b = {v1.x, v1.y, v1.z, v1.w}; c = {v2.x, v2.y, v2.z, v2.w}; d = {v3.x, v3.y, v3.z, v3.w};
-      } else {
-        const float* np = reinterpret_cast<const float*>(ts.pairs + cur);
-        a = ld4(np); b = ld4(np + 4); c = ld4(np + 8); d = ld4(np + 12);
-      }
-      const uint32_t ref0 = __float_as_uint(d.x), ref1 = __float_as_uint(d.y), meta = __float_as_uint(d.z);
-      const uint32_t n0 = (meta >> 2) & 0xfffu, n1 = (meta >> 14) & 0xfffu;
-      float t0, t1;
-      const bool s0 = box_slabs_f32(a.x, a.y, a.z, a.w, b.x, b.y, r, &t0), s1 = box_slabs_f32(b.z, b.w, c.x, c.y, c.z, c.w, r, &t1);
-      const bool h0 = s0 && t0 < r.tmax, h1 = s1 && t1 < r.tmax;
-      const bool second_first = (r.neg >> (meta & 3u)) & 1u;   // dir_is_neg[axis]: the reference visits the second child first
-      // The near child is tested now, like the reference does. The far child's `t_min < t_max` belongs to the moment it
-      // is popped: a closest-hit t_max can also GROW in between (each accepted hit overwrites it, Q10), so it is pushed
-      // whenever its slabs are hit and judged at pop time. Shadow rays never change t_max: prune at once.
-      const bool hn = second_first ? h1 : h0, hf = ANY ? (second_first ? h0 : h1) : (second_first ? s0 : s1);
-      const uint32_t refn = second_first ? ref1 : ref0, reff = second_first ? ref0 : ref1;
-      const uint32_t nn = second_first ? n1 : n0, nf = second_first ? n0 : n1;
-      const float tf = second_first ? t0 : t1;
-      if (hf) push(reff, nf, tf);
-      if (hn) {
-        if (nn) { lf = refn; ln = nn; state = ST_LEAF; }
-        else cur = refn;
-      } else pop();
-    }
-    if (state == ST_LEAF) {
-      leaf(lf, ln);
-      if (ANY && found) state = ST_DONE;
-      else pop();
-    }
-  }
-  if (ANY) {
-    if (occluded) occluded[gid] = found ? 1 : 0;
-    else if (!found) add_pending(p, gid);
-  } else {
-    p.hit[gid] = make_float4(r.tmax, __uint_as_float((uint32_t)hit), hu, hv);
-  }
   }  // grid-stride loop over rays
 }
 
@@ -278,8 +295,8 @@ __global__ void __launch_bounds__(kTravBlock) k_trace_pairs_f32(TravScene ts, Po
 // Persistent-thread variant: the kernel is VALU-issue bound with ~26 % of the lanes doing useful work when a wave
 // owns 64 fixed rays (a wave lasts as long as its longest ray). Here a wave keeps pulling rays: it reserves
 // kGrain rays at a time from a global cursor (one atomic per kGrain rays) and refills idle lanes from that private
-// range, so lanes stay busy until the queue is empty. Each lane is a small state machine that advances one step
-// per loop iteration: NODE (one pair-node step), TRI (one triangle of the current leaf), IDLE.
+// range, so lanes stay busy until the queue is empty. Each lane advances one step per loop iteration: node steps
+// (RRT_NODE_STEPS pair nodes) or the triangles of its current leaf, whichever the wave votes for; the others wait.
 // Per ray the sequence of box tests, triangle tests, acceptances and t_max updates is unchanged.
 // ------------------------------------------------------------------------------------------------------------
 #ifndef RRT_PT_BLOCK
@@ -288,16 +305,9 @@ __global__ void __launch_bounds__(kTravBlock) k_trace_pairs_f32(TravScene ts, Po
 #ifndef RRT_PT_STACK
 #define RRT_PT_STACK 10
 #endif
-#ifndef RRT_PT_TREELET
-#define RRT_PT_TREELET 0
-#endif
-#ifndef RRT_XCD_WORK
-#define RRT_XCD_WORK 1
-#endif
-constexpr uint32_t kXcdParts = RRT_XCD_WORK ? 8u : 1u;   // parts of a queue with their own work cursor (8 XCDs)
+constexpr uint32_t kXcdParts = 8u;   // parts of a queue with their own work cursor (8 XCDs)
 constexpr int kPtBlock = RRT_PT_BLOCK;
 constexpr int kPtStack = RRT_PT_STACK;
-constexpr int kPtTreelet = RRT_PT_TREELET;   // pair nodes of the BFS top of the tree kept in LDS by the persistent kernel (0 = none)
 constexpr uint32_t kGrain = 256;
 
 template <bool ANY>
@@ -307,28 +317,19 @@ __global__ void __launch_bounds__(kPtBlock) k_trace_pt_f32(TravScene ts, Pools<f
     const uint32_t nn = count ? *count : n_fixed;
     if (nn < n_lo || nn >= n_hi) return;
   }
-  __shared__ uint32_t stk_id[kPtStack * kPtBlock];
-  __shared__ float stk_t[kPtStack * kPtBlock];
-  __shared__ float4 pt_treelet[kPtTreelet > 0 ? kPtTreelet * 4 : 1];
+  __shared__ uint2 stk[kPtStack * kPtBlock];   // [entry][thread]: {child word, entry distance}, one ds_write_b64 / ds_read_b64 each
   const uint32_t tid = threadIdx.x, lane = tid & 63u;
   const uint32_t gtid = blockIdx.x * blockDim.x + tid;   // overflow-stack column of this lane
-  const uint32_t n_tl = kPtTreelet > 0 ? (ts.n_treelet < (uint32_t)kPtTreelet ? ts.n_treelet : (uint32_t)kPtTreelet) : 0u;
-  if (kPtTreelet > 0) {
-    for (uint32_t i = tid; i < n_tl * 4u; i += kPtBlock) pt_treelet[i] = reinterpret_cast<const float4*>(ts.pairs)[i];
-    __syncthreads();
-  }
   const uint32_t n = count ? *count : n_fixed;
-  enum { ST_IDLE = 0, ST_NODE = 1, ST_TRI = 2 };
-  int state = ST_IDLE;
   LaneRay r;
-  r.ox = r.oy = r.oz = r.dx = r.dy = r.dz = r.ix = r.iy = r.iz = r.tmax = r.lx = r.ly = r.lz = 0.0f; r.neg = 0; r.skip_plane = 0xffffffffu;
-  uint32_t qidx = 0, cur = 0, sp = 0, lf = 0, ln = 0;
+  r.oxy = r.ixy = r.ozz = r.izz = v2f{0.0f, 0.0f};
+  r.dx = r.dy = r.dz = r.tmax = r.lx = r.ly = r.lz = 0.0f; r.neg = 0; r.skip_plane = 0xffffffffu;
+  uint32_t cur = kIdle, qidx = 0, sp = 0;
   int hit = -1;
   float hu = 0.0f, hv = 0.0f;
-  bool found = false;
   uint32_t lo = 0, hi = 0;      // wave-private range of reserved rays
   bool exhausted = false;       // wave-uniform
-  const uint32_t home = RRT_XCD_WORK ? (blockIdx.x & (kXcdParts - 1u)) : 0u;
+  const uint32_t home = blockIdx.x & (kXcdParts - 1u);
   uint32_t parts_done = 0;      // parts of the queue this wave has found empty
   // reservation grain: large enough to amortise the atomic, small enough that a short queue still spreads over
   // every resident wave (a wave that reserves 256 rays of a 100k-ray queue would serialise four ray chains)
@@ -336,42 +337,34 @@ __global__ void __launch_bounds__(kPtBlock) k_trace_pt_f32(TravScene ts, Pools<f
   uint32_t grain = (n / (2u * n_waves) + 63u) & ~63u;
   grain = grain < 64u ? 64u : (grain > kGrain ? kGrain : grain);
 
-  auto push = [&](uint32_t ref, uint32_t nprims, float tmin) {
-    const uint32_t id = nprims ? (0x80000000u | (nprims << 19) | ref) : ref;
-    if (sp < (uint32_t)kPtStack) { stk_id[sp * kPtBlock + tid] = id; stk_t[sp * kPtBlock + tid] = tmin; }
-    else { uint32_t* o = ts.overflow + ((size_t)(sp - kPtStack) * ts.overflow_stride + gtid) * 2; o[0] = id; o[1] = __float_as_uint(tmin); }
-    sp++;
-  };
-  auto finish = [&]() {
+  auto finish = [&](bool found) {
     if (ANY) {
       if (occluded) occluded[qidx] = found ? 1 : 0;
       else if (!found) add_pending(p, qidx);
     } else {
       p.hit[qidx] = make_float4(r.tmax, __uint_as_float((uint32_t)hit), hu, hv);
     }
-    state = ST_IDLE;
+    cur = kIdle;
   };
   auto pop = [&]() {   // re-checks the one comparison that depends on the current t_max
     while (sp > 0) {
       sp--;
-      uint32_t id; float tmin;
-      if (sp < (uint32_t)kPtStack) { id = stk_id[sp * kPtBlock + tid]; tmin = stk_t[sp * kPtBlock + tid]; }
-      else { const uint32_t* o = ts.overflow + ((size_t)(sp - kPtStack) * ts.overflow_stride + gtid) * 2; id = o[0]; tmin = __uint_as_float(o[1]); }
-      if (!(tmin < r.tmax)) continue;
-      if (id & 0x80000000u) { lf = id & 0x7ffffu; ln = (id >> 19) & 0xfffu; state = ST_TRI; }
-      else { cur = id; state = ST_NODE; }
-      return;
+      // (the LDS read is unconditional and the overflow entry a rare fix-up: an if / else between the two address spaces compiles to flat loads)
+      uint2 e = stk[(sp < (uint32_t)kPtStack ? sp : 0u) * kPtBlock + tid];
+      asm volatile("" : "+v"(e.x), "+v"(e.y));
+      if (__builtin_expect(sp >= (uint32_t)kPtStack, 0)) e = *reinterpret_cast<const uint2*>(ts.overflow + ((size_t)(sp - kPtStack) * ts.overflow_stride + gtid) * 2);
+      if (__uint_as_float(e.y) < r.tmax) { cur = e.x; return; }
     }
-    finish();
+    finish(false);
   };
 
   while (true) {
     // ---- refill idle lanes ---------------------------------------------------------------------------------------
-    const uint64_t idle = __ballot(state == ST_IDLE);
+    const uint64_t idle = __ballot(cur == kIdle);
     const uint32_t n_idle = (uint32_t)__popcll(idle);
     if (!exhausted && (n_idle >= RRT_TR_REFILL)) {
       if (lo == hi) {
-        // XCD-aware work distribution (RRT_XCD_WORK): the queue is cut into 8 contiguous parts, one per group of workgroups that share an XCD
+        // XCD-aware work distribution: the queue is cut into 8 contiguous parts, one per group of workgroups that share an XCD
         // (blockIdx % 8, MI355X_MICROARCH.md: blocks are dealt round-robin over the XCDs). The queues are roughly in image order (the camera
         // kernel emits pixel block by pixel block, shading preserves the order), so a part's rays walk one region of the BVH, which then
         // fits that XCD's 4 MiB L2 instead of all 8 L2s each holding a third of the 11 MB tree. A group that runs dry helps with the next part.
@@ -389,76 +382,42 @@ __global__ void __launch_bounds__(kPtBlock) k_trace_pt_f32(TravScene ts, Pools<f
       if (!exhausted) {
         const uint32_t take = (hi - lo) < n_idle ? (hi - lo) : n_idle;
         const uint32_t rank = (uint32_t)__popcll(idle & ((1ull << lane) - 1ull));
-        if (state == ST_IDLE && rank < take) {
+        if (cur == kIdle && rank < take) {
           qidx = lo + rank;
-          int sk;
-          {
-            const float4 ro = (ANY && !occluded) ? p.sray_o[qidx] : p.ray_o[qidx], rd = (ANY && !occluded) ? p.sray_d[qidx] : p.ray_d[qidx];
-            V3<float> lo;
-            ray_tail(ro, (ANY && !occluded) ? 1.0f - 0.0001f : Const<float>::inf, &r.tmax, &lo);
-            r.ox = ro.x; r.oy = ro.y; r.oz = ro.z; r.dx = rd.x; r.dy = rd.y; r.dz = rd.z; sk = (int)__float_as_uint(rd.w);
-            r.lx = lo.x; r.ly = lo.y; r.lz = lo.z;
-          }
-          r.skip_plane = sk >= 0 ? __float_as_uint(ts.tris[(size_t)sk * 12 + 11]) : 0xffffffffu;
-          r.ix = 1.0f / r.dx; r.iy = 1.0f / r.dy; r.iz = 1.0f / r.dz;
-          r.neg = (r.ix < 0.0f ? 1u : 0u) | (r.iy < 0.0f ? 2u : 0u) | (r.iz < 0.0f ? 4u : 0u);
-          sp = 0; hit = -1; hu = 0.0f; hv = 0.0f; found = false;
-          float tmin;
-          if (ANY && !occluded && ts.any_entry && sk >= 0) { cur = ts.any_entry[sk]; state = ST_NODE; }   // (see TravScene::any_entry)
-          else if (ts.n_nodes != 0 && box_slabs_f32(ts.root_box[0], ts.root_box[1], ts.root_box[2], ts.root_box[3], ts.root_box[4], ts.root_box[5], r, &tmin) && tmin < r.tmax) {
-            if (ts.root_n) { lf = ts.root_ref; ln = ts.root_n; state = ST_TRI; }
-            else { cur = ts.root_ref; state = ST_NODE; }
-          } else finish();
+          sp = 0; hit = -1; hu = 0.0f; hv = 0.0f;
+          cur = lane_ray_begin<ANY>(ts, p, !occluded, qidx, r);
+          if (cur == kIdle) finish(false);
         }
         lo += take;
       }
     }
-    if (__ballot(state != ST_IDLE) == 0ull) { if (exhausted) break; else continue; }
+    const uint64_t m_node = __ballot(is_node(cur)), m_leaf = __ballot(is_leaf(cur));
+    if ((m_node | m_leaf) == 0ull) { if (exhausted) break; else continue; }
 
-    // ---- one step, for the lanes of ONE state only: the other path is not executed at all this iteration (its lanes
+    // ---- one step, for the lanes of ONE kind only: the other path is not executed at all this iteration (its lanes
     // wait). Node steps run while they outnumber the waiting triangle tests 2 : 1 (measured best of 1:1 ... 1:8; a leaf
     // holds 1-3 triangles against ~23 node steps per ray, so triangle lanes must not wait for a majority).
-    const uint32_t n_node = (uint32_t)__popcll(__ballot(state == ST_NODE)), n_tri = (uint32_t)__popcll(__ballot(state == ST_TRI));
-    const bool do_node = n_node * RRT_VOTE_A >= n_tri * RRT_VOTE_B;
-    if (do_node && state == ST_NODE) {
-      for (int rep_k = 0; rep_k < RRT_NODE_STEPS && state == ST_NODE; rep_k++) {
-      F4 a, b, c, d;
-      if (kPtTreelet > 0 && cur < n_tl) {
-        const float4 v0 = pt_treelet[cur * 4], v1 = pt_treelet[cur * 4 + 1], v2 = pt_treelet[cur * 4 + 2], v3 = pt_treelet[cur * 4 + 3];
-        a = {v0.x, v0.y, v0.z, v0.w}; b = {v1.x, v1.y, v1.z, v1.w}; c = {v2.x, v2.y, v2.z, v2.w}; d = {v3.x, v3.y, v3.z, v3.w};
-      } else {
-        const float* np = reinterpret_cast<const float*>(ts.pairs + cur);
-        a = ld4(np); b = ld4(np + 4); c = ld4(np + 8); d = ld4(np + 12);
-      }
-      const uint32_t ref0 = __float_as_uint(d.x), ref1 = __float_as_uint(d.y), meta = __float_as_uint(d.z);
-      const uint32_t n0 = (meta >> 2) & 0xfffu, n1 = (meta >> 14) & 0xfffu;
-      float t0, t1;
-      const bool s0 = box_slabs_f32(a.x, a.y, a.z, a.w, b.x, b.y, r, &t0), s1 = box_slabs_f32(b.z, b.w, c.x, c.y, c.z, c.w, r, &t1);
-      const bool h0 = s0 & (t0 < r.tmax), h1 = s1 & (t1 < r.tmax);
-      const bool second_first = (r.neg >> (meta & 3u)) & 1u;
-      // far child: judged against t_max when popped (closest-hit t_max can grow, Q10); see k_trace_pairs_f32
-      const bool hn = second_first ? h1 : h0, hf = ANY ? (second_first ? h0 : h1) : (second_first ? s0 : s1);
-      const uint32_t refn = second_first ? ref1 : ref0, reff = second_first ? ref0 : ref1;
-      const uint32_t nn = second_first ? n1 : n0, nf = second_first ? n0 : n1;
-      const float tf = second_first ? t0 : t1;
-      if (hf) push(reff, nf, tf);
-      if (hn) {
-        if (nn) { lf = refn; ln = nn; state = ST_TRI; }
-        else cur = refn;
-      } else pop();
-      }
-    } else if (!do_node && state == ST_TRI) {
-      // the whole leaf (1-3 triangles) in one step: fewer scheduling rounds than one triangle per step
-      do {
-        float t, u, v;
-        const bool h = tri_test_f32<ANY>(ts.tris + (size_t)lf * 12, r, &t, &u, &v);
-        if (h) {
-          if (ANY) found = true;
-          else { r.tmax = t; hit = (int)lf; hu = u; hv = v; }
+    const bool do_node = (uint32_t)__popcll(m_node) * RRT_VOTE_A >= (uint32_t)__popcll(m_leaf) * RRT_VOTE_B;
+    if (do_node) {
+      for (int rep_k = 0; rep_k < RRT_NODE_STEPS; rep_k++) {
+        if (is_node(cur)) {
+          const char* np = reinterpret_cast<const char*>(ts.pairs) + cur;   // 32-bit byte offset from a uniform base: no address arithmetic
+          const float4 a = *reinterpret_cast<const float4*>(np), b = *reinterpret_cast<const float4*>(np + 16), c = *reinterpret_cast<const float4*>(np + 32);
+          const uint4 d = *reinterpret_cast<const uint4*>(np + 48);
+          const PairStep st = pair_step_f32<ANY>(a, b, c, d, r);
+          if (st.push_far) {
+            const uint2 e = make_uint2(st.id_far, __float_as_uint(st.t_far));
+            if (sp < (uint32_t)kPtStack) stk[sp * kPtBlock + tid] = e;
+            else *reinterpret_cast<uint2*>(ts.overflow + ((size_t)(sp - kPtStack) * ts.overflow_stride + gtid) * 2) = e;
+            sp++;
+          }
+          if (st.go_near) cur = st.id_near;
+          else pop();
         }
-        lf++; ln--;
-      } while (ln != 0 && !(ANY && found));
-      if (ANY && found) finish();
+      }
+    } else if (is_leaf(cur)) {
+      // the whole leaf (1-3 triangles) in one step: fewer scheduling rounds than one triangle per step
+      if (leaf_step_f32<ANY>(ts, cur, r, &hit, &hu, &hv)) finish(true);
       else pop();
     }
   }

@@ -1296,17 +1296,21 @@ class Handle : public HandleBase {
         if (np == 0) compact[i] = n_int++;
         else if (np >= 4096) return;
       }
-      std::vector<PairNode> pairs(n_int);
+      struct Pair {   // host-side form; packed into the kernels' PairNode below
+        float b0min[3], b0max[3], b1min[3], b1max[3];
+        uint32_t ref0, ref1;   // interior child: pair index; leaf child: first triangle
+        uint32_t meta;         // bits 0-1 split axis, bits 2-13 n_prims of child 0 (0 = interior), bits 14-25 of child 1
+      };
+      std::vector<Pair> pairs(n_int);
       for (size_t i = 0; i < nodes.size(); i++) {
         if ((nodes[i].meta >> 2) != 0) continue;
-        PairNode& pn = pairs[compact[i]];
+        Pair& pn = pairs[compact[i]];
         const size_t c0 = i + 1, c1 = nodes[i].offset;
         const uint32_t n0 = nodes[c0].meta >> 2, n1 = nodes[c1].meta >> 2;
         for (int k = 0; k < 3; k++) { pn.b0min[k] = nodes[c0].bmin[k]; pn.b0max[k] = nodes[c0].bmax[k]; pn.b1min[k] = nodes[c1].bmin[k]; pn.b1max[k] = nodes[c1].bmax[k]; }
         pn.ref0 = n0 ? nodes[c0].offset : compact[c0];
         pn.ref1 = n1 ? nodes[c1].offset : compact[c1];
         pn.meta = (nodes[i].meta & 3u) | (n0 << 2) | (n1 << 14);
-        pn.pad = 0;
       }
       // renumber: the BFS top of the tree first (staged in LDS by the kernels), the rest in pre-order
       if (n_int > 0 && (nodes[0].meta >> 2) == 0) {
@@ -1318,7 +1322,7 @@ class Handle : public HandleBase {
           for (uint32_t k : frontier) {
             if (order.size() >= (size_t)kTreeletNodes) break;
             order.push_back(k); taken[k] = 1;
-            const PairNode& pn = pairs[k];
+            const Pair& pn = pairs[k];
             if (((pn.meta >> 2) & 0xfffu) == 0) next.push_back(pn.ref0);
             if (((pn.meta >> 14) & 0xfffu) == 0) next.push_back(pn.ref1);
           }
@@ -1329,9 +1333,9 @@ class Handle : public HandleBase {
         std::vector<uint32_t> newidx(n_int);
         for (uint32_t i = 0; i < n_int; i++) newidx[order[i]] = i;
         newidx_keep_ = newidx;
-        std::vector<PairNode> re(n_int);
+        std::vector<Pair> re(n_int);
         for (uint32_t i = 0; i < n_int; i++) {
-          PairNode pn = pairs[order[i]];
+          Pair pn = pairs[order[i]];
           if (((pn.meta >> 2) & 0xfffu) == 0) pn.ref0 = newidx[pn.ref0];
           if (((pn.meta >> 14) & 0xfffu) == 0) pn.ref1 = newidx[pn.ref1];
           re[i] = pn;
@@ -1380,18 +1384,32 @@ class Handle : public HandleBase {
             const uint32_t off = on == c0 ? c1 : c0;
             if (box_dist2(nodes[off], nd) <= reach2) { e = a; break; }
           }
-          for (uint32_t t = 0; t < np; t++) if ((size_t)nd.offset + t < n_tris) entry[nd.offset + t] = pair_of[e];
+          for (uint32_t t = 0; t < np; t++) if ((size_t)nd.offset + t < n_tris) entry[nd.offset + t] = pair_of[e] * 64u;   // child word of an interior node
         }
         any_entry_.upload(entry, st_);
       }
-      pairs_.upload(pairs, st_);
+      // the kernels' form: plane coordinates paired for the packed slab arithmetic, children as ready-made stack words
+      if ((uint64_t)n_int * 64u >= kIdle) return;
+      std::vector<PairNode> packed(n_int);
+      auto child_word = [](uint32_t ref, uint32_t n_prims) { return n_prims ? (kLeafBit | (n_prims << 19) | ref) : ref * 64u; };
+      for (uint32_t i = 0; i < n_int; i++) {
+        const Pair& s = pairs[i];
+        PairNode& d = packed[i];
+        d.xy0[0] = s.b0min[0]; d.xy0[1] = s.b0min[1]; d.xy0[2] = s.b0max[0]; d.xy0[3] = s.b0max[1];
+        d.xy1[0] = s.b1min[0]; d.xy1[1] = s.b1min[1]; d.xy1[2] = s.b1max[0]; d.xy1[3] = s.b1max[1];
+        d.zz[0] = s.b0min[2]; d.zz[1] = s.b0max[2]; d.zz[2] = s.b1min[2]; d.zz[3] = s.b1max[2];
+        d.id0 = child_word(s.ref0, (s.meta >> 2) & 0xfffu);
+        d.id1 = child_word(s.ref1, (s.meta >> 14) & 0xfffu);
+        d.axis = s.meta & 3u;
+        d.pad = 0;
+      }
+      pairs_.upload(packed, st_);
       HIP_CHECK(hipStreamSynchronize(st_));
       trav_.any_entry = (any_entry_on_ && any_entry_.n) ? any_entry_.p : nullptr;
       trav_.pairs = pairs_.p;
       trav_.tris = reinterpret_cast<const float*>(tris_.p);
       for (int k = 0; k < 3; k++) { trav_.root_box[k] = nodes[0].bmin[k]; trav_.root_box[3 + k] = nodes[0].bmax[k]; }
-      trav_.root_n = nodes[0].meta >> 2;
-      trav_.root_ref = trav_.root_n ? nodes[0].offset : 0u;
+      trav_.root_id = (nodes[0].meta >> 2) ? (kLeafBit | ((nodes[0].meta >> 2) << 19) | nodes[0].offset) : 0u;
       trav_.n_nodes = (uint32_t)nodes.size();
       pairs_ok_ = true;
     }
