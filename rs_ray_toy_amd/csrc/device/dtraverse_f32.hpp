@@ -39,7 +39,7 @@
 namespace rrtd {
 
 constexpr int kTravBlock = 512;     // 8 waves share one LDS copy of the treelet
-constexpr int kStackLds = 8;        // LDS stack entries per thread (8 B each); deeper entries spill to global
+constexpr int kStackLds = 8;        // LDS stack entries per thread (8 B each); deeper entries spill to global (>= kAnyList: a list starts on the LDS part)
 constexpr int kTreeletNodes = 512;  // top of the tree (BFS order) staged in LDS: 512 pair nodes = 32 KB
 
 // Field order chosen for the packed fp32 VALU forms (v_pk_add_f32 / v_pk_mul_f32 work on aligned register pairs, and a 128-bit load
@@ -147,22 +147,27 @@ struct TravScene {
   uint32_t overflow_stride;
   // Shadow rays (any-hit, t_max = 1 - 1e-4, unit direction: Q9) of the pool start ON a triangle and reach less than one unit far. Every
   // ancestor of that triangle's leaf contains the origin, so its box test passes whatever the direction, and a sibling subtree whose box is
-  // more than a unit away from the leaf's box fails whatever the direction: the walk from the root down to the first ancestor with a NEAR
-  // sibling - half of the 47 box tests of an average shadow ray on the 100k-triangle mesh - decides nothing. any_entry[triangle] is that
-  // ancestor's child word (host: build_pairs()); an occlusion query is order independent, so starting there changes no result. Null = off.
-  const uint32_t* any_entry;
+  // more than a unit away from the leaf's box fails it whatever the direction: a pair node on the way down whose off-path child is that far
+  // away - half of the 17 levels above an average leaf of the 100k-triangle mesh - decides nothing. any_list holds, per triangle, the nodes
+  // that do decide something (host: build_pairs()): word 0 = where the ordinary walk resumes (a child word), words 1..6 = the pair nodes
+  // above it whose off-path child is within reach, flagged with the child to leave out (kSkip0 / kSkip1: the on-path child - the walk does
+  // not go down through it), word 7 = how many of those there are. They start on the lane's stack. The boxes tested, the leaves visited and
+  // the triangles tested are the reference's, less the tests that cannot pass; an occlusion query is order independent. Null = off.
+  const uint4* any_list;
 };
 
 // A lane's position in the walk is one child word: an interior node to visit (byte offset of its PairNode, < kIdle), a leaf to test
 // (kLeafBit set), or kIdle. The traversal stack holds the same words with the child's entry distance.
 constexpr uint32_t kIdle = 0x7fffffffu;
+constexpr uint32_t kSkip0 = 1u, kSkip1 = 2u;   // any-hit list entries (TravScene::any_list): low bits of an interior child word
+constexpr int kAnyList = 6;                    // flagged entries per list
 RRT_DEV bool is_node(uint32_t w) { return w < kIdle; }
 RRT_DEV bool is_leaf(uint32_t w) { return (int32_t)w < 0; }
 
 // Ray `idx` of the queue this launch serves (POOL_SHADOW: the pool's shadow rays, t_max = 1 - 1e-4; otherwise the closest-ray arrays
 // with their own t_max) -> lane registers; returns the word the walk starts with (kIdle: the ray misses the root box).
 template <bool POOL_SHADOW>
-RRT_DEV uint32_t lane_ray_begin(const TravScene& ts, const Pools<float>& p, bool pool_shadow, uint32_t idx, LaneRay& r) {
+RRT_DEV uint32_t lane_ray_begin(const TravScene& ts, const Pools<float>& p, bool pool_shadow, uint32_t idx, LaneRay& r, int* start_tri) {
   const float4 ro = (POOL_SHADOW && pool_shadow) ? p.sray_o[idx] : p.ray_o[idx], rd = (POOL_SHADOW && pool_shadow) ? p.sray_d[idx] : p.ray_d[idx];
   V3<float> lo;
   ray_tail(ro, (POOL_SHADOW && pool_shadow) ? 1.0f - 0.0001f : Const<float>::inf, &r.tmax, &lo);
@@ -172,7 +177,8 @@ RRT_DEV uint32_t lane_ray_begin(const TravScene& ts, const Pools<float>& p, bool
   r.skip_plane = sk >= 0 ? __float_as_uint(ts.tris[(size_t)sk * 12 + 11]) : 0xffffffffu;
   r.ixy = v2f{1.0f / r.dx, 1.0f / r.dy}; r.izz.x = 1.0f / r.dz; r.izz.y = r.izz.x;
   r.neg = (r.ixy.x < 0.0f ? 1u : 0u) | (r.ixy.y < 0.0f ? 2u : 0u) | (r.izz.x < 0.0f ? 4u : 0u);
-  if (POOL_SHADOW && pool_shadow && ts.any_entry && sk >= 0) return ts.any_entry[sk];   // (see TravScene::any_entry)
+  *start_tri = (POOL_SHADOW && pool_shadow && ts.any_list) ? sk : -1;   // >= 0: the walk starts from any_list[start_tri] (the caller owns the stack)
+  if (*start_tri >= 0) return kIdle;
   float tmin;
   if (ts.n_nodes != 0 && box_slabs_f32(ts.root_box[0], ts.root_box[1], ts.root_box[2], ts.root_box[3], ts.root_box[4], ts.root_box[5], r, &tmin) && tmin < r.tmax)
     return ts.root_id;
@@ -185,8 +191,12 @@ RRT_DEV uint32_t lane_ray_begin(const TravScene& ts, const Pools<float>& p, bool
 // Shadow rays never change t_max: they prune at once. The selections are written on lane masks (scalar unit), not on 0 / 1 values.
 struct PairStep { uint32_t id_near, id_far; float t_far; bool go_near, push_far; };
 template <bool ANY>
-RRT_DEV PairStep pair_step_f32(const float4 a, const float4 b, const float4 c, const uint4 d, const LaneRay& r) {
-  const PairHit h = pair_slabs_f32(a, b, c, r);
+RRT_DEV PairStep pair_step_f32(const float4 a, const float4 b, const float4 c, const uint4 d, const LaneRay& r, uint32_t word) {
+  PairHit h = pair_slabs_f32(a, b, c, r);
+  if (ANY) {   // a list entry (TravScene::any_list) leaves out the child the walk does not go down through
+    h.s0 &= ~__builtin_amdgcn_ballot_w64((word & kSkip0) != 0u);
+    h.s1 &= ~__builtin_amdgcn_ballot_w64((word & kSkip1) != 0u);
+  }
   // lane masks and scalar logic: the compiler turns a select between two conditions into 0 / 1 values and five vector instructions
   const uint64_t m_sf = __builtin_amdgcn_ballot_w64(((r.neg >> d.z) & 1u) != 0u);
   const uint64_t m_s0 = h.s0, m_s1 = h.s1;
@@ -238,11 +248,18 @@ __global__ void __launch_bounds__(kTravBlock) k_trace_pairs_f32(TravScene ts, Po
   const uint32_t treelet_bytes = ts.n_treelet * 64u;
   for (uint32_t gid = col; gid < n; gid += gridDim.x * kTravBlock) {
     LaneRay r;
-    uint32_t cur = lane_ray_begin<ANY>(ts, p, !occluded, gid, r);
+    int start_tri;
+    uint32_t cur = lane_ray_begin<ANY>(ts, p, !occluded, gid, r, &start_tri);
     int hit = -1;
     float hu = 0.0f, hv = 0.0f;
     bool found = false;
     uint32_t sp = 0;
+    if (ANY && start_tri >= 0) {   // TravScene::any_list
+      const uint4 la = ts.any_list[2 * (size_t)start_tri], lb = ts.any_list[2 * (size_t)start_tri + 1];
+      cur = la.x; sp = lb.w;
+      stk[0 * kTravBlock + tid] = make_uint2(la.y, 0u); stk[1 * kTravBlock + tid] = make_uint2(la.z, 0u); stk[2 * kTravBlock + tid] = make_uint2(la.w, 0u);
+      stk[3 * kTravBlock + tid] = make_uint2(lb.x, 0u); stk[4 * kTravBlock + tid] = make_uint2(lb.y, 0u); stk[5 * kTravBlock + tid] = make_uint2(lb.z, 0u);
+    }
     auto pop = [&]() {   // re-checks the one comparison that depends on the current t_max
       cur = kIdle;
       while (sp > 0) {
@@ -256,16 +273,17 @@ __global__ void __launch_bounds__(kTravBlock) k_trace_pairs_f32(TravScene ts, Po
     while (__ballot(cur != kIdle) != 0ull) {
       while (is_node(cur)) {
         float4 a, b, c; uint4 d;
-        if (cur < treelet_bytes) {
-          const float4* tp = treelet + (cur >> 4);
+        const uint32_t off = ANY ? (cur & ~63u) : cur;
+        if (off < treelet_bytes) {
+          const float4* tp = treelet + (off >> 4);
           a = tp[0]; b = tp[1]; c = tp[2]; const float4 dd = tp[3];
           d = make_uint4(__float_as_uint(dd.x), __float_as_uint(dd.y), __float_as_uint(dd.z), 0u);
         } else {
-          const char* np = reinterpret_cast<const char*>(ts.pairs) + cur;
+          const char* np = reinterpret_cast<const char*>(ts.pairs) + off;
           a = *reinterpret_cast<const float4*>(np); b = *reinterpret_cast<const float4*>(np + 16); c = *reinterpret_cast<const float4*>(np + 32);
           d = *reinterpret_cast<const uint4*>(np + 48);
         }
-        const PairStep st = pair_step_f32<ANY>(a, b, c, d, r);
+        const PairStep st = pair_step_f32<ANY>(a, b, c, d, r, cur);
         if (st.push_far) {
           const uint2 e = make_uint2(st.id_far, __float_as_uint(st.t_far));
           if (sp < (uint32_t)kStackLds) stk[sp * kTravBlock + tid] = e;
@@ -303,11 +321,22 @@ __global__ void __launch_bounds__(kTravBlock) k_trace_pairs_f32(TravScene ts, Po
 #define RRT_PT_BLOCK 256
 #endif
 #ifndef RRT_PT_STACK
-#define RRT_PT_STACK 10
+#define RRT_PT_STACK 8
 #endif
+#ifndef RRT_PT_STACK_ANY
+#define RRT_PT_STACK_ANY 10
+#endif
+#ifndef RRT_PT_TREELET
+#define RRT_PT_TREELET 64
+#endif
+// LDS of a 256-thread workgroup, 20 KB so that eight of them (8 waves per SIMD) fit a CU's 160 KB: closest-hit = 8 stack entries per lane +
+// the top 64 pair nodes of the tree (BFS order; 28 % of its node fetches, which then do not queue at the vector L1 - the unit this kernel
+// keeps busiest); any-hit = 10 stack entries and no treelet (its rays start from their lists, far below the top). Measured frame times
+// with (entries, nodes) = (10, 0) 44.4 ms, (9, 32) 43.5, (8, 64) 43.4, (7, 96) 44.6, (6, 128) 45.2, (5, 160) 46.4 when both kernels shared one setting.
+constexpr int kPtTreelet = RRT_PT_TREELET;   // closest-hit only
 constexpr uint32_t kXcdParts = 8u;   // parts of a queue with their own work cursor (8 XCDs)
 constexpr int kPtBlock = RRT_PT_BLOCK;
-constexpr int kPtStack = RRT_PT_STACK;
+constexpr int kPtStack = RRT_PT_STACK, kPtStackAny = RRT_PT_STACK_ANY;   // LDS stack entries per lane (closest-hit, any-hit); deeper entries spill to global
 constexpr uint32_t kGrain = 256;
 
 template <bool ANY>
@@ -317,7 +346,16 @@ __global__ void __launch_bounds__(kPtBlock) k_trace_pt_f32(TravScene ts, Pools<f
     const uint32_t nn = count ? *count : n_fixed;
     if (nn < n_lo || nn >= n_hi) return;
   }
-  __shared__ uint2 stk[kPtStack * kPtBlock];   // [entry][thread]: {child word, entry distance}, one ds_write_b64 / ds_read_b64 each
+  constexpr int kStack = ANY ? kPtStackAny : kPtStack, kTl = ANY ? 0 : kPtTreelet;
+  __shared__ uint2 stk[kStack * kPtBlock];   // [entry][thread]: {child word, entry distance}, one ds_write_b64 / ds_read_b64 each
+  // Top of the tree in LDS. A lane reads the four 16-byte words of ITS node, so with nodes laid out as in memory all lanes of an instruction
+  // would hit the 4 of 16 bank groups their word index selects: word w of node n lives at slot w ^ ((n >> 2) & 3) instead.
+  __shared__ float4 pt_treelet[kTl > 0 ? kTl * 4 : 1];
+  const uint32_t tl_bytes = kTl > 0 ? (ts.n_treelet < (uint32_t)kTl ? ts.n_treelet : (uint32_t)kTl) * 64u : 0u;
+  if (kTl > 0) {
+    for (uint32_t i = threadIdx.x; i < tl_bytes / 16u; i += kPtBlock) pt_treelet[(i & ~3u) | ((i ^ (i >> 4)) & 3u)] = reinterpret_cast<const float4*>(ts.pairs)[i];
+    __syncthreads();
+  }
   const uint32_t tid = threadIdx.x, lane = tid & 63u;
   const uint32_t gtid = blockIdx.x * blockDim.x + tid;   // overflow-stack column of this lane
   const uint32_t n = count ? *count : n_fixed;
@@ -350,9 +388,9 @@ __global__ void __launch_bounds__(kPtBlock) k_trace_pt_f32(TravScene ts, Pools<f
     while (sp > 0) {
       sp--;
       // (the LDS read is unconditional and the overflow entry a rare fix-up: an if / else between the two address spaces compiles to flat loads)
-      uint2 e = stk[(sp < (uint32_t)kPtStack ? sp : 0u) * kPtBlock + tid];
+      uint2 e = stk[(sp < (uint32_t)kStack ? sp : 0u) * kPtBlock + tid];
       asm volatile("" : "+v"(e.x), "+v"(e.y));
-      if (__builtin_expect(sp >= (uint32_t)kPtStack, 0)) e = *reinterpret_cast<const uint2*>(ts.overflow + ((size_t)(sp - kPtStack) * ts.overflow_stride + gtid) * 2);
+      if (__builtin_expect(sp >= (uint32_t)kStack, 0)) e = *reinterpret_cast<const uint2*>(ts.overflow + ((size_t)(sp - kStack) * ts.overflow_stride + gtid) * 2);
       if (__uint_as_float(e.y) < r.tmax) { cur = e.x; return; }
     }
     finish(false);
@@ -385,7 +423,14 @@ __global__ void __launch_bounds__(kPtBlock) k_trace_pt_f32(TravScene ts, Pools<f
         if (cur == kIdle && rank < take) {
           qidx = lo + rank;
           sp = 0; hit = -1; hu = 0.0f; hv = 0.0f;
-          cur = lane_ray_begin<ANY>(ts, p, !occluded, qidx, r);
+          int start_tri;
+          cur = lane_ray_begin<ANY>(ts, p, !occluded, qidx, r, &start_tri);
+          if (ANY && start_tri >= 0) {   // TravScene::any_list
+            const uint4 la = ts.any_list[2 * (size_t)start_tri], lb = ts.any_list[2 * (size_t)start_tri + 1];
+            cur = la.x; sp = lb.w;
+            stk[0 * kPtBlock + tid] = make_uint2(la.y, 0u); stk[1 * kPtBlock + tid] = make_uint2(la.z, 0u); stk[2 * kPtBlock + tid] = make_uint2(la.w, 0u);
+            stk[3 * kPtBlock + tid] = make_uint2(lb.x, 0u); stk[4 * kPtBlock + tid] = make_uint2(lb.y, 0u); stk[5 * kPtBlock + tid] = make_uint2(lb.z, 0u);
+          }
           if (cur == kIdle) finish(false);
         }
         lo += take;
@@ -401,14 +446,24 @@ __global__ void __launch_bounds__(kPtBlock) k_trace_pt_f32(TravScene ts, Pools<f
     if (do_node) {
       for (int rep_k = 0; rep_k < RRT_NODE_STEPS; rep_k++) {
         if (is_node(cur)) {
-          const char* np = reinterpret_cast<const char*>(ts.pairs) + cur;   // 32-bit byte offset from a uniform base: no address arithmetic
-          const float4 a = *reinterpret_cast<const float4*>(np), b = *reinterpret_cast<const float4*>(np + 16), c = *reinterpret_cast<const float4*>(np + 32);
-          const uint4 d = *reinterpret_cast<const uint4*>(np + 48);
-          const PairStep st = pair_step_f32<ANY>(a, b, c, d, r);
+          const uint32_t off = ANY ? (cur & ~63u) : cur;
+          float4 a, b, c; uint4 d;
+          if (kTl > 0 && off < tl_bytes) {
+            const uint32_t x = off ^ ((off >> 4) & 0x30u);   // byte address of word 0's slot
+            const char* lp = reinterpret_cast<const char*>(pt_treelet);
+            a = *reinterpret_cast<const float4*>(lp + x); b = *reinterpret_cast<const float4*>(lp + (x ^ 16u)); c = *reinterpret_cast<const float4*>(lp + (x ^ 32u));
+            const float4 dd = *reinterpret_cast<const float4*>(lp + (x ^ 48u));
+            d = make_uint4(__float_as_uint(dd.x), __float_as_uint(dd.y), __float_as_uint(dd.z), 0u);
+          } else {
+            const char* np = reinterpret_cast<const char*>(ts.pairs) + off;   // 32-bit byte offset from a uniform base: no address arithmetic
+            a = *reinterpret_cast<const float4*>(np); b = *reinterpret_cast<const float4*>(np + 16); c = *reinterpret_cast<const float4*>(np + 32);
+            d = *reinterpret_cast<const uint4*>(np + 48);
+          }
+          const PairStep st = pair_step_f32<ANY>(a, b, c, d, r, cur);
           if (st.push_far) {
             const uint2 e = make_uint2(st.id_far, __float_as_uint(st.t_far));
-            if (sp < (uint32_t)kPtStack) stk[sp * kPtBlock + tid] = e;
-            else *reinterpret_cast<uint2*>(ts.overflow + ((size_t)(sp - kPtStack) * ts.overflow_stride + gtid) * 2) = e;
+            if (sp < (uint32_t)kStack) stk[sp * kPtBlock + tid] = e;
+            else *reinterpret_cast<uint2*>(ts.overflow + ((size_t)(sp - kStack) * ts.overflow_stride + gtid) * 2) = e;
             sp++;
           }
           if (st.go_near) cur = st.id_near;

@@ -365,7 +365,7 @@ class Handle : public HandleBase {
     else if (key == "overlap_shadow") overlap_shadow_ = v != 0;
     else if (key == "aux_margin") aux_margin_ = v != 0;
     else if (key == "frame_stats") frame_stats_ = v != 0;
-    else if (key == "any_entry") { any_entry_on_ = v != 0; trav_.any_entry = (any_entry_on_ && any_entry_.n) ? any_entry_.p : nullptr; }
+    else if (key == "any_entry") { any_entry_on_ = v != 0; trav_.any_list = (any_entry_on_ && any_list_.n) ? reinterpret_cast<const uint4*>(any_list_.p) : nullptr; }
     else if (key == "nonblocking_streams") {   // see rrt.h: needed for two handles to overlap their frames
       if (pending_) throw std::invalid_argument("nonblocking_streams: a frame is in flight");
       HIP_CHECK(hipSetDevice(dev_));
@@ -727,7 +727,7 @@ class Handle : public HandleBase {
   int trav_mode_ = 3;   // 1 = LDS-treelet grid-stride kernel, 2 = persistent-thread kernel, 3 = by queue size
   uint32_t pt_split_closest_ = 100000u, pt_split_any_ = 100000u;   // re-tuned with the shadow launches overlapped (tools/band_scaling.py)
   DevBuf<uint32_t> pt_overflow_, pt_overflow_any_;
-  DevBuf<uint32_t> any_entry_;             // TravScene::any_entry
+  DevBuf<uint32_t> any_list_;              // TravScene::any_list, 8 words per triangle
   bool any_entry_on_ = true;
   std::vector<uint32_t> newidx_keep_;      // build_pairs(): BFS renumbering of the pair nodes
   DevBuf<uint32_t> pix_off_;
@@ -1264,10 +1264,8 @@ class Handle : public HandleBase {
           HIP_CHECK(hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, dev_));
           HIP_CHECK(hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu, k_trace_pt_f32<false>, kPtBlock, 0));
           pt_grid_ = (uint32_t)(std::max(1, per_cu) * std::max(1, cus));
-          if (pairs_ok_ && scene_.stack_depth > (uint32_t)kPtStack) {
-            pt_overflow_.alloc((size_t)(scene_.stack_depth - kPtStack) * (size_t)pt_grid_ * kPtBlock * 2);
-            pt_overflow_any_.alloc((size_t)(scene_.stack_depth - kPtStack) * (size_t)pt_grid_ * kPtBlock * 2);
-          }
+          if (pairs_ok_ && scene_.stack_depth > (uint32_t)kPtStack) pt_overflow_.alloc((size_t)(scene_.stack_depth - kPtStack) * (size_t)pt_grid_ * kPtBlock * 2);
+          if (pairs_ok_ && scene_.stack_depth > (uint32_t)kPtStackAny) pt_overflow_any_.alloc((size_t)(scene_.stack_depth - kPtStackAny) * (size_t)pt_grid_ * kPtBlock * 2);
         }
         TravScene t2 = trav_;
         t2.overflow = any ? pt_overflow_any_.p : pt_overflow_.p;
@@ -1342,10 +1340,12 @@ class Handle : public HandleBase {
         }
         pairs.swap(re);
       } else trav_.n_treelet = 0;
-      // any-hit entry nodes (TravScene::any_entry): per leaf, the first ancestor on the way down from the root whose OTHER child's box is
-      // within reach of a shadow ray (1 - 1e-4 long, Q9; 1.02 with room for the fp32 box rounding, the test's widening and |d| = 1 +- 1e-6)
-      std::vector<uint32_t> entry(n_tris, 0u);
+      // any-hit start lists (TravScene::any_list): per triangle, the pair nodes between the root and its leaf whose OFF-path child is within
+      // reach of a shadow ray (1 - 1e-4 long, Q9; 1.02 with room for the fp32 box rounding, the test's widening and |d| = 1 +- 1e-6), top down,
+      // at most kAnyList of them; the ordinary walk resumes at the next such node (or at the leaf itself when the list holds them all).
+      std::vector<uint32_t> lists;
       if (n_int > 0 && (nodes[0].meta >> 2) == 0) {
+        lists.assign(n_tris * 8, kIdle);
         std::vector<uint32_t> pair_of(nodes.size(), 0xffffffffu);   // linear interior node -> pair node id as the kernels index them
         {
           std::vector<uint32_t> renum(n_int);
@@ -1360,9 +1360,9 @@ class Handle : public HandleBase {
           return d2;
         };
         const double reach2 = 1.02 * 1.02;
-        // iterative pre-order walk carrying the path of (interior node, on-path child is its second child)
+        // iterative pre-order walk carrying the path of interior nodes from the root to the current node's parent
         struct Step { uint32_t node; uint32_t depth; };
-        std::vector<uint32_t> path;   // interior nodes from the root to the current node's parent
+        std::vector<uint32_t> path;
         std::vector<Step> todo{{0u, 0u}};
         while (!todo.empty()) {
           const Step st = todo.back(); todo.pop_back();
@@ -1375,18 +1375,23 @@ class Handle : public HandleBase {
             todo.push_back({st.node + 1, st.depth + 1});
             continue;
           }
-          // leaf: first ancestor (from the root) whose off-path child is near; its parent if none is
-          uint32_t e = path.empty() ? 0u : path.back();
+          uint32_t words[8];
+          for (uint32_t& w : words) w = kIdle;
+          uint32_t n_flagged = 0;
+          words[0] = kLeafBit | (np << 19) | nd.offset;   // every deciding node fits the list: only the leaf itself is left
           for (size_t k = 0; k < path.size(); k++) {
             const uint32_t a = path[k];
             const uint32_t on = (k + 1 < path.size()) ? path[k + 1] : st.node;
             const uint32_t c0 = a + 1, c1 = nodes[a].offset;
             const uint32_t off = on == c0 ? c1 : c0;
-            if (box_dist2(nodes[off], nd) <= reach2) { e = a; break; }
+            if (box_dist2(nodes[off], nd) > reach2) continue;   // the off-path child cannot be hit from this leaf: the node decides nothing
+            if (n_flagged == (uint32_t)kAnyList) { words[0] = pair_of[a] * 64u; break; }   // list full: the ordinary walk takes over here
+            words[1 + n_flagged++] = (pair_of[a] * 64u) | (on == c0 ? kSkip0 : kSkip1);
           }
-          for (uint32_t t = 0; t < np; t++) if ((size_t)nd.offset + t < n_tris) entry[nd.offset + t] = pair_of[e] * 64u;   // child word of an interior node
+          words[7] = n_flagged;
+          for (uint32_t t = 0; t < np; t++) if ((size_t)nd.offset + t < n_tris) for (int w = 0; w < 8; w++) lists[((size_t)nd.offset + t) * 8 + w] = words[w];
         }
-        any_entry_.upload(entry, st_);
+        any_list_.upload(lists, st_);
       }
       // the kernels' form: plane coordinates paired for the packed slab arithmetic, children as ready-made stack words
       if ((uint64_t)n_int * 64u >= kIdle) return;
@@ -1405,7 +1410,7 @@ class Handle : public HandleBase {
       }
       pairs_.upload(packed, st_);
       HIP_CHECK(hipStreamSynchronize(st_));
-      trav_.any_entry = (any_entry_on_ && any_entry_.n) ? any_entry_.p : nullptr;
+      trav_.any_list = (any_entry_on_ && any_list_.n) ? reinterpret_cast<const uint4*>(any_list_.p) : nullptr;
       trav_.pairs = pairs_.p;
       trav_.tris = reinterpret_cast<const float*>(tris_.p);
       for (int k = 0; k < 3; k++) { trav_.root_box[k] = nodes[0].bmin[k]; trav_.root_box[3 + k] = nodes[0].bmax[k]; }

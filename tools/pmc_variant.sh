@@ -1,5 +1,5 @@
 #!/bin/bash
-# usage (GPU box): tools/pmc_variant.sh <name> [<name> ...]   ("default" = rs_ray_toy_amd/csrc/librrt.so)
+# usage (GPU box): [BENCH_OPTS="--opt key=value ..."] tools/pmc_variant.sh <name> [<name> ...]   ("default" = rs_ray_toy_amd/csrc/librrt.so)
 # SQ counters (two --pmc passes) of a short one-frame-at-a-time bench.py run per kernel-tuning variant -> gpurun_out/pv_<name>.txt
 cd /tmp && export TMPDIR=/tmp && cd $GRAFT_REPO_ROOT
 for v in "$@"; do
@@ -10,7 +10,7 @@ for v in "$@"; do
   for set in "SQ_WAVES SQ_WAVE_CYCLES SQ_BUSY_CYCLES SQ_INSTS_VALU SQ_ACTIVE_INST_VALU SQ_THREAD_CYCLES_VALU SQ_WAIT_INST_ANY SQ_WAIT_ANY" \
              "SQ_INSTS_VMEM_RD SQ_INSTS_LDS SQ_INSTS_SALU SQ_ACTIVE_INST_ANY SQ_ACTIVE_INST_SCA SQ_INSTS_VMEM_WR SQ_INSTS_SMEM SQ_INSTS_BRANCH"; do
     i=$((i+1))
-    timeout -k 10 300 rocprofv3 --pmc $set --output-format csv -d $out/pass$i -- python3 bench.py --no-cpu-baseline --steps 2 --warmup 1 --frames-in-flight 1 > $out.pass$i.log 2>&1 || { tail -5 $out.pass$i.log; exit 1; }
+    timeout -k 10 300 rocprofv3 --pmc $set --output-format csv -d $out/pass$i -- python3 bench.py --no-cpu-baseline --steps 2 --warmup 1 --frames-in-flight 1 $BENCH_OPTS > $out.pass$i.log 2>&1 || { tail -5 $out.pass$i.log; exit 1; }
   done
   python3 tools/pmc_kernels.py $out > gpurun_out/pv_$v.txt
   python3 - $out <<'PY' >> gpurun_out/pv_$v.txt
