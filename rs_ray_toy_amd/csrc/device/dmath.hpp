@@ -242,6 +242,10 @@ RRT_DEV uint32_t div5(uint32_t a) { return __umulhi(a, 0xCCCCCCCDu) >> 2; }
 RRT_DEV uint32_t div7(uint32_t a) { const uint32_t q = __umulhi(a, 0x24924925u); return (((a - q) >> 1) + q) >> 2; }
 template <typename R>
 RRT_DEV void halton_cam4(const SceneDev<R>& s, uint32_t index, double* d0, double* d1, double* d2, double* d3) {
+#ifdef RRT_EXP_FAKE_HALTON
+  { uint32_t h = index * 2654435761u; *d0 = (double)(h >> 8) * (1.0 / 16777216.0); h = h * 2654435761u + 1u; *d1 = (double)(h >> 8) * (1.0 / 16777216.0);
+    h = h * 2654435761u + 1u; *d2 = (double)(h >> 8) * (1.0 / 16777216.0); h = h * 2654435761u + 1u; *d3 = (double)(h >> 8) * (1.0 / 16777216.0); return; }
+#endif
   if (s.sample_at_center) { *d0 = 0.5; *d1 = 0.5; }
   else {
     *d0 = (double)__brev(index >> s.base_exp0) * 2.3283064365386963e-10;

@@ -892,6 +892,9 @@ static __global__ void __launch_bounds__(kRgDense) k_raygen_main_f32(SceneDev<fl
     index = po.x + (pd.s_begin + sl) * s.stride;
     double d0, d1, d2, d3;
     halton_cam4(s, index, &d0, &d1, &d2, &d3);
+#ifdef RRT_EXP_HALTON_TWICE
+    { double e0, e1, e2, e3; uint32_t i2 = index ^ 0x5a5a5u; asm volatile("" : "+v"(i2)); halton_cam4(s, i2, &e0, &e1, &e2, &e3); if (e0 + e1 + e2 + e3 == 123.0) d0 = e1; }
+#endif
     pfx = (float)px + to_real<float>(d0); pfy = (float)py + to_real<float>(d1);
     lx = to_real<float>(d2) + 0.5f; ly = to_real<float>(d3) + 0.5f;   // Q5
     if (write_samp) p.samp[slot] = make_float4(pfx, pfy, lx, ly);
