@@ -240,28 +240,49 @@ RRT_DEV double halton_cam_dim(const SceneDev<R>& s, uint32_t index, int which) {
 RRT_DEV uint32_t div3(uint32_t a) { return __umulhi(a, 0xAAAAAAABu) >> 1; }
 RRT_DEV uint32_t div5(uint32_t a) { return __umulhi(a, 0xCCCCCCCDu) >> 2; }
 RRT_DEV uint32_t div7(uint32_t a) { const uint32_t q = __umulhi(a, 0x24924925u); return (((a - q) >> 1) + q) >> 2; }
+constexpr uint32_t kCamB3 = 729u, kCamB5 = 15625u, kCamB7 = 16807u;   // 3^6, 5^6, 7^5: low-digit blocks of SceneDev::cam_lo / cam_hi
 template <typename R>
 RRT_DEV void halton_cam4(const SceneDev<R>& s, uint32_t index, double* d0, double* d1, double* d2, double* d3) {
 #ifdef RRT_EXP_FAKE_HALTON
   { uint32_t h = index * 2654435761u; *d0 = (double)(h >> 8) * (1.0 / 16777216.0); h = h * 2654435761u + 1u; *d1 = (double)(h >> 8) * (1.0 / 16777216.0);
     h = h * 2654435761u + 1u; *d2 = (double)(h >> 8) * (1.0 / 16777216.0); h = h * 2654435761u + 1u; *d3 = (double)(h >> 8) * (1.0 / 16777216.0); return; }
 #endif
+  // With the tables the digits of an index come in two blocks: reversed = rev(low block) * base^(digits of hi) + rev(hi) - the same
+  // integer the loop builds digit by digit - times the same tabulated f64 power. An index below one block takes the loop.
+  const bool tab = s.cam_lo[0] != nullptr;
   if (s.sample_at_center) { *d0 = 0.5; *d1 = 0.5; }
   else {
     *d0 = (double)__brev(index >> s.base_exp0) * 2.3283064365386963e-10;
     uint32_t a = (uint32_t)((double)index * s.inv_base_scale1), rev = 0, k = 0;   // index / 3^base_exponents[1], exact after the fix-up (cf. div_base())
     { const uint32_t r = index - a * s.base_scale1; if ((int32_t)r < 0) a -= 1u; else if (r >= s.base_scale1) a += 1u; }
-    while (a != 0) { const uint32_t q = div3(a); rev = rev * 3u + (a - q * 3u); a = q; k++; }
-    *d1 = fmin((double)rev * s.inv3pow[k], 0.99999999999999989);
+    if (tab && a >= kCamB3) {
+      const uint32_t hi = a / kCamB3, lo = a - hi * kCamB3;
+      const uint4 e = s.cam_hi[0][hi];
+      rev = s.cam_lo[0][lo] * e.y + e.x;
+      *d1 = fmin((double)rev * __hiloint2double((int)e.w, (int)e.z), 0.99999999999999989);
+    } else {
+      while (a != 0) { const uint32_t q = div3(a); rev = rev * 3u + (a - q * 3u); a = q; k++; }
+      *d1 = fmin((double)rev * s.inv3pow[k], 0.99999999999999989);
+    }
   }
-  {
+  if (tab && index >= kCamB5) {
+    const uint32_t hi = index / kCamB5, lo = index - hi * kCamB5;
+    const uint4 e = s.cam_hi[1][hi];
+    const uint64_t reversed = (uint64_t)s.cam_lo[1][lo] * e.y + e.x;
+    *d2 = fmin(__hiloint2double((int)e.w, (int)e.z) * ((double)reversed + s.cam_tail[0]), 0.99999999999999989);
+  } else {
     const uint32_t packed = s.cam_perm[0];
     uint64_t reversed = 0;
     uint32_t a = index, k = 0;
     while (a != 0) { const uint32_t q = div5(a), digit = a - q * 5u; reversed = reversed * 5u + ((packed >> (3u * digit)) & 7u); a = q; k++; }
     *d2 = fmin(s.cam_invpow[0][k] * ((double)reversed + s.cam_tail[0]), 0.99999999999999989);
   }
-  {
+  if (tab && index >= kCamB7) {
+    const uint32_t hi = index / kCamB7, lo = index - hi * kCamB7;
+    const uint4 e = s.cam_hi[2][hi];
+    const uint64_t reversed = (uint64_t)s.cam_lo[2][lo] * e.y + e.x;
+    *d3 = fmin(__hiloint2double((int)e.w, (int)e.z) * ((double)reversed + s.cam_tail[1]), 0.99999999999999989);
+  } else {
     const uint32_t packed = s.cam_perm[1];
     uint64_t reversed = 0;
     uint32_t a = index, k = 0;

@@ -172,6 +172,11 @@ struct SceneDev {
   double cam_tail[2];          // inv_base * perm[0] / (1 - inv_base)
   double inv_base_scale1;      // 1 / base_scale1
   double inv3pow[24];          // (1/3)^k by the reference's running product (radical_inverse of dimension 1, lowdiscrepancy.rs:188-202)
+  // The digit loops of camera dimensions 1-3 as two table look-ups each (fp32 camera kernel; null = loops): the index is split as
+  // hi * B + lo, B = 3^6 / 5^6 / 7^5; cam_lo[w][lo] = the permuted reversal of exactly that many low digits, cam_hi[w][hi] = {permuted
+  // reversal of hi's digits, base^(digits of hi), inv_base^(all digits) as the two words of the f64 the loop's table holds} - see halton_cam4()
+  const uint32_t* cam_lo[3];
+  const uint4* cam_hi[3];
   // integrator
   int32_t integrator, max_depth, light_strategy;
   R rr_threshold;

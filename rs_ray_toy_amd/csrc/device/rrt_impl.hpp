@@ -365,6 +365,7 @@ class Handle : public HandleBase {
     else if (key == "overlap_shadow") overlap_shadow_ = v != 0;
     else if (key == "aux_margin") aux_margin_ = v != 0;
     else if (key == "frame_stats") frame_stats_ = v != 0;
+    else if (key == "cam_tables") { for (int w = 0; w < 3; w++) { scene_.cam_lo[w] = (v != 0 && cam_lo_.n) ? cam_lo_.p + cam_lo_off_[w] : nullptr; scene_.cam_hi[w] = (v != 0 && cam_hi_.n) ? cam_hi_.p + cam_hi_off_[w] : nullptr; } }
     else if (key == "any_entry") { any_entry_on_ = v != 0; trav_.any_list = (any_entry_on_ && any_list_.n) ? reinterpret_cast<const uint4*>(any_list_.p) : nullptr; }
     else if (key == "nonblocking_streams") {   // see rrt.h: needed for two handles to overlap their frames
       if (pending_) throw std::invalid_argument("nonblocking_streams: a frame is in flight");
@@ -752,6 +753,10 @@ class Handle : public HandleBase {
   float aux_delta_ = 0.0f, aux_pupil_ = 0.0f;
   DevBuf<R> filter_table_;
   DevBuf<HaltonDim> hdims_;
+  DevBuf<uint32_t> cam_lo_;                // SceneDev::cam_lo / cam_hi
+  DevBuf<uint4> cam_hi_;
+  bool cam_tables_on_ = true;
+  size_t cam_lo_off_[3] = {0, 0, 0}, cam_hi_off_[3] = {0, 0, 0};
   DevBuf<uint16_t> perms_;
   DevBuf<typename Vec4T<R>::type> vpool_;
   DevBuf<R> rpool_;
@@ -1090,6 +1095,40 @@ class Handle : public HandleBase {
       double v = 1.0;
       for (int k = 0; k < 16; k++) { s.cam_invpow[w][k] = v; v *= inv_base; }
       s.cam_tail[w] = pm ? inv_base * (double)pm[0] / (1.0 - inv_base) : 0.0;
+    }
+    for (int w = 0; w < 3; w++) { s.cam_lo[w] = nullptr; s.cam_hi[w] = nullptr; }
+    if constexpr (std::is_same<R, float>::value) {
+      // block tables of the camera dimensions' digit loops (SceneDev::cam_lo / cam_hi, halton_cam4()); every sample index is below stride * spp
+      const uint64_t max_index = std::min<uint64_t>(0xffffffffull, (uint64_t)d->sampler.sample_stride * (uint64_t)std::max<int64_t>(1, d->sampler.samples_per_pixel));
+      if (d->sampler.type == RRT_SAMPLER_HALTON && !perms.empty() && cam_tables_on_) {
+        const uint32_t bases[3] = {3u, 5u, 7u}, blocks[3] = {kCamB3, kCamB5, kCamB7}, low_digits[3] = {6u, 6u, 5u};
+        const uint64_t top[3] = {max_index / std::max<uint32_t>(1u, s.base_scale1), max_index, max_index};   // dimension 1 digests index / 3^e
+        std::vector<uint32_t> lo_all;
+        std::vector<uint4> hi_all;
+        size_t lo_off[3], hi_off[3];
+        for (int w = 0; w < 3; w++) {
+          const uint32_t b = bases[w];
+          const uint16_t* pm = w == 0 ? nullptr : perms.data() + hd[1 + w].perm_offset;   // dimension 1 is not scrambled (halton.rs:107-128)
+          auto perm = [&](uint32_t dgt) { return pm ? (uint32_t)pm[dgt] & 7u : dgt; };
+          lo_off[w] = lo_all.size(); hi_off[w] = hi_all.size();
+          for (uint32_t lo = 0; lo < blocks[w]; lo++) {
+            uint32_t a = lo, rev = 0;
+            for (uint32_t i = 0; i < low_digits[w]; i++) { rev = rev * b + perm(a % b); a /= b; }
+            lo_all.push_back(rev);
+          }
+          const uint64_t n_hi = top[w] / blocks[w] + 2;
+          for (uint64_t hi = 0; hi < n_hi; hi++) {
+            uint64_t a = hi, rev = 0, pw = 1; uint32_t kh = 0;
+            while (a != 0) { rev = rev * b + perm((uint32_t)(a % b)); a /= b; pw *= b; kh++; }
+            const double ip = w == 0 ? s.inv3pow[std::min<uint32_t>(23u, low_digits[w] + kh)] : s.cam_invpow[w - 1][std::min<uint32_t>(15u, low_digits[w] + kh)];
+            uint64_t bits; std::memcpy(&bits, &ip, 8);
+            hi_all.push_back(make_uint4((uint32_t)rev, (uint32_t)pw, (uint32_t)bits, (uint32_t)(bits >> 32)));
+          }
+        }
+        cam_lo_.upload(lo_all, st_); cam_hi_.upload(hi_all, st_);
+        HIP_CHECK(hipStreamSynchronize(st_));
+        for (int w = 0; w < 3; w++) { cam_lo_off_[w] = lo_off[w]; cam_hi_off_[w] = hi_off[w]; s.cam_lo[w] = cam_lo_.p + lo_off[w]; s.cam_hi[w] = cam_hi_.p + hi_off[w]; }
+      }
     }
     {
       std::vector<R> ft(256);
