@@ -243,10 +243,6 @@ RRT_DEV uint32_t div7(uint32_t a) { const uint32_t q = __umulhi(a, 0x24924925u);
 constexpr uint32_t kCamB3 = 729u, kCamB5 = 15625u, kCamB7 = 16807u;   // 3^6, 5^6, 7^5: low-digit blocks of SceneDev::cam_lo / cam_hi
 template <typename R>
 RRT_DEV void halton_cam4(const SceneDev<R>& s, uint32_t index, double* d0, double* d1, double* d2, double* d3) {
-#ifdef RRT_EXP_FAKE_HALTON
-  { uint32_t h = index * 2654435761u; *d0 = (double)(h >> 8) * (1.0 / 16777216.0); h = h * 2654435761u + 1u; *d1 = (double)(h >> 8) * (1.0 / 16777216.0);
-    h = h * 2654435761u + 1u; *d2 = (double)(h >> 8) * (1.0 / 16777216.0); h = h * 2654435761u + 1u; *d3 = (double)(h >> 8) * (1.0 / 16777216.0); return; }
-#endif
   // With the tables the digits of an index come in two blocks: reversed = rev(low block) * base^(digits of hi) + rev(hi) - the same
   // integer the loop builds digit by digit - times the same tabulated f64 power. An index below one block takes the loop.
   const bool tab = s.cam_lo[0] != nullptr;

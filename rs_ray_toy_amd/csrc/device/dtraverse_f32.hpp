@@ -12,13 +12,17 @@
 // previous one: Q10) — the same winners, t, u, v as the generic kernels in dkernels.hpp (tests compare them; the slab test below treats a
 // NaN plane distance differently, see box_slabs_f32).
 //
-// What bounds these kernels on MI355X is the vector L1 (TCP): every lane's 16 B fetch of its own node touches a
-// different cache line, and the TCP retires about one line per clock per CU, so time ~ (lines touched) / (CUs x clk). (Round 2's counters
-// say the persistent kernel below is VALU-issue bound, with 87 % of its node fetches served by that L1: DESIGN.md section 3.)
-// Hence (a) the top kTreeletNodes pair nodes (BFS order: the levels every ray walks) are staged in LDS once per
-// workgroup and read with ds_read_b128 — no TCP traffic for them; (b) the traversal stack lives in LDS
-// ([entry][thread], conflict-free), entries beyond kStackLds spill to a strided global array; (c) workgroups are
-// persistent (grid-stride over the ray queue), so the treelet is loaded once per workgroup, not once per 512 rays.
+// What these kernels cost on MI355X, measured (tools/micro/tcp_gather2.hip, valu_rate.hip):
+//  * vector L1 (TCP): a 16-byte load whose 64 lanes read their own nodes costs the CU's one TCP 39 cycles (1.6 lanes per clock, 26 B/clk per
+//    CU - L1 hits; no cheaper when the lanes of a quad share a line, twice as dear per instruction for 4-byte loads), i.e. 156 cycles per
+//    64 pair-node fetches, against ~225 SIMD cycles of arithmetic spread over four SIMDs. The closest-hit kernel keeps that unit busiest.
+//  * VALU: v_mul / v_fma / v_sub / v_mov / v_and are full rate (2.7 cycles per wave-instruction), v_min / v_max / v_min3 / v_cmp / v_cndmask /
+//    v_bfe / shifts half rate (4.3), packed fp32 (v_pk_*) half rate too - two results for the price of two, so it only pays where the
+//    operands already sit in register pairs: PairNode's field order.
+//  * SALU: 4.3 cycles per instruction and SIMD (one scalar unit per CU) - condition logic on lane masks runs beside the VALU, not for free.
+// Hence (a) the top pair nodes (BFS order: the levels every ray walks) are staged in LDS once per workgroup - no TCP traffic for them;
+// (b) the traversal stack lives in LDS ([entry][thread], conflict-free), deeper entries spill to a strided global array; (c) workgroups
+// are persistent, so the treelet is loaded once per workgroup.
 #pragma once
 #include "dkernels.hpp"
 
@@ -861,7 +865,10 @@ RRT_DEV bool rg_step_lean(const float4 el, const float2 el2, RgLane* L, const fl
 // ------------------------------------------------------------------------------------------------------------
 namespace rrtd {
 
-constexpr int kRgDense = 1024;
+#ifndef RRT_RG_DENSE
+#define RRT_RG_DENSE 512
+#endif
+constexpr int kRgDense = RRT_RG_DENSE;
 #ifndef RRT_RG_REPACK
 #define RRT_RG_REPACK 3
 #endif
@@ -892,9 +899,6 @@ static __global__ void __launch_bounds__(kRgDense) k_raygen_main_f32(SceneDev<fl
     index = po.x + (pd.s_begin + sl) * s.stride;
     double d0, d1, d2, d3;
     halton_cam4(s, index, &d0, &d1, &d2, &d3);
-#ifdef RRT_EXP_HALTON_TWICE
-    { double e0, e1, e2, e3; uint32_t i2 = index ^ 0x5a5a5u; asm volatile("" : "+v"(i2)); halton_cam4(s, i2, &e0, &e1, &e2, &e3); if (e0 + e1 + e2 + e3 == 123.0) d0 = e1; }
-#endif
     pfx = (float)px + to_real<float>(d0); pfy = (float)py + to_real<float>(d1);
     lx = to_real<float>(d2) + 0.5f; ly = to_real<float>(d3) + 0.5f;   // Q5
     if (write_samp) p.samp[slot] = make_float4(pfx, pfy, lx, ly);
