@@ -28,6 +28,8 @@ HBM_PEAK_GBS = 8000.0  # MI355X_MICROARCH.md: HBM3E peak 8.0 TB/s (6.3 TB/s meas
 # MI355X_MICROARCH.md "Indexed rows: gather": rows served from the XCD's L2 16.8-18.8 TB/s chip-wide, from the Infinity Cache 8.6 TB/s.
 # The 11 MB BVH (pair nodes + triangles) does not fit one XCD's 4 MiB L2, so its gathered 64-B lines come from a mix of both.
 GATHER_L2_GBS, GATHER_IC_GBS = 17800.0, 8600.0
+# vector L1 (TCP) of a CU: 39 cycles per 16-byte load whose 64 lanes read distinct lines, L1 hits (tools/micro/tcp_gather2.hip, measured on MI355X)
+TCP_CYCLES_PER_ACCESS, N_CUS, CLOCK_HZ = 39.0 / 64.0, 256, 2.4e9
 
 
 def kernel_source_hash():
@@ -267,7 +269,7 @@ def main():
         # `traffic`: fabric-side bytes per launch from the committed PMC passes of this same workload and this same device code
         # (tools/profile_round.sh: separate --pmc FETCH_SIZE / WRITE_SIZE runs, x1024, reads x2 per the gfx950 note; Infinity-Cache hits
         # are included). A file measured on other kernel sources is ignored (null) rather than quoted stale.
-        traffic = lane_util = None
+        traffic = lane_util = tcp_acc = None
         if args.res == 1024 and args.spp == 256 and args.depth == 8 and world == 1:
             import glob
             src = kernel_source_hash()
@@ -277,6 +279,7 @@ def main():
                 if j.get("source_hash") == src:
                     traffic = round(j["closest"]["hbm_bytes"] / n_launch, 1)
                     lane_util = j.get("closest", {}).get("valu_lane_util")
+                    tcp_acc = j.get("closest", {}).get("tcp_accesses")
                     break
         # What can actually bind this kernel: the 11 MB BVH is served by L2 / Infinity Cache, so the bytes above never reach HBM
         # (hbm_frac); what it does is gather one 64-B pair-node line per two nodes and one 48-B triangle per test, per lane.
@@ -291,6 +294,12 @@ def main():
                                "peak_l2": GATHER_L2_GBS, "peak_infinity_cache": GATHER_IC_GBS,
                                "frac_l2": round(gather / GATHER_L2_GBS, 4), "frac_infinity_cache": round(gather / GATHER_IC_GBS, 4)},
                     "valu_lane_util": lane_util,
+                    # The unit this kernel keeps busiest is the CU's vector L1 (TCP): a 16-byte load whose 64 lanes read their own BVH nodes occupies
+                    # it for 39 cycles (tools/micro/tcp_gather2.hip, L1 hits), 0.61 cycles per lane-level access; accesses per launch from the
+                    # committed PMC pass (TCP_TOTAL_CACHE_ACCESSES). frac = TCP cycles needed / (256 CUs x launch duration x 2.4 GHz), L1 misses not priced.
+                    "l1_gather": None if tcp_acc is None else {"tcp_accesses_per_launch": round(tcp_acc / n_launch, 1), "cycles_per_access": TCP_CYCLES_PER_ACCESS,
+                                                              "frac": round(tcp_acc / n_launch * TCP_CYCLES_PER_ACCESS / (N_CUS * launch_s * CLOCK_HZ), 4),
+                                                              "frac_alone": round(tcp_acc / n_launch * TCP_CYCLES_PER_ACCESS / (N_CUS * (mx_tot["ms_closest_isolated"] * 1e-3 * world / n_launch) * CLOCK_HZ), 4)},
                     "note": "achieved / frac price every node and triangle a ray touches as an HBM byte (the SURVEY 8d definition); the BVH is "
                             "cache resident, so hbm_frac (PMC bytes) and gather (line fetches against the guide's gather rates) say what binds",
                     # the same launches with the shadow launches back on the main stream and one frame at a time: the kernel alone on the chip

@@ -32,6 +32,11 @@ for k in fam:
     rd = tot[k]["FETCH_SIZE"] * 1024 * 2 / nf
     wr = tot[k]["WRITE_SIZE"] * 1024 / nf
     out[k] = {"read_bytes": rd, "write_bytes": wr, "hbm_bytes": rd + wr, "dispatches_per_frame": disp[k]["FETCH_SIZE"] / nf}
+# lane-level accesses of the vector L1 (TCP): what the traversal kernels queue for (tools/micro/tcp_gather2.hip: 0.61 cycles of the CU's TCP each)
+for k in fam:
+    acc = tot[k].get("TCP_TOTAL_CACHE_ACCESSES_sum", 0.0)
+    if acc > 0:
+        out[k]["tcp_accesses"] = acc / (FRAMES if k in ("closest", "any") else FRAMES + 1)
 # VALU lane utilisation of the traversal kernels where the SQ pass was collected too (tools/pmc.sh pass 1)
 for k in ("closest", "any"):
     tc, ai = tot[k].get("SQ_THREAD_CYCLES_VALU", 0.0), tot[k].get("SQ_ACTIVE_INST_VALU", 0.0)
