@@ -227,7 +227,14 @@ def main():
     # per-kernel durations: HIP events on the handles' own streams around every launch of every frame of the timed region, averaged per frame
     assert len(frame_log) == args.steps
     timed = {k: sum(f[k] for f in frame_log) / len(frame_log) for k in frame_log[0]}
-    # the same frame with the shadow launches back on the main stream: the closest-hit kernel alone on the chip
+    # Kernel durations for the roofline (after the timed region, not part of `value`): the same frames ONE AT A TIME on the first handle. With
+    # several frames in flight an event pair around a launch also holds the time the stream waits for compute units behind the other frame's
+    # kernels, and rocprofv3's per-dispatch duration of a persistent launch holds the time it runs on the few CUs it got first - neither is the
+    # kernel's duration. One frame at a time both views coincide (profiles/: kernel_stats_1flight.csv of `bench.py --frames-in-flight 1`).
+    step()
+    single = [step(collect=True) for _ in range(max(2, args.steps // 2))]
+    single = {k: sum(f[k] for f in single) / len(single) for k in single[0]}
+    # ... and with the shadow launches back on the main stream: the closest-hit kernel alone on the chip
     r.set_option("overlap_shadow", 0)
     step()
     isolated = step(collect=True)
@@ -238,7 +245,8 @@ def main():
     tt = torch.tensor([elapsed], dtype=torch.float64, device=stat_dev)
     keys = ["camera_samples", "camera_rays", "closest_queries", "any_queries", "closest_nodes", "closest_prims", "any_nodes", "any_prims", "closest_launches"]
     counted["closest_launches"] = timed["closest_launches"]
-    cnt = torch.tensor([float(counted[k]) for k in keys] + [timed["ms_closest"], timed["ms_any"], timed["ms_shade"], timed["ms_raygen"], timed["ms_film"], timed["ms_total"], isolated["ms_closest"]],
+    cnt = torch.tensor([float(counted[k]) for k in keys] + [timed["ms_closest"], timed["ms_any"], timed["ms_shade"], timed["ms_raygen"], timed["ms_film"], timed["ms_total"], isolated["ms_closest"],
+                                                            single["ms_closest"], single["ms_any"], single["ms_shade"], single["ms_raygen"], single["ms_film"], single["ms_total"]],
                        dtype=torch.float64, device=stat_dev)
     if world > 1:
         dist.all_reduce(tt, op=dist.ReduceOp.MAX)
@@ -248,7 +256,8 @@ def main():
     else:
         mx = cnt
     elapsed = float(tt.item())
-    names = keys + ["ms_closest", "ms_any", "ms_shade", "ms_raygen", "ms_film", "ms_total", "ms_closest_isolated"]
+    names = keys + ["ms_closest", "ms_any", "ms_shade", "ms_raygen", "ms_film", "ms_total", "ms_closest_isolated",
+                    "ms1_closest", "ms1_any", "ms1_shade", "ms1_raygen", "ms1_film", "ms1_total"]
     tot = dict(zip(names, cnt.tolist()))
     mx_tot = dict(zip(names, mx.tolist()))
 
@@ -258,12 +267,12 @@ def main():
         value = queries / (ms_per_step * 1e-3) / 1e6
         # Roofline of the dominant kernel: closest-hit BVH traversal. ALGORITHMIC bytes per closest query: 28 B ray in +
         # 16 B hit out + 32 B per BVH node visited + 48 B per triangle tested; node / triangle counts are exact device counters of a
-        # counting frame of this very workload; duration = the kernel's launches of every timed frame, HIP events on the stream they
-        # were launched on, as the frames really ran (two frames in flight, shadow launches beside them: what rocprofv3's kernel
-        # trace of the same command shows per dispatch, profiles/).
+        # counting frame of this very workload; duration = the kernel's launches, HIP events on the stream they were launched on, in the
+        # one-frame-at-a-time pass above (shadow launches beside them on the second stream, as in the product): what rocprofv3's kernel trace
+        # of `bench.py --frames-in-flight 1` shows per dispatch (profiles/). `as_ran` = the same events inside the timed region.
         n_launch = max(1.0, tot["closest_launches"])
         bytes_closest = tot["closest_queries"] * 44.0 + 32.0 * tot["closest_nodes"] + 48.0 * tot["closest_prims"]
-        ms_closest = mx_tot["ms_closest"]   # per frame; ranks run concurrently: the slowest rank's sum
+        ms_closest = mx_tot["ms1_closest"]   # per frame; ranks run concurrently: the slowest rank's sum
         launch_s = ms_closest * 1e-3 / (n_launch / world) if ms_closest > 0 else float("inf")
         achieved = (bytes_closest / n_launch) / launch_s / 1e9
         # `traffic`: fabric-side bytes per launch from the committed PMC passes of this same workload and this same device code
@@ -289,6 +298,8 @@ def main():
                     "achieved": round(achieved, 2), "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": round(achieved / HBM_PEAK_GBS, 4), "traffic": traffic,
                     "algorithmic_bytes_per_launch": round(bytes_closest / n_launch, 1),
                     "avg_launch_ms": round(launch_s * 1e3, 4), "launches": int(n_launch),
+                    "as_ran": {"frames_in_flight": nfl, "avg_launch_ms": round(mx_tot["ms_closest"] * world / n_launch, 4),
+                               "frac": round((bytes_closest / n_launch) / (mx_tot["ms_closest"] * 1e-3 * world / n_launch) / 1e9 / HBM_PEAK_GBS, 4) if mx_tot["ms_closest"] > 0 else None},
                     "hbm_frac": None if traffic is None else round(traffic / launch_s / 1e9 / HBM_PEAK_GBS, 4),
                     "gather": {"achieved": round(gather, 1), "unit": "GB/s of 64-B pair-node lines + 48-B triangles + ray / hit records",
                                "peak_l2": GATHER_L2_GBS, "peak_infinity_cache": GATHER_IC_GBS,
@@ -300,8 +311,9 @@ def main():
                     "l1_gather": None if tcp_acc is None else {"tcp_accesses_per_launch": round(tcp_acc / n_launch, 1), "cycles_per_access": TCP_CYCLES_PER_ACCESS,
                                                               "frac": round(tcp_acc / n_launch * TCP_CYCLES_PER_ACCESS / (N_CUS * launch_s * CLOCK_HZ), 4),
                                                               "frac_alone": round(tcp_acc / n_launch * TCP_CYCLES_PER_ACCESS / (N_CUS * (mx_tot["ms_closest_isolated"] * 1e-3 * world / n_launch) * CLOCK_HZ), 4)},
-                    "note": "achieved / frac price every node and triangle a ray touches as an HBM byte (the SURVEY 8d definition); the BVH is "
-                            "cache resident, so hbm_frac (PMC bytes) and gather (line fetches against the guide's gather rates) say what binds",
+                    "note": "achieved / frac price every node and triangle a ray touches as an HBM byte (the SURVEY 8d definition); the BVH is cache "
+                            "resident (LDS treelet, vector L1, L2), so that figure can exceed 1 and is not a bandwidth: hbm_frac (PMC bytes) is the HBM "
+                            "position, l1_gather (lane-level vector-L1 accesses x their measured cost) the unit that binds",
                     # the same launches with the shadow launches back on the main stream and one frame at a time: the kernel alone on the chip
                     "alone_avg_launch_ms": round(mx_tot["ms_closest_isolated"] * world / n_launch, 4),
                     "bytes_per_query": round(bytes_closest / max(1.0, tot["closest_queries"]), 1),
@@ -324,6 +336,7 @@ def main():
             "closest_queries": int(tot["closest_queries"]), "any_queries": int(tot["any_queries"]),
             "any_nodes_per_query": round(tot["any_nodes"] / max(1.0, tot["any_queries"]), 2), "any_tris_per_query": round(tot["any_prims"] / max(1.0, tot["any_queries"]), 2),
             "kernel_ms_per_frame": {k: round(mx_tot[k], 3) for k in ("ms_raygen", "ms_closest", "ms_any", "ms_shade", "ms_film", "ms_total")},
+            "kernel_ms_per_frame_one_at_a_time": {k.replace("ms1_", "ms_"): round(mx_tot[k], 3) for k in ("ms1_raygen", "ms1_closest", "ms1_any", "ms1_shade", "ms1_film", "ms1_total")},
             "host_scene_build_s": round(t_build, 3),
         }
         print(json.dumps(out))
