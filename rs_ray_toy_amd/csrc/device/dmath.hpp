@@ -213,6 +213,18 @@ RRT_DEV double halton_dim(const SceneDev<R>& s, uint32_t index, uint32_t dim) {
   }
   if (dim == 1) return radical_inverse_dev(index / s.base_scale1, s.hdims[1], s.fast_div);
   const HaltonDim hd = s.hdims[dim];
+  if (dim < s.n_hblk) {
+    // Block tables (SceneDev::hblk): reversed = rev(low block) * base^(digits of hi) + rev(hi) is the integer the loop builds digit by digit,
+    // and the f64 power is the loop's own running product - the same value, bit for bit; an index below one block takes the loop.
+    const HaltonBlk hb = s.hblk[dim];
+    if (hb.block != 0u && index >= hb.block) {
+      const uint32_t t = __umulhi(hb.magic, index);
+      const uint32_t hi = (t + ((index - t) >> 1)) >> hb.shift, lo = index - hi * hb.block;
+      const uint4 e = s.hhi[hb.hi_off + hi];
+      const uint64_t reversed = (uint64_t)s.hlo[hb.lo_off + lo] * e.y + e.x;
+      return fmin(__hiloint2double((int)e.w, (int)e.z) * ((double)reversed + hd.tail), 0.99999999999999989);
+    }
+  }
   return scrambled_radical_inverse_dev(index, hd, s.perms + hd.perm_offset, s.fast_div);
 }
 // dims 2 / 3 (lens sample) on the fast path: same digits, same permutation, same f64 value as

@@ -9,6 +9,17 @@
 namespace rrtd {
 
 // LinearBVHNode bvh.rs:103-109, narrowed: f32 = 32 B (bounds rounded outward from the f64 build), f64 = 64 B.
+// Block tables of a sampler dimension's digit loop (fp32 mode): the sample index is split as hi * block + lo, block = base^low_digits;
+// lo[lo_off + lo] = the permuted reversal of exactly low_digits digits, hi[hi_off + hi] = {permuted reversal of hi's digits, base^(digits of hi),
+// the two words of the f64 inv_base^(all digits) the loop's running product arrives at}. See scrambled_radical_inverse_tab() in dmath.hpp.
+struct HaltonBlk {
+  uint32_t block;         // 0 = no table for this dimension
+  uint32_t shift;         // l - 1 of the division by `block` (div_base())
+  uint32_t magic;         // m'
+  uint32_t lo_off, hi_off;
+  uint32_t pad[3];
+};
+
 template <typename R>
 struct alignas(sizeof(R) * 8) Node {
   R bmin[3];
@@ -177,6 +188,11 @@ struct SceneDev {
   // reversal of hi's digits, base^(digits of hi), inv_base^(all digits) as the two words of the f64 the loop's table holds} - see halton_cam4()
   const uint32_t* cam_lo[3];
   const uint4* cam_hi[3];
+  // the same for the sampler dimensions the integrators draw (dimension < n_hblk; null / 0 = loops)
+  const HaltonBlk* hblk;
+  const uint32_t* hlo;
+  const uint4* hhi;
+  uint32_t n_hblk;
   // integrator
   int32_t integrator, max_depth, light_strategy;
   R rr_threshold;

@@ -365,6 +365,7 @@ class Handle : public HandleBase {
     else if (key == "overlap_shadow") overlap_shadow_ = v != 0;
     else if (key == "aux_margin") aux_margin_ = v != 0;
     else if (key == "frame_stats") frame_stats_ = v != 0;
+    else if (key == "halton_tables") scene_.n_hblk = (v != 0 && hblk_.n) ? (uint32_t)kHaltonTabDims : 0u;
     else if (key == "cam_tables") { for (int w = 0; w < 3; w++) { scene_.cam_lo[w] = (v != 0 && cam_lo_.n) ? cam_lo_.p + cam_lo_off_[w] : nullptr; scene_.cam_hi[w] = (v != 0 && cam_hi_.n) ? cam_hi_.p + cam_hi_off_[w] : nullptr; } }
     else if (key == "any_entry") { any_entry_on_ = v != 0; trav_.any_list = (any_entry_on_ && any_list_.n) ? reinterpret_cast<const uint4*>(any_list_.p) : nullptr; }
     else if (key == "nonblocking_streams") {   // see rrt.h: needed for two handles to overlap their frames
@@ -753,6 +754,10 @@ class Handle : public HandleBase {
   float aux_delta_ = 0.0f, aux_pupil_ = 0.0f;
   DevBuf<R> filter_table_;
   DevBuf<HaltonDim> hdims_;
+  static constexpr int kHaltonTabDims = 64;
+  DevBuf<HaltonBlk> hblk_;                 // SceneDev::hblk / hlo / hhi
+  DevBuf<uint32_t> hlo_;
+  DevBuf<uint4> hhi_;
   DevBuf<uint32_t> cam_lo_;                // SceneDev::cam_lo / cam_hi
   DevBuf<uint4> cam_hi_;
   bool cam_tables_on_ = true;
@@ -1097,6 +1102,48 @@ class Handle : public HandleBase {
       s.cam_tail[w] = pm ? inv_base * (double)pm[0] / (1.0 - inv_base) : 0.0;
     }
     for (int w = 0; w < 3; w++) { s.cam_lo[w] = nullptr; s.cam_hi[w] = nullptr; }
+    s.hblk = nullptr; s.hlo = nullptr; s.hhi = nullptr; s.n_hblk = 0;
+    if constexpr (std::is_same<R, float>::value) {
+      // block tables of the dimensions the integrators draw (SceneDev::hblk, halton_dim()): the first kHaltonTabDims dimensions, block =
+      // the largest power of the base below 2^17 (a 0.5 MB table of low blocks at most), one entry per high part up to the largest sample index
+      if (d->sampler.type == RRT_SAMPLER_HALTON && !perms.empty()) {
+        const uint64_t max_index = std::min<uint64_t>(0xffffffffull, (uint64_t)d->sampler.sample_stride * (uint64_t)std::max<int64_t>(1, d->sampler.samples_per_pixel));
+        std::vector<HaltonBlk> blk(kHaltonTabDims);
+        std::vector<uint32_t> lo_all;
+        std::vector<uint4> hi_all;
+        for (uint32_t dim = 0; dim < (uint32_t)kHaltonTabDims; dim++) {
+          HaltonBlk& hb = blk[dim];
+          std::memset(&hb, 0, sizeof(hb));
+          if (dim < 2) continue;   // dimensions 0 and 1 are the pixel's (halton.rs:107-121)
+          const uint32_t b = hd[dim].base;
+          if (hd[dim].perm_offset + b > perms.size()) continue;
+          const uint16_t* pm = perms.data() + hd[dim].perm_offset;
+          uint32_t low_digits = 1; uint64_t block = b;
+          while (block * b < (1ull << 17)) { block *= b; low_digits++; }
+          if (block >= max_index) continue;
+          { uint32_t l = 0; while ((1ull << l) < block) l++; const uint64_t mp = ((1ull << 32) * ((1ull << l) - block)) / block + 1ull; hb.magic = (uint32_t)mp; hb.shift = l - 1; }
+          hb.block = (uint32_t)block; hb.lo_off = (uint32_t)lo_all.size(); hb.hi_off = (uint32_t)hi_all.size();
+          for (uint32_t lo = 0; lo < hb.block; lo++) {
+            uint32_t a = lo, rev = 0;
+            for (uint32_t i = 0; i < low_digits; i++) { rev = rev * b + pm[a % b]; a /= b; }
+            lo_all.push_back(rev);
+          }
+          const uint64_t n_hi = max_index / block + 2;
+          for (uint64_t hi = 0; hi < n_hi; hi++) {
+            uint64_t a = hi, rev = 0, pw = 1; uint32_t k = low_digits;
+            while (a != 0) { rev = rev * b + pm[a % b]; a /= b; pw *= b; k++; }
+            volatile double ip = 1.0;   // the loop's running product inv_base_n *= inv_base, k times (lowdiscrepancy.rs:204-227)
+            for (uint32_t i = 0; i < k; i++) ip = ip * hd[dim].inv;
+            const double ipv = ip;
+            uint64_t bits; std::memcpy(&bits, &ipv, 8);
+            hi_all.push_back(make_uint4((uint32_t)rev, (uint32_t)pw, (uint32_t)bits, (uint32_t)(bits >> 32)));
+          }
+        }
+        hblk_.upload(blk, st_); hlo_.upload(lo_all, st_); hhi_.upload(hi_all, st_);
+        HIP_CHECK(hipStreamSynchronize(st_));
+        s.hblk = hblk_.p; s.hlo = hlo_.p; s.hhi = hhi_.p; s.n_hblk = (uint32_t)kHaltonTabDims;
+      }
+    }
     if constexpr (std::is_same<R, float>::value) {
       // block tables of the camera dimensions' digit loops (SceneDev::cam_lo / cam_hi, halton_cam4()); every sample index is below stride * spp
       const uint64_t max_index = std::min<uint64_t>(0xffffffffull, (uint64_t)d->sampler.sample_stride * (uint64_t)std::max<int64_t>(1, d->sampler.samples_per_pixel));

@@ -494,6 +494,31 @@ def test_camera_halton_block_tables_change_nothing(workdir):
     assert np.array_equal(film_on, film_off) and film_on[..., :3].max() > 0
 
 
+@pytest.mark.parametrize("which", ["cfg4_path8", "cfg3_direct", "cfg2_glass_debug"])
+def test_halton_block_tables_change_nothing(which, workdir):
+    """The fp32 mode draws the sampler dimensions of the integrators (scrambled_radical_inverse, lowdiscrepancy.rs:204-227) from block tables
+    too (SceneDev::hblk: the index split into a block of low digits and the rest, first 64 dimensions) - the same integers and the same f64
+    products as the digit loops. Bar: frames and query counts with and without the tables are identical bit for bit (the oracle, which has no
+    tables, holds the same frames in the render cases)."""
+    if which == "cfg4_path8": cfg, root = scenes.cfg4(workdir, xres=160, yres=120, nsamp=17, max_depth=8, n=64)
+    elif which == "cfg3_direct":
+        cfg, root = scenes.cfg3(workdir, xres=128, yres=128, nsamp=9)
+        cfg["Integrator"] = {"integrator_type": "DirectLighting", "light_strategy": "all", "max_depth": 3}
+    else:
+        cfg, root = scenes.cfg2(workdir, xres=128, yres=128, nsamp=9, max_depth=6)
+        _with_material(cfg, "gl", ("GlassMaterial", {"kr": [1.0, 1.0, 1.0], "kt": [0.9, 0.9, 0.9]}, {"eta": 1.5}, {}))
+        cfg["Aggregate"]["primitives"][0]["material_name"] = "gl"
+        cfg["Integrator"] = {"integrator_type": "Debug", "max_depth": 6}
+    sc = Scene.loads(cfg, root, flags=RRT_FIXED_BVH)
+    r = Renderer(sc, 0, RRT_F32)
+    a, st_a = r.render(stats=True)
+    r.set_option("halton_tables", 0)
+    b, st_b = r.render(stats=True)
+    r.close()
+    assert st_a.closest_queries == st_b.closest_queries and st_a.any_queries == st_b.any_queries and st_a.closest_queries > 1000
+    assert np.array_equal(a, b, equal_nan=True) and np.nanmax(a[..., :3]) > 0
+
+
 AUX_CASES = {
     "cfg2_640x360": lambda wd: scenes.cfg2(wd, xres=640, yres=360, nsamp=9, max_depth=2),
     "cfg2_tiny_film": lambda wd: scenes.cfg2(wd, xres=24, yres=16, nsamp=65, max_depth=2),     # 0.05 px is 70 um of film here
