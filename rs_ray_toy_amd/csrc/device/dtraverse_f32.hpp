@@ -219,6 +219,7 @@ RRT_DEV PairStep pair_step_f32(const float4 a, const float4 b, const float4 c, c
 template <bool ANY>
 RRT_DEV bool leaf_step_f32(const TravScene& ts, uint32_t word, LaneRay& r, int* hit, float* hu, float* hv) {
   uint32_t lf = word & 0x7ffffu, ln = (word >> 19) & 0xfffu;
+  // (Measured and dropped: the next triangle's loads in flight while this one is tested - 12 more registers, 7 waves per SIMD: +0.5 ms per frame.)
   do {
     float t, u, v;
     if (tri_test_f32<ANY>(ts.tris + (size_t)lf * 12, r, &t, &u, &v)) {
@@ -343,6 +344,15 @@ constexpr int kPtBlock = RRT_PT_BLOCK;
 constexpr int kPtStack = RRT_PT_STACK, kPtStackAny = RRT_PT_STACK_ANY;   // LDS stack entries per lane (closest-hit, any-hit); deeper entries spill to global
 constexpr uint32_t kGrain = 256;
 
+#ifdef RRT_PT_STATS
+// tuning instrumentation (variant builds only): [0] iterations, [1] node iterations, [2] active lanes over node steps, [3] node steps (wave level),
+// [4] leaf iterations, [5] active lanes over leaf iterations, [6] refills, [7] lanes refilled, [8] pop-loop rounds (wave level), [9] lanes over pop rounds,
+// [10] idle lanes over iterations, [11] leaf-waiting lanes over node iterations, [12] node-waiting lanes over leaf iterations
+__device__ unsigned long long g_pt_stats[2][16];
+#define PT_STAT(i, v) st_[i] += (v)
+#else
+#define PT_STAT(i, v)
+#endif
 template <bool ANY>
 __global__ void __launch_bounds__(kPtBlock) k_trace_pt_f32(TravScene ts, Pools<float> p, const uint32_t* queue, const uint32_t* count,
                                                             uint32_t n_fixed, uint32_t* work, uint8_t* occluded, uint32_t n_lo, uint32_t n_hi) {
@@ -379,6 +389,9 @@ __global__ void __launch_bounds__(kPtBlock) k_trace_pt_f32(TravScene ts, Pools<f
   uint32_t grain = (n / (2u * n_waves) + 63u) & ~63u;
   grain = grain < 64u ? 64u : (grain > kGrain ? kGrain : grain);
 
+#ifdef RRT_PT_STATS
+  unsigned long long st_[16] = {0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0};
+#endif
   auto finish = [&](bool found) {
     if (ANY) {
       if (occluded) occluded[qidx] = found ? 1 : 0;
@@ -389,8 +402,11 @@ __global__ void __launch_bounds__(kPtBlock) k_trace_pt_f32(TravScene ts, Pools<f
     cur = kIdle;
   };
   auto pop = [&]() {   // re-checks the one comparison that depends on the current t_max
+    // (Measured and dropped: reading the two top entries per round - a closest-hit lane that has found its hit rejects most of what is left on
+    // its stack, 1.7 rounds of this loop per node step with 14 lanes in each, tools/pt_stats.py - closest-hit alone 18.0 -> 19.4 ms.)
     while (sp > 0) {
       sp--;
+      PT_STAT(8, lane == (uint32_t)__builtin_ctzll(__builtin_amdgcn_ballot_w64(true)) ? 1 : 0); PT_STAT(9, 1);
       // (the LDS read is unconditional and the overflow entry a rare fix-up: an if / else between the two address spaces compiles to flat loads)
       uint2 e = stk[(sp < (uint32_t)kStack ? sp : 0u) * kPtBlock + tid];
       asm volatile("" : "+v"(e.x), "+v"(e.y));
@@ -424,7 +440,9 @@ __global__ void __launch_bounds__(kPtBlock) k_trace_pt_f32(TravScene ts, Pools<f
       if (!exhausted) {
         const uint32_t take = (hi - lo) < n_idle ? (hi - lo) : n_idle;
         const uint32_t rank = (uint32_t)__popcll(idle & ((1ull << lane) - 1ull));
+        PT_STAT(6, lane == 0 ? 1 : 0);
         if (cur == kIdle && rank < take) {
+          PT_STAT(7, 1);
           qidx = lo + rank;
           sp = 0; hit = -1; hu = 0.0f; hv = 0.0f;
           int start_tri;
@@ -447,9 +465,13 @@ __global__ void __launch_bounds__(kPtBlock) k_trace_pt_f32(TravScene ts, Pools<f
     // wait). Node steps run while they outnumber the waiting triangle tests 2 : 1 (measured best of 1:1 ... 1:8; a leaf
     // holds 1-3 triangles against ~23 node steps per ray, so triangle lanes must not wait for a majority).
     const bool do_node = (uint32_t)__popcll(m_node) * RRT_VOTE_A >= (uint32_t)__popcll(m_leaf) * RRT_VOTE_B;
+    PT_STAT(0, lane == 0 ? 1 : 0); PT_STAT(10, cur == kIdle ? 1 : 0);
     if (do_node) {
+      PT_STAT(1, lane == 0 ? 1 : 0); PT_STAT(11, is_leaf(cur) ? 1 : 0);
       for (int rep_k = 0; rep_k < RRT_NODE_STEPS; rep_k++) {
+        { const bool any_node = __builtin_amdgcn_ballot_w64(is_node(cur)) != 0ull; PT_STAT(3, (lane == 0 && any_node) ? 1 : 0); (void)any_node; }
         if (is_node(cur)) {
+          PT_STAT(2, 1);
           const uint32_t off = ANY ? (cur & ~63u) : cur;
           float4 a, b, c; uint4 d;
           if (kTl > 0 && off < tl_bytes) {
@@ -474,12 +496,19 @@ __global__ void __launch_bounds__(kPtBlock) k_trace_pt_f32(TravScene ts, Pools<f
           else pop();
         }
       }
-    } else if (is_leaf(cur)) {
-      // the whole leaf (1-3 triangles) in one step: fewer scheduling rounds than one triangle per step
-      if (leaf_step_f32<ANY>(ts, cur, r, &hit, &hu, &hv)) finish(true);
-      else pop();
+    } else {
+      PT_STAT(4, lane == 0 ? 1 : 0); PT_STAT(12, is_node(cur) ? 1 : 0);
+      if (is_leaf(cur)) {
+        PT_STAT(5, 1);
+        // the whole leaf (1-3 triangles) in one step: fewer scheduling rounds than one triangle per step
+        if (leaf_step_f32<ANY>(ts, cur, r, &hit, &hu, &hv)) finish(true);
+        else pop();
+      }
     }
   }
+#ifdef RRT_PT_STATS
+  for (int i = 0; i < 16; i++) if (st_[i]) atomicAdd(&g_pt_stats[ANY ? 1 : 0][i], st_[i]);
+#endif
 }
 
 }  // namespace rrtd
