@@ -7,6 +7,10 @@
 //                              direct xGMI link to root (root receives from all peers at once: no ring);
 //   wider filters              samples splat into neighbouring rows of the rank's own film: ncclReduce(sum) of the film.
 // A band is contiguous in the film (rows x W x 4 words), so no packing is needed.
+// RCCL is bound at the first collective call (dlopen of the librccl.so.1 the process already holds - torch.distributed's, for instance - or
+// of the ROCm one), not linked into librrt.so: a single-GPU user never loads it, and a process that loads librrt.so before PyTorch does not
+// end up with two copies of RCCL's SMI library whose static destructors then free the same tables twice at exit.
+#include <dlfcn.h>
 #include <rccl/rccl.h>
 
 #include <mutex>
@@ -21,10 +25,47 @@ namespace {
 constexpr int kBandRows = 16;   // tile height of integrator/mod.rs:55 (rrt_render_bands)
 
 struct NcclError : std::runtime_error { using std::runtime_error::runtime_error; };
-#define NCCL_CHECK(expr)                                                                                       \
-  do {                                                                                                         \
-    ncclResult_t _r = (expr);                                                                                  \
-    if (_r != ncclSuccess) throw NcclError(std::string("RCCL error: ") + ncclGetErrorString(_r) + " at " #expr); \
+
+// the RCCL entry points this file calls, resolved once
+struct Rccl {
+  decltype(&::ncclGetUniqueId) GetUniqueId = nullptr;
+  decltype(&::ncclCommInitRank) CommInitRank = nullptr;
+  decltype(&::ncclCommInitAll) CommInitAll = nullptr;
+  decltype(&::ncclCommDestroy) CommDestroy = nullptr;
+  decltype(&::ncclGroupStart) GroupStart = nullptr;
+  decltype(&::ncclGroupEnd) GroupEnd = nullptr;
+  decltype(&::ncclSend) Send = nullptr;
+  decltype(&::ncclRecv) Recv = nullptr;
+  decltype(&::ncclReduce) Reduce = nullptr;
+  decltype(&::ncclGetErrorString) GetErrorString = nullptr;
+};
+const Rccl& rccl() {
+  static Rccl api;
+  static std::once_flag once;
+  static std::string failure;
+  std::call_once(once, []() {
+    void* lib = nullptr;
+    for (const char* name : {"librccl.so.1", "librccl.so", "/opt/rocm/lib/librccl.so.1"}) if ((lib = dlopen(name, RTLD_NOW | RTLD_GLOBAL))) break;
+    if (!lib) { failure = std::string("RCCL not found (dlopen librccl.so.1): ") + (dlerror() ? dlerror() : "?"); return; }
+    auto sym = [&](const char* n) { void* f = dlsym(lib, n); if (!f && failure.empty()) failure = std::string("RCCL symbol missing: ") + n; return f; };
+    api.GetUniqueId = (decltype(api.GetUniqueId))sym("ncclGetUniqueId");
+    api.CommInitRank = (decltype(api.CommInitRank))sym("ncclCommInitRank");
+    api.CommInitAll = (decltype(api.CommInitAll))sym("ncclCommInitAll");
+    api.CommDestroy = (decltype(api.CommDestroy))sym("ncclCommDestroy");
+    api.GroupStart = (decltype(api.GroupStart))sym("ncclGroupStart");
+    api.GroupEnd = (decltype(api.GroupEnd))sym("ncclGroupEnd");
+    api.Send = (decltype(api.Send))sym("ncclSend");
+    api.Recv = (decltype(api.Recv))sym("ncclRecv");
+    api.Reduce = (decltype(api.Reduce))sym("ncclReduce");
+    api.GetErrorString = (decltype(api.GetErrorString))sym("ncclGetErrorString");
+  });
+  if (!failure.empty()) throw NcclError(failure);
+  return api;
+}
+#define NCCL_CHECK(expr)                                                                                                \
+  do {                                                                                                                  \
+    ncclResult_t _r = (expr);                                                                                           \
+    if (_r != ncclSuccess) throw NcclError(std::string("RCCL error: ") + rccl().GetErrorString(_r) + " at " #expr);    \
   } while (0)
 
 template <typename F>
@@ -45,7 +86,7 @@ void enqueue_gather(rrtd::HandleBase* h, ncclComm_t comm, int rank, int world, v
   const size_t word = h->precision() == RRT_F32 ? 4 : 8;
   hipStream_t st = h->stream();
   if (splats) {   // overlapping films: sum (in place on root)
-    NCCL_CHECK(ncclReduce(film, film, (size_t)W * (size_t)H * 4, dt, ncclSum, root, comm, st));
+    NCCL_CHECK(rccl().Reduce(film, film, (size_t)W * (size_t)H * 4, dt, ncclSum, root, comm, st));
     return;
   }
   const int n_bands = (H + kBandRows - 1) / kBandRows;
@@ -56,8 +97,8 @@ void enqueue_gather(rrtd::HandleBase* h, ncclComm_t comm, int rank, int world, v
     const int y0 = b * kBandRows, y1 = std::min(H, y0 + kBandRows);
     char* at = (char*)film + (size_t)y0 * (size_t)W * 4 * word;
     const size_t count = (size_t)(y1 - y0) * (size_t)W * 4;
-    if (rank == root) NCCL_CHECK(ncclRecv(at, count, dt, owner, comm, st));
-    else NCCL_CHECK(ncclSend(at, count, dt, root, comm, st));
+    if (rank == root) NCCL_CHECK(rccl().Recv(at, count, dt, owner, comm, st));
+    else NCCL_CHECK(rccl().Send(at, count, dt, root, comm, st));
   }
 }
 }  // namespace
@@ -80,7 +121,7 @@ int rrt_comm_id(uint8_t id[RRT_COMM_ID_BYTES]) {
   if (!id) { rrt::set_last_error("rrt_comm_id: null argument"); return RRT_EINVAL; }
   return guarded([&]() {
     ncclUniqueId u;
-    NCCL_CHECK(ncclGetUniqueId(&u));
+    NCCL_CHECK(rccl().GetUniqueId(&u));
     memcpy(id, u.internal, NCCL_UNIQUE_ID_BYTES);
   });
 }
@@ -96,7 +137,7 @@ int rrt_comm_create(const uint8_t id[RRT_COMM_ID_BYTES], int rank, int world, in
     ncclUniqueId u;
     memcpy(u.internal, id, NCCL_UNIQUE_ID_BYTES);
     ncclComm_t c = nullptr;
-    NCCL_CHECK(ncclCommInitRank(&c, world, u, rank));
+    NCCL_CHECK(rccl().CommInitRank(&c, world, u, rank));
     *out = new rrt_comm{c, rank, world, device};
   });
 }
@@ -104,7 +145,7 @@ int rrt_comm_create(const uint8_t id[RRT_COMM_ID_BYTES], int rank, int world, in
 void rrt_comm_destroy(rrt_comm* c) {
   if (!c) return;
   (void)hipSetDevice(c->device);
-  (void)ncclCommDestroy(c->comm);
+  try { (void)rccl().CommDestroy(c->comm); } catch (const NcclError&) {}
   delete c;
 }
 
@@ -114,10 +155,10 @@ int rrt_film_gather(rrt_handle* h, rrt_comm* c, void* film_xyzw_device, int root
   if (h->impl->device() != c->device) { rrt::set_last_error("rrt_film_gather: handle and communicator live on different devices"); return RRT_EINVAL; }
   return guarded([&]() {
     HIP_CHECK(hipSetDevice(c->device));
-    NCCL_CHECK(ncclGroupStart());
+    NCCL_CHECK(rccl().GroupStart());
     try { enqueue_gather(h->impl, c->comm, c->rank, c->world, film_xyzw_device, root); }
-    catch (...) { (void)ncclGroupEnd(); throw; }
-    NCCL_CHECK(ncclGroupEnd());
+    catch (...) { (void)rccl().GroupEnd(); throw; }
+    NCCL_CHECK(rccl().GroupEnd());
   });
 }
 
@@ -135,19 +176,19 @@ int rrt_film_gather_all(rrt_handle* const* handles, void* const* films_device, i
     for (int i = 0; i < n; i++) want[i] = handles[i]->impl->device();
     for (int i = 0; i < n; i++) for (int j = 0; j < i; j++) if (want[i] == want[j]) throw std::invalid_argument("rrt_film_gather_all: two handles on one device (RCCL needs one rank per GPU)");
     if (want != devs) {
-      for (ncclComm_t c : comms) (void)ncclCommDestroy(c);
+      for (ncclComm_t c : comms) (void)rccl().CommDestroy(c);
       comms.assign(n, nullptr); devs.clear();
-      NCCL_CHECK(ncclCommInitAll(comms.data(), n, want.data()));
+      NCCL_CHECK(rccl().CommInitAll(comms.data(), n, want.data()));
       devs = want;
     }
-    NCCL_CHECK(ncclGroupStart());
+    NCCL_CHECK(rccl().GroupStart());
     try {
       for (int i = 0; i < n; i++) {
         HIP_CHECK(hipSetDevice(want[i]));
         enqueue_gather(handles[i]->impl, comms[i], i, n, films_device[i], root);
       }
-    } catch (...) { (void)ncclGroupEnd(); throw; }
-    NCCL_CHECK(ncclGroupEnd());
+    } catch (...) { (void)rccl().GroupEnd(); throw; }
+    NCCL_CHECK(rccl().GroupEnd());
   });
 }
 

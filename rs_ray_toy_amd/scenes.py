@@ -6,6 +6,7 @@ vertices / 6 normals / 12 faces (the reference's samples/ directory is not avail
 GPU box).
 """
 import json
+import copy
 import os
 
 import numpy as np
@@ -75,13 +76,14 @@ MATERIALS = [
 
 
 def _base(xres, yres, nsamp, integrator):
+    # (every builder hands out its own copies of the module-level templates: callers edit instances, lights and materials in place)
     return {
-        "float_texture": [], "rgb_texture": [], "materials": MATERIALS, "objs": [], "lights": [], "infinite_lights": [],
+        "float_texture": [], "rgb_texture": [], "materials": copy.deepcopy(MATERIALS), "objs": [], "lights": [], "infinite_lights": [],
         "Aggregate": {"max_prims_in_node": 4, "primitives": []},
         "Integrator": integrator,
         "Sampler": {"sampler_type": "HaltonSampler", "nsamp": nsamp},
         "Film": {"xres": xres, "yres": yres, "diagonal": 20, "Filter": {}},
-        "Camera": CAMERA,
+        "Camera": copy.deepcopy(CAMERA),
     }
 
 
@@ -145,7 +147,7 @@ def write_heightfield(workdir, n=224, extent=20.0, center=(35.0, 0.0, 0.0), amp=
 def cfg1(workdir, xres=256, yres=256, nsamp=2):
     """24 spheres r=0.75 via `instances` (Q16), 3 point lights, DirectLighting (BASELINE config 1)."""
     cfg = _base(xres, yres, nsamp, {"integrator_type": "DirectLighting", "light_strategy": "all", "max_depth": 5})
-    cfg["lights"] = SCENE_JSON_LIGHTS
+    cfg["lights"] = copy.deepcopy(SCENE_JSON_LIGHTS)
     inst = []
     for i in range(24):
         gx, gy = i % 6, i // 6
@@ -159,9 +161,9 @@ def cfg2(workdir, xres=512, yres=512, nsamp=65, max_depth=4):
     write_cube(workdir)
     cfg = _base(xres, yres, nsamp, {"integrator_type": "Path", "max_depth": max_depth})
     cfg["objs"] = [{"filename": "cube.obj", "obj_name": "cube_01"}]
-    cfg["lights"] = SCENE_JSON_LIGHTS
+    cfg["lights"] = copy.deepcopy(SCENE_JSON_LIGHTS)
     cfg["Aggregate"]["primitives"] = [{"primitive_type": "triangle", "material_name": "mat_matte", "obj_name": "cube_01",
-                                       "instances": SCENE_JSON_INSTANCES}]
+                                       "instances": copy.deepcopy(SCENE_JSON_INSTANCES)}]
     return cfg, workdir
 
 
@@ -185,7 +187,7 @@ def cfg4(workdir, xres=1024, yres=1024, nsamp=257, max_depth=8, n=224):
     write_heightfield(workdir, n=n)
     cfg = _base(xres, yres, nsamp, {"integrator_type": "Path", "max_depth": max_depth})
     cfg["objs"] = [{"filename": "heightfield.obj", "obj_name": "hf"}]
-    cfg["lights"] = SCENE_JSON_LIGHTS
+    cfg["lights"] = copy.deepcopy(SCENE_JSON_LIGHTS)
     cfg["Aggregate"]["primitives"] = [{"primitive_type": "triangle", "material_name": "mat_matte", "obj_name": "hf"}]
     return cfg, workdir
 
