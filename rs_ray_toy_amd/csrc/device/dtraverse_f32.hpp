@@ -34,9 +34,6 @@
 #ifndef RRT_NODE_STEPS
 #define RRT_NODE_STEPS 2
 #endif
-#ifndef RRT_POP_FLAT
-#define RRT_POP_FLAT 0
-#endif
 #ifndef RRT_RG_REFILL
 #define RRT_RG_REFILL 32u
 #endif
@@ -166,10 +163,9 @@ struct TravScene {
 // A lane's position in the walk is one child word: an interior node to visit (byte offset of its PairNode, < kIdle), a leaf to test
 // (kLeafBit set), or kIdle. The traversal stack holds the same words with the child's entry distance.
 constexpr uint32_t kIdle = 0x7fffffffu;
-constexpr uint32_t kPop = 0x7ffffffeu;   // (RRT_POP_FLAT) the lane takes its next word from its stack at the start of the next node step
 constexpr uint32_t kSkip0 = 1u, kSkip1 = 2u;   // any-hit list entries (TravScene::any_list): low bits of an interior child word
 constexpr int kAnyList = 6;                    // flagged entries per list
-RRT_DEV bool is_node(uint32_t w) { return w < kPop; }
+RRT_DEV bool is_node(uint32_t w) { return w < kIdle; }
 RRT_DEV bool is_leaf(uint32_t w) { return (int32_t)w < 0; }
 
 // Ray `idx` of the queue this launch serves (POOL_SHADOW: the pool's shadow rays, t_max = 1 - 1e-4; otherwise the closest-ray arrays
@@ -406,8 +402,10 @@ __global__ void __launch_bounds__(kPtBlock) k_trace_pt_f32(TravScene ts, Pools<f
     cur = kIdle;
   };
   auto pop = [&]() {   // re-checks the one comparison that depends on the current t_max
-    // (Measured and dropped: reading the two top entries per round - a closest-hit lane that has found its hit rejects most of what is left on
-    // its stack, 1.7 rounds of this loop per node step with 14 lanes in each, tools/pt_stats.py - closest-hit alone 18.0 -> 19.4 ms.)
+    // (This loop runs 1.7 rounds per node step with 14 lanes in each - a closest-hit lane that has found its hit rejects most of what is left on
+    // its stack, tools/pt_stats.py. Measured and dropped: reading the two top entries per round (closest-hit alone 18.0 -> 19.4 ms); one pop
+    // attempt per node step for all the lanes that need one, a rejected lane trying again at the next step (1.0 round of 23 lanes, frame -0.3 ms,
+    // the kernel alone +0.3 ms: a wash).)
     while (sp > 0) {
       sp--;
       PT_STAT(8, lane == (uint32_t)__builtin_ctzll(__builtin_amdgcn_ballot_w64(true)) ? 1 : 0); PT_STAT(9, 1);
@@ -420,17 +418,6 @@ __global__ void __launch_bounds__(kPtBlock) k_trace_pt_f32(TravScene ts, Pools<f
     finish(false);
   };
 
-  // RRT_POP_FLAT: one pop attempt per node step for all the lanes that need one, together (a lane whose entry is rejected tries again at the
-  // next step) instead of a loop per lane inside the step, which runs 1.7 rounds per node step with 14 lanes in each (tools/pt_stats.py)
-  auto pop_later = [&]() { if (sp == 0u) finish(false); else cur = kPop; };
-  auto pop_once = [&]() {
-    sp--;
-    uint2 e = stk[(sp < (uint32_t)kStack ? sp : 0u) * kPtBlock + tid];
-    asm volatile("" : "+v"(e.x), "+v"(e.y));
-    if (__builtin_expect(sp >= (uint32_t)kStack, 0)) e = *reinterpret_cast<const uint2*>(ts.overflow + ((size_t)(sp - kStack) * ts.overflow_stride + gtid) * 2);
-    if (__uint_as_float(e.y) < r.tmax) cur = e.x;
-    else if (sp == 0u) finish(false);
-  };
   while (true) {
     // ---- refill idle lanes ---------------------------------------------------------------------------------------
     const uint64_t idle = __ballot(cur == kIdle);
@@ -473,7 +460,7 @@ __global__ void __launch_bounds__(kPtBlock) k_trace_pt_f32(TravScene ts, Pools<f
         lo += take;
       }
     }
-    const uint64_t m_node = __ballot(RRT_POP_FLAT ? cur < kIdle : is_node(cur)), m_leaf = __ballot(is_leaf(cur));
+    const uint64_t m_node = __ballot(is_node(cur)), m_leaf = __ballot(is_leaf(cur));
     if ((m_node | m_leaf) == 0ull) { if (exhausted) break; else continue; }
 
     // ---- one step, for the lanes of ONE kind only: the other path is not executed at all this iteration (its lanes
@@ -484,8 +471,7 @@ __global__ void __launch_bounds__(kPtBlock) k_trace_pt_f32(TravScene ts, Pools<f
     if (do_node) {
       PT_STAT(1, lane == 0 ? 1 : 0); PT_STAT(11, is_leaf(cur) ? 1 : 0);
       for (int rep_k = 0; rep_k < RRT_NODE_STEPS; rep_k++) {
-        { const bool any_node = __builtin_amdgcn_ballot_w64(RRT_POP_FLAT ? cur < kIdle : is_node(cur)) != 0ull; PT_STAT(3, (lane == 0 && any_node) ? 1 : 0); (void)any_node; }
-        if (RRT_POP_FLAT && cur == kPop) { PT_STAT(8, lane == (uint32_t)__builtin_ctzll(__builtin_amdgcn_ballot_w64(true)) ? 1 : 0); PT_STAT(9, 1); pop_once(); }
+        { const bool any_node = __builtin_amdgcn_ballot_w64(is_node(cur)) != 0ull; PT_STAT(3, (lane == 0 && any_node) ? 1 : 0); (void)any_node; }
         if (is_node(cur)) {
           PT_STAT(2, 1);
           const uint32_t off = ANY ? (cur & ~63u) : cur;
@@ -509,7 +495,6 @@ __global__ void __launch_bounds__(kPtBlock) k_trace_pt_f32(TravScene ts, Pools<f
             sp++;
           }
           if (st.go_near) cur = st.id_near;
-          else if (RRT_POP_FLAT) pop_later();
           else pop();
         }
       }
@@ -519,7 +504,6 @@ __global__ void __launch_bounds__(kPtBlock) k_trace_pt_f32(TravScene ts, Pools<f
         PT_STAT(5, 1);
         // the whole leaf (1-3 triangles) in one step: fewer scheduling rounds than one triangle per step
         if (leaf_step_f32<ANY>(ts, cur, r, &hit, &hu, &hv)) finish(true);
-        else if (RRT_POP_FLAT) pop_later();
         else pop();
       }
     }
