@@ -1007,12 +1007,15 @@ __global__ void __launch_bounds__(ShadeBlock<R>::n) __attribute__((amdgpu_waves_
         V3<R> wi;
         R pdf = R(0);
         uint32_t flags = 0;
-        Rgb<R> f = bsdf.sample_f(si.wo, &wi, u0, u1, &pdf, BXDF_ALL, &flags);
+        // `let wo = -ray.d` (path.rs:126): the WORLD ray's direction, not the interaction's wo - which estimate_direct uses (integrator/mod.rs:441)
+        // and which differs from it on a non-rigid instance (transformed back, not re-normalised: primitives.rs:131-136) and by rounding on a sphere
+        const V3<R> wo_path = -d;
+        Rgb<R> f = bsdf.sample_f(wo_path, &wi, u0, u1, &pdf, BXDF_ALL, &flags);
         if (!(f.is_black() || pdf == R(0))) {
           beta = beta * (f * absdot(wi, si.sn) / pdf);
           if (!(beta.y() > R(0)) || isinf(beta.y()) || beta.y() != beta.y()) atomicOr(&p.counters[C_ERROR], (uint32_t)ERR_BETA);  // path.rs:146-147 asserts
           if ((flags & BXDF_SPECULAR) && (flags & BXDF_TRANSMISSION))   // path.rs:150-162
-            eta_scale *= dot(si.wo, si.n) > R(0) ? bsdf.eta * bsdf.eta : R(1) / (bsdf.eta * bsdf.eta);
+            eta_scale *= dot(wo_path, si.n) > R(0) ? bsdf.eta * bsdf.eta : R(1) / (bsdf.eta * bsdf.eta);
           V3<R> nd = vnormalize(wi);  // spawn_ray -> Ray::new_od (Q8: no origin offset)
           bool cont = true;
           // Russian roulette (:214-222) on beta * eta_scale

@@ -410,16 +410,22 @@ def _non_rigid(wd, integrator):
     return cfg, root
 
 
-@pytest.mark.parametrize("which", ["path", "direct_all", "debug"])
+@pytest.mark.parametrize("which", ["path", "path_metal", "path_plastic", "direct_all", "debug"])
 def test_non_rigid_triangle_instances(which, workdir):
     """`scale` on a mesh instance (renderprocess.rs:242-252): TransformedPrimitive::intersect (primitives.rs:115-139) tests the triangle with
     the ray moved into the instance's space and RE-NORMALISED there (transform.rs:525-537), copies that object-space t to the world ray
     (Q15: boxes are then pruned with a distance in the wrong space) and transforms the interaction back, leaving wo un-normalised.
     The device replays exactly that for non-rigid instances (rigid ones are flattened). f64 mode: hits, t, counters bit for bit and
-    frames to 1e-9 against the oracle; fp32 on the generic kernels within the triangle scenes' bar."""
-    integ = {"path": {"integrator_type": "Path", "max_depth": 3}, "direct_all": {"integrator_type": "DirectLighting", "light_strategy": "all", "max_depth": 3},
+    frames to 1e-9 against the oracle; fp32 on the generic kernels within the triangle scenes' bar.
+    path_metal / path_plastic: the path integrator samples the BSDF with `wo = -ray.d` (path.rs:126), the WORLD ray's direction, while
+    estimate_direct evaluates it with the interaction's un-normalised wo - on a scaled instance the two differ, and every lobe but the
+    Lambertian one sees it (fuzz seed 703 case 95 found the device using the interaction's wo for both: 75 % of the pixels off by up to 6e-3)."""
+    integ = {"path": {"integrator_type": "Path", "max_depth": 3}, "path_metal": {"integrator_type": "Path", "max_depth": 4},
+             "path_plastic": {"integrator_type": "Path", "max_depth": 4}, "direct_all": {"integrator_type": "DirectLighting", "light_strategy": "all", "max_depth": 3},
              "debug": {"integrator_type": "Debug", "max_depth": 3}}[which]
     cfg, root = _non_rigid(workdir, integ)
+    if which in ("path_metal", "path_plastic"):
+        cfg["Aggregate"]["primitives"][0]["material_name"] = "mat_metal" if which == "path_metal" else "mat_plastic"
     sc = Scene.loads(cfg, root)
     o, d, tmax, _ = _rays_for(sc, 2048, 17)
     ref_t = O.trace_closest(sc, o, d, tmax, flat=True)      # flat: rigid instances flattened like on the device, non-rigid ones per primitive
@@ -439,7 +445,7 @@ def test_non_rigid_triangle_instances(which, workdir):
     assert np.array_equal(got["u"][hit], ref_t["u"][hit]) and np.array_equal(got["v"][hit], ref_t["v"][hit])
     assert np.array_equal(occ, ref_a["occluded"])
     assert np.array_equal(film[..., 3], ref[..., 3]) and st.camera_rays == st_ref.camera_rays
-    if which != "path":   # (the path integrator's dead final-bounce and MIS queries are not issued on the device)
+    if not which.startswith("path"):   # (the path integrator's dead final-bounce and MIS queries are not issued on the device)
         assert st.closest_queries == st_ref.closest_queries and st.any_queries == st_ref.any_queries
     scale = np.abs(ref[..., :3]).max()
     assert scale > 0
