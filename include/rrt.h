@@ -385,7 +385,10 @@ int rrt_film_gather_all(rrt_handle* const* handles, void* const* films_device, i
  * (exact node / triangle-test counters in rrt_render_stats, generic kernels), "persistent_traversal" (fp32: 0 generic
  * kernels, 1 grid-stride pair-node kernel, 2 persistent-thread kernel, 3 = default, by queue size), "pt_split_closest" /
  * "pt_split_any" (queue sizes at which 3 switches), "raygen_pt" (fp32: 0 = the generic two-stage raygen in the reference's
- * operation order, 1 = persistent-thread lens tracing, 2 = default: dense kernels with the lean lens arithmetic) */
+ * operation order, 1 = persistent-thread lens tracing, 2 = default: dense kernels with the lean lens arithmetic), and three
+ * result-invariant shortcuts of the fp32 mode that tests switch off to show that they are (1 = default): "any_entry" (shadow rays start from
+ * their triangle's list of deciding nodes instead of the root), "cam_tables" / "halton_tables" (block tables instead of the digit loops of
+ * the camera's / the integrators' Halton dimensions) */
 int rrt_set_option(rrt_handle*, const char* key, double value);
 
 const char* rrt_last_error(void);
