@@ -28,8 +28,23 @@ HBM_PEAK_GBS = 8000.0  # MI355X_MICROARCH.md: HBM3E peak 8.0 TB/s (6.3 TB/s meas
 # MI355X_MICROARCH.md "Indexed rows: gather": rows served from the XCD's L2 16.8-18.8 TB/s chip-wide, from the Infinity Cache 8.6 TB/s.
 # The 11 MB BVH (pair nodes + triangles) does not fit one XCD's 4 MiB L2, so its gathered 64-B lines come from a mix of both.
 GATHER_L2_GBS, GATHER_IC_GBS = 17800.0, 8600.0
-# vector L1 (TCP) of a CU: 39 cycles per 16-byte load whose 64 lanes read distinct lines, L1 hits (tools/micro/tcp_gather2.hip, measured on MI355X)
-TCP_CYCLES_PER_ACCESS, N_CUS, CLOCK_HZ = 39.0 / 64.0, 256, 2.4e9
+# vector L1 (TCP) of a CU: 39 cycles per 16-byte load whose 64 lanes read distinct lines, L1 hits - 0.61 cycles per lane-level access - but
+# 1.0 per access when the active lanes have no active neighbour (32 alternate lanes: 32 cycles; 16 of 64: 16) and 0.63 for adjacent pairs
+# (tools/micro/tcp_gather2.hip, measured on MI355X). For a wave whose lanes are active with probability p: 1 - 0.39 p cycles per access.
+TCP_CYCLES_PER_ACCESS, TCP_CYCLES_PER_ACCESS_SPARSE, N_CUS, CLOCK_HZ = 39.0 / 64.0, 1.0, 256, 2.4e9
+
+
+def l1_gather_bound(accesses, load_insts, launch_s, alone_s):
+    """How busy the CUs' vector L1 (TCP) is during a closest-hit launch: lane-level accesses (PMC TCP_TOTAL_CACHE_ACCESSES) x the cycles each
+    occupies the TCP, over 256 CUs x duration x 2.4 GHz. The cost per access depends on how full the loading waves are (see the constants):
+    `frac_dense` prices every access as in a full wave (a lower bound), `frac` at the measured density p = accesses / (64 x wave-level vector
+    loads, PMC SQ_INSTS_VMEM_RD) with 1 - 0.39 p cycles per access; L1 misses (13 % of the accesses) are not priced."""
+    p = None if not load_insts else min(1.0, accesses / (64.0 * load_insts))
+    c = TCP_CYCLES_PER_ACCESS if p is None else 1.0 - (1.0 - TCP_CYCLES_PER_ACCESS) * p
+    cap = lambda t: N_CUS * t * CLOCK_HZ
+    return {"tcp_accesses_per_launch": round(accesses, 1), "lanes_per_load": None if p is None else round(64.0 * p, 1), "cycles_per_access": round(c, 3),
+            "cycles_per_access_dense": round(TCP_CYCLES_PER_ACCESS, 3), "frac": round(accesses * c / cap(launch_s), 4), "frac_alone": round(accesses * c / cap(alone_s), 4),
+            "frac_dense": round(accesses * TCP_CYCLES_PER_ACCESS / cap(launch_s), 4), "frac_alone_dense": round(accesses * TCP_CYCLES_PER_ACCESS / cap(alone_s), 4)}
 
 
 def kernel_source_hash():
@@ -278,7 +293,7 @@ def main():
         # `traffic`: fabric-side bytes per launch from the committed PMC passes of this same workload and this same device code
         # (tools/profile_round.sh: separate --pmc FETCH_SIZE / WRITE_SIZE runs, x1024, reads x2 per the gfx950 note; Infinity-Cache hits
         # are included). A file measured on other kernel sources is ignored (null) rather than quoted stale.
-        traffic = lane_util = tcp_acc = None
+        traffic = lane_util = tcp_acc = tcp_insts = None
         if args.res == 1024 and args.spp == 256 and args.depth == 8 and world == 1:
             import glob
             src = kernel_source_hash()
@@ -289,6 +304,7 @@ def main():
                     traffic = round(j["closest"]["hbm_bytes"] / n_launch, 1)
                     lane_util = j.get("closest", {}).get("valu_lane_util")
                     tcp_acc = j.get("closest", {}).get("tcp_accesses")
+                    tcp_insts = j.get("closest", {}).get("vmem_rd_insts")
                     break
         # What can actually bind this kernel: the 11 MB BVH is served by L2 / Infinity Cache, so the bytes above never reach HBM
         # (hbm_frac); what it does is gather one 64-B pair-node line per two nodes and one 48-B triangle per test, per lane.
@@ -308,9 +324,8 @@ def main():
                     # The unit this kernel keeps busiest is the CU's vector L1 (TCP): a 16-byte load whose 64 lanes read their own BVH nodes occupies
                     # it for 39 cycles (tools/micro/tcp_gather2.hip, L1 hits), 0.61 cycles per lane-level access; accesses per launch from the
                     # committed PMC pass (TCP_TOTAL_CACHE_ACCESSES). frac = TCP cycles needed / (256 CUs x launch duration x 2.4 GHz), L1 misses not priced.
-                    "l1_gather": None if tcp_acc is None else {"tcp_accesses_per_launch": round(tcp_acc / n_launch, 1), "cycles_per_access": TCP_CYCLES_PER_ACCESS,
-                                                              "frac": round(tcp_acc / n_launch * TCP_CYCLES_PER_ACCESS / (N_CUS * launch_s * CLOCK_HZ), 4),
-                                                              "frac_alone": round(tcp_acc / n_launch * TCP_CYCLES_PER_ACCESS / (N_CUS * (mx_tot["ms_closest_isolated"] * 1e-3 * world / n_launch) * CLOCK_HZ), 4)},
+                    "l1_gather": None if tcp_acc is None else l1_gather_bound(tcp_acc / n_launch, None if tcp_insts is None else tcp_insts / n_launch, launch_s,
+                                                                               mx_tot["ms_closest_isolated"] * 1e-3 * world / n_launch),
                     "note": "achieved / frac price every node and triangle a ray touches as an HBM byte (the SURVEY 8d definition); the BVH is cache "
                             "resident (LDS treelet, vector L1, L2), so that figure can exceed 1 and is not a bandwidth: hbm_frac (PMC bytes) is the HBM "
                             "position, l1_gather (lane-level vector-L1 accesses x their measured cost) the unit that binds",

@@ -8,7 +8,7 @@
 
 // MODE: 0 = 4 x b128 same node; 1 = 4 x b128 of four different nodes (chunk 0); 2 = 4 x b128 of four different nodes, chunks 0..3;
 //       3 = 2 x b128 same node; 4 = 3 x b128 same node; 5 = 8 x b64 same node; 6 = 16 x b32 same node; 7 = 4 x b96 (48 B) same node;
-//       8 = 1 x b128; 9 = 2 x b128 of two different nodes; 10 = 4 x b128 same node, s_nop spacing via independent valu work between loads
+//       8 = 1 x b128; 9 = 2 x b128 of two different nodes; 11 / 12 / 13 / 14 / 15 = mode 0 with every other lane / every fourth lane / the first 32 lanes / three lanes of every quad / two adjacent lanes of every quad active
 template <int MODE>
 __global__ void __launch_bounds__(256) k(const char* __restrict__ base, uint32_t mask, int steps, uint32_t* out) {
   uint32_t idx = (blockIdx.x * 256u + threadIdx.x) * 2654435761u & mask;
@@ -29,6 +29,11 @@ __global__ void __launch_bounds__(256) k(const char* __restrict__ base, uint32_t
       uint32_t v[16]; for (int i = 0; i < 16; i++) { asm volatile("global_load_dword %0, %1, off" : "=v"(v[i]) : "v"(p + i)); }
       asm volatile("s_waitcnt vmcnt(0)" ::: "memory"); for (int i = 0; i < 16; i++) h ^= v[i]; }
     else if (MODE == 8) h = L4(idx, 0);
+    else if (MODE == 11) { if (threadIdx.x & 1u) h = L4(idx, 0) ^ L4(idx, 16) ^ L4(idx, 32) ^ L4(idx, 48); }        // 32 of 64 lanes active (every other lane)
+    else if (MODE == 12) { if ((threadIdx.x & 3u) == 0u) h = L4(idx, 0) ^ L4(idx, 16) ^ L4(idx, 32) ^ L4(idx, 48); } // 16 of 64 lanes active
+    else if (MODE == 14) { if ((threadIdx.x & 3u) != 3u) h = L4(idx, 0) ^ L4(idx, 16) ^ L4(idx, 32) ^ L4(idx, 48); }  // 48 of 64: three lanes of every quad
+    else if (MODE == 15) { if ((threadIdx.x & 2u) == 0u) h = L4(idx, 0) ^ L4(idx, 16) ^ L4(idx, 32) ^ L4(idx, 48); }  // 32 of 64: two ADJACENT lanes of every quad
+    else if (MODE == 13) { if ((threadIdx.x & 63u) < 32u) h = L4(idx, 0) ^ L4(idx, 16) ^ L4(idx, 32) ^ L4(idx, 48); } // the first 32 lanes
     else if (MODE == 9) h = L4(idx, 0) ^ L4(j1, 16);
     acc += h;
     idx = (idx * 1664525u + 1013904223u + (h & 1u) * 977u) & mask;
@@ -57,6 +62,8 @@ int main() {
     printf("table %6.0f KB, %d waves/SIMD | cycles per CU per wave-step: 4xb128 same node %5.0f | 4 nodes chunk0 %5.0f | 4 nodes chunks 0-3 %5.0f | 2xb128 %5.0f | 3xb128 %5.0f | 8xb64 %5.0f | 16xb32 %5.0f | 1xb128 %5.0f | 2 nodes %5.0f\n",
            n * 64 / 1024.0, wps, run<0>(d, n, steps, blocks, out) * sc, run<1>(d, n, steps, blocks, out) * sc, run<2>(d, n, steps, blocks, out) * sc, run<3>(d, n, steps, blocks, out) * sc,
            run<4>(d, n, steps, blocks, out) * sc, run<5>(d, n, steps, blocks, out) * sc, run<6>(d, n, steps, blocks, out) * sc, run<8>(d, n, steps, blocks, out) * sc, run<9>(d, n, steps, blocks, out) * sc);
+    printf("   4xb128 same node with 32 of 64 lanes active (alternate) %5.0f | 16 of 64 %5.0f | the first 32 lanes %5.0f | 3 lanes of every quad %5.0f | 2 adjacent lanes of every quad %5.0f\n", run<11>(d, n, steps, blocks, out) * sc,
+           run<12>(d, n, steps, blocks, out) * sc, run<13>(d, n, steps, blocks, out) * sc, run<14>(d, n, steps, blocks, out) * sc, run<15>(d, n, steps, blocks, out) * sc);
     CK(hipFree(d));
   }
   return 0;

@@ -36,7 +36,10 @@ for k in fam:
 for k in fam:
     acc = tot[k].get("TCP_TOTAL_CACHE_ACCESSES_sum", 0.0)
     if acc > 0:
-        out[k]["tcp_accesses"] = acc / (FRAMES if k in ("closest", "any") else FRAMES + 1)
+        nf = FRAMES if k in ("closest", "any") else FRAMES + 1
+        out[k]["tcp_accesses"] = acc / nf
+        if tot[k].get("SQ_INSTS_VMEM_RD", 0.0) > 0:   # wave-level vector loads: accesses / (64 x this) = how full the loading waves are
+            out[k]["vmem_rd_insts"] = tot[k]["SQ_INSTS_VMEM_RD"] / nf
 # VALU lane utilisation of the traversal kernels where the SQ pass was collected too (tools/pmc.sh pass 1)
 for k in ("closest", "any"):
     tc, ai = tot[k].get("SQ_THREAD_CYCLES_VALU", 0.0), tot[k].get("SQ_ACTIVE_INST_VALU", 0.0)
