@@ -32,7 +32,7 @@
 extern "C" {
 #endif
 
-#define RRT_ABI_VERSION 7
+#define RRT_ABI_VERSION 8
 
 /* ---- error codes ------------------------------------------------------- */
 enum {
@@ -50,8 +50,16 @@ enum {
 enum {
   RRT_FIX_BVH_LBVH_SLICE = 1u << 0, /* Q26 off: emit_lbvh second child uses slice[split..] */
   RRT_FIX_BVH_SAH        = 1u << 1, /* Q27 off: real 12-bucket SAH in build_upper_sah      */
-  RRT_SKIP_MIS_BSDF_RAY  = 1u << 2  /* do not trace estimate_direct's BSDF-sampled ray;
+  RRT_SKIP_MIS_BSDF_RAY  = 1u << 2, /* do not trace estimate_direct's BSDF-sampled ray;
                                        result-invariant because of Q18     */
+  /* How the DEVICE evaluates triangle instances (TransformedPrimitive, primitives.rs:115-139; transform.rs:525-537). "Kept": every
+   * instance goes through the reference's own per-primitive ray transform (world_to_prim.t(ray), object-space test, t copied
+   * back, interaction transformed) - the reference's evaluation order, bit for bit in RRT_F64. "Flattened": rigid instances
+   * are moved to world space once at upload (one ray per traversal; exact box / face ties may break differently, DESIGN.md
+   * section 4). Defaults: RRT_F64 keeps (parity mode = the reference's order), RRT_F32 flattens (product speed; non-rigid
+   * instances are always kept). The two flags override the default of either mode. */
+  RRT_INSTANCES_FLATTEN  = 1u << 3,
+  RRT_INSTANCES_KEEP     = 1u << 4
 };
 #define RRT_FIXED_BVH (RRT_FIX_BVH_LBVH_SLICE | RRT_FIX_BVH_SAH)
 
@@ -304,6 +312,10 @@ void rrt_scene_free(rrt_scene*);
 size_t rrt_scene_warning_count(const rrt_scene*);
 const char* rrt_scene_warning(const rrt_scene*, size_t i);
 
+/* what a host needs of the film to size its buffers and resolve the image (Film::full_resolution film.rs:137, Film::scale :142) without
+ * reading rrt_scene_desc's layout; any pointer may be NULL */
+int rrt_scene_film(const rrt_scene*, int32_t* xres, int32_t* yres, double* scale);
+
 /* Film::write_image film.rs:323-366 (Q3 already folded into w) + write_image renderprocess.rs:1501-1530.
  * film_xyzw: W*H*4 host floats/doubles (X,Y,Z sums and filter_weight_sum per pixel). */
 int rrt_resolve_rgba8(const void* film_xyzw, int precision, int w, int h, double scale, uint8_t* rgba);
@@ -315,6 +327,11 @@ int rrt_device_count(void);
  * pools are allocated on first use. RRT_EDEVICE without a HIP device: there is no CPU fallback. */
 int rrt_create(int device, const rrt_scene_desc* desc, int precision, rrt_handle** out);
 void rrt_destroy(rrt_handle*);
+/* non-fatal diagnostics of rrt_create, in the manner of the reference's eprintln! lines (rrt_scene_warning): what this handle's precision
+ * mode does not claim for this scene - RRT_F32 with transmissive sphere primitives (sphere.rs:124-259 has no epsilon: the reference's own
+ * sphere pixels hang on last-bit coins that fp32 cannot replay; use RRT_F64) - and shortcuts that were switched off */
+size_t rrt_warning_count(const rrt_handle*);
+const char* rrt_warning(const rrt_handle*, size_t i);
 /* raw hipStream_t of the handle (for event timing by the caller) */
 void* rrt_stream(rrt_handle*);
 
@@ -381,11 +398,13 @@ int rrt_film_gather(rrt_handle*, rrt_comm*, void* film_xyzw_device, int root);
 int rrt_film_gather_all(rrt_handle* const* handles, void* const* films_device, int n, int root);
 
 /* handle options: "frame_stats" (see rrt_render_end_stats), "aux_margin" (fp32: 0 = trace the auxiliary camera rays of every surviving
- * sample, 1 = default: skip them where the main ray clears every lens interface by the calibrated margin), "max_paths" (wavefront pool slots; default 2^28 clamped to half of the free HBM), "count_traversal"
+ * sample, 1 = default: skip them where the main ray clears every lens interface by the calibrated margin, DESIGN.md - a CALIBRATED HEURISTIC, not a
+ * proven bound: 16 x the largest displacement of an auxiliary ray measured at scene load over 16 384 host samples of the scene's own lens; validated
+ * bit for bit against the full traces on the built-in and on randomly perturbed prescriptions, tests/test_gpu_parity.py::test_aux_margins_change_nothing), "max_paths" (wavefront pool slots; default 2^28 clamped to half of the free HBM), "count_traversal"
  * (exact node / triangle-test counters in rrt_render_stats, generic kernels), "persistent_traversal" (fp32: 0 generic
  * kernels, 1 grid-stride pair-node kernel, 2 persistent-thread kernel, 3 = default, by queue size), "pt_split_closest" /
  * "pt_split_any" (queue sizes at which 3 switches), "raygen_pt" (fp32: 0 = the generic two-stage raygen in the reference's
- * operation order, 1 = persistent-thread lens tracing, 2 = default: dense kernels with the lean lens arithmetic), and three
+ * operation order, otherwise = default: dense kernels with the lean lens arithmetic), and three
  * result-invariant shortcuts of the fp32 mode that tests switch off to show that they are (1 = default): "any_entry" (shadow rays start from
  * their triangle's list of deciding nodes instead of the root), "cam_tables" / "halton_tables" (block tables instead of the digit loops of
  * the camera's / the integrators' Halton dimensions) */

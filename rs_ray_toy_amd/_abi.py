@@ -13,6 +13,7 @@ LIB_PATH = os.environ.get("RRT_LIBRARY") or os.path.join(_HERE, "csrc", "librrt.
 RRT_OK, RRT_EINVAL, RRT_EIO, RRT_EPARSE, RRT_EPANIC, RRT_EUNSUP, RRT_EDEVICE, RRT_ENOMEM = 0, -1, -2, -3, -4, -5, -6, -7
 # flags
 RRT_FIX_BVH_LBVH_SLICE, RRT_FIX_BVH_SAH, RRT_SKIP_MIS_BSDF_RAY = 1, 2, 4
+RRT_INSTANCES_FLATTEN, RRT_INSTANCES_KEEP = 8, 16   # device evaluation of triangle instances (rrt.h)
 RRT_FIXED_BVH = RRT_FIX_BVH_LBVH_SLICE | RRT_FIX_BVH_SAH
 RRT_PRIM_TRIANGLE, RRT_PRIM_SPHERE = 0, 1
 RRT_MAT_MATTE, RRT_MAT_PLASTIC, RRT_MAT_METAL, RRT_MAT_MIRROR, RRT_MAT_DEBUG = range(5)
@@ -160,11 +161,14 @@ PROTOTYPES = {
     "rrt_scene_free": (None, [C.c_void_p]),
     "rrt_scene_warning_count": (C.c_size_t, [C.c_void_p]),
     "rrt_scene_warning": (C.c_char_p, [C.c_void_p, C.c_size_t]),
+    "rrt_scene_film": (C.c_int, [C.c_void_p, C.POINTER(C.c_int32), C.POINTER(C.c_int32), C.POINTER(C.c_double)]),
     "rrt_resolve_rgba8": (C.c_int, [C.c_void_p, C.c_int, C.c_int, C.c_int, C.c_double, C.c_void_p]),
     "rrt_write_png": (C.c_int, [C.c_char_p, C.c_void_p, C.c_int, C.c_int]),
     "rrt_device_count": (C.c_int, []),
     "rrt_create": (C.c_int, [C.c_int, C.POINTER(SceneDesc), C.c_int, C.POINTER(C.c_void_p)]),
     "rrt_destroy": (None, [C.c_void_p]),
+    "rrt_warning_count": (C.c_size_t, [C.c_void_p]),
+    "rrt_warning": (C.c_char_p, [C.c_void_p, C.c_size_t]),
     "rrt_stream": (C.c_void_p, [C.c_void_p]),
     "rrt_trace_closest": (C.c_int, [C.c_void_p, C.POINTER(Rays), C.c_size_t, C.POINTER(Hits)]),
     "rrt_trace_any": (C.c_int, [C.c_void_p, C.POINTER(Rays), C.c_size_t, C.c_void_p]),

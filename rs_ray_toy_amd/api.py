@@ -87,12 +87,17 @@ def _np_dtype(precision):
 class Renderer:
     """Device executor (`Integrator::render`, integrator/mod.rs:21-23) for one GPU."""
 
-    def __init__(self, scene, device=0, precision=A.RRT_F32):
+    def __init__(self, scene, device=0, precision=A.RRT_F32, flags=0):
+        """`flags`: device-side flags OR-ed into a copy of the scene's desc (RRT_INSTANCES_KEEP / RRT_INSTANCES_FLATTEN)."""
         self.scene = scene
         self.precision = precision
         self.dtype = _np_dtype(precision)
+        desc = scene.desc
+        if flags:
+            desc = A.SceneDesc.from_buffer_copy(scene.desc)   # shallow: the arrays stay the scene's
+            desc.flags |= flags
         h = C.c_void_p()
-        _check(A.lib().rrt_create(device, C.byref(scene.desc), precision, C.byref(h)))
+        _check(A.lib().rrt_create(device, C.byref(desc), precision, C.byref(h)))
         self._h = h
 
     def close(self):
@@ -109,6 +114,12 @@ class Renderer:
     @property
     def stream(self):
         return A.lib().rrt_stream(self._h)
+
+    @property
+    def warnings(self):
+        """rrt_warning(): what this handle's precision mode does not claim for the scene (fp32 + transmissive spheres ...)."""
+        L = A.lib()
+        return [L.rrt_warning(self._h, i).decode() for i in range(L.rrt_warning_count(self._h))]
 
     def set_option(self, key, value):
         _check(A.lib().rrt_set_option(self._h, key.encode(), float(value)))
@@ -271,6 +282,8 @@ def deploy_render(filepath, save_to, device=0, precision=A.RRT_F32, flags=0, ove
     for w in scene.warnings:
         print(w, flush=True)
     r = Renderer(scene, device, precision)
+    for w in r.warnings:
+        print(w, flush=True)
     film, st = r.render(stats=True)
     print(f"{st.camera_rays} rays generated")
     rgba = resolve_rgba8(film, scene.desc.film.scale)

@@ -3,7 +3,7 @@
 //
 //   deploy_render:  make_scene + make_integrator        -> rrt_scene_load (host: loader, OBJ parser, BVH build, camera init)
 //                   inte.render(&scene)                 -> rrt_create + rrt_render_bands_begin on every GPU this process owns,
-//                                                          rrt_film_gather_all (RCCL) to device 0
+//                                                          rrt_film_gather_all (RCCL; nothing to do on one GPU) to device 0
 //                   film.write_image -> write_image     -> rrt_resolve_rgba8 + rrt_write_png
 // Diagnostics go to stderr like the reference's eprintln!; its "N rays generated" line (integrator/mod.rs:137) goes to stdout.
 // Environment: RRT_GPUS = number of GPUs to partition the film over (default 1), RRT_PRECISION = f32 (default) | f64,
@@ -45,8 +45,10 @@ int main(int argc, char** argv) {
   int rc = rrt_scene_load(argv[1], flags, 0x853C49E6748FEA9Bull, &scene);
   if (rc != RRT_OK) return fail("rrt_scene_load", rc);
   for (size_t i = 0; i < rrt_scene_warning_count(scene); i++) std::fprintf(stderr, "%s\n", rrt_scene_warning(scene, i));
-  const rrt_scene_desc* desc = rrt_scene_desc_of(scene);
-  const int W = desc->film.xres, H = desc->film.yres;
+  const rrt_scene_desc* desc = rrt_scene_desc_of(scene);   // opaque here: handed to rrt_create as it is
+  int32_t W = 0, H = 0;
+  double film_scale = 1.0;
+  (void)rrt_scene_film(scene, &W, &H, &film_scale);
   const size_t word = precision == RRT_F32 ? 4 : 8, film_bytes = (size_t)W * (size_t)H * 4 * word;
   // the tiles banner of integrator/mod.rs:59-62
   std::fprintf(stderr, "Rendering %d x %d, %d tile rows of 16 over %d GPU(s)\n", W, H, (H + 15) / 16, n_gpus);
@@ -63,6 +65,7 @@ int main(int argc, char** argv) {
   for (int i = 0; i < n_gpus; i++) {
     rc = rrt_create(i, desc, precision, &handles[i]);
     if (rc != RRT_OK) { const int e = fail("rrt_create", rc); cleanup(); return e; }
+    if (i == 0) for (size_t k = 0; k < rrt_warning_count(handles[i]); k++) std::fprintf(stderr, "%s\n", rrt_warning(handles[i], k));
     if (hipSetDevice(i) != hipSuccess || hipMalloc(&films[i], film_bytes) != hipSuccess || hipMemset(films[i], 0, film_bytes) != hipSuccess) {
       std::fprintf(stderr, "rrt_render: cannot allocate the %zu-byte film on device %d\n", film_bytes, i);
       cleanup();
@@ -76,17 +79,21 @@ int main(int argc, char** argv) {
   }
   rc = rrt_film_gather_all(handles.data(), films.data(), n_gpus, 0);
   if (rc != RRT_OK) { const int e = fail("rrt_film_gather_all", rc); cleanup(); return e; }
+  unsigned long long rays_generated = 0;
   for (int i = n_gpus - 1; i >= 0; i--) {   // rank 0 last: its stream carries the receiving half of the collective
-    rc = rrt_render_end(handles[i]);
+    rrt_render_stats st;
+    rc = rrt_render_end_stats(handles[i], &st);
     if (rc != RRT_OK) { const int e = fail("rrt_render_end", rc); cleanup(); return e; }
+    rays_generated += st.camera_rays;
   }
+  std::printf("%llu rays generated\n", rays_generated);   // integrator/mod.rs:137 (camera samples with weight > 0, over all tiles)
   std::vector<unsigned char> host(film_bytes), rgba((size_t)W * (size_t)H * 4);
   if (hipSetDevice(0) != hipSuccess || hipMemcpy(host.data(), films[0], film_bytes, hipMemcpyDeviceToHost) != hipSuccess) {
     std::fprintf(stderr, "rrt_render: film copy-out failed\n");
     cleanup();
     return 1;
   }
-  rc = rrt_resolve_rgba8(host.data(), precision, W, H, desc->film.scale, rgba.data());
+  rc = rrt_resolve_rgba8(host.data(), precision, W, H, film_scale, rgba.data());
   if (rc == RRT_OK) rc = rrt_write_png(argv[2], rgba.data(), W, H);
   if (rc != RRT_OK) { const int e = fail("write_image", rc); cleanup(); return e; }
   cleanup();

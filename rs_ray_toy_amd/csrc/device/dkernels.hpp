@@ -1200,9 +1200,12 @@ __global__ void __launch_bounds__(ShadeBlock<R>::n) k_shade_specular(SceneDev<R>
 // when its reflect subtree returns instead of keeping its interaction on the stack). A correctness path, not a fast one.
 // TEX: textured materials; every frame then carries its ray's differentials, which specular children inherit
 // (integrator/mod.rs:183-201, 238-292) - the reason textured scenes take this kernel even without transmissive materials.
+// The explicit stack holds one frame per level of the recursion (at most max_depth): the first kTreeMax in registers / scratch, deeper
+// ones in a strided global array `deep` ([level - kTreeMax][thread of the launch], TreeFrame<R> each; null when max_depth <= kTreeMax).
 constexpr int kTreeMax = 16;
+template <typename R> struct TreeFrame { V3<R> o, d, lo; Rgb<R> beta; int skip, depth, phase; DiffRay<R> dr; };
 template <typename R, bool TEX>
-__global__ void __launch_bounds__(kBlock) k_direct_tree(SceneDev<R> s, Pools<R> p, unsigned long long* totals) {
+__global__ void __launch_bounds__(kBlock) k_direct_tree(SceneDev<R> s, Pools<R> p, unsigned long long* totals, TreeFrame<R>* deep, uint32_t deep_stride) {
   using V4 = typename Vec4T<R>::type;
   const uint32_t i = blockIdx.x * blockDim.x + threadIdx.x;
   if (i >= p.counters[C_ACTIVE]) return;
@@ -1210,8 +1213,10 @@ __global__ void __launch_bounds__(kBlock) k_direct_tree(SceneDev<R> s, Pools<R> 
   const QEnt qe = p.q_active[i];
   const uint32_t index = qe.index;
   uint32_t dim = qe.db & 0xffffu;
-  struct Frame { V3<R> o, d, lo; Rgb<R> beta; int skip, depth, phase; DiffRay<R> dr; };
+  using Frame = TreeFrame<R>;
   Frame st[kTreeMax];
+  auto frame = [&](int k) -> Frame& { return k < kTreeMax ? st[k] : deep[(size_t)(k - kTreeMax) * deep_stride + i]; };
+  const int sp_max = deep ? s.max_depth : kTreeMax;
   int sp = 0;
   {
     const V4 ro = p.ray_o[i], rd = p.ray_d[i];
@@ -1227,7 +1232,7 @@ __global__ void __launch_bounds__(kBlock) k_direct_tree(SceneDev<R> s, Pools<R> 
   Rgb<R> L;
   const bool all_lights = s.integrator == 2 || s.light_strategy == 1 /* RRT_STRATEGY_ALL */;
   while (sp > 0) {
-    Frame& f = st[sp - 1];
+    Frame& f = frame(sp - 1);
     RayCtx<R> r = make_ctx(f.o, f.d, Const<R>::inf, f.lo);
     R hu = 0, hv = 0;
     uint32_t nn, np;
@@ -1289,8 +1294,8 @@ __global__ void __launch_bounds__(kBlock) k_direct_tree(SceneDev<R> s, Pools<R> 
       R pdf = R(0);
       uint32_t sampled = 0;
       const Rgb<R> fs = bsdf.sample_f(si.wo, &wi, to_real<R>(db0), to_real<R>(db1), &pdf, want, &sampled);
-      if (pdf > R(0) && !fs.is_black() && absdot(wi, si.sn) != R(0) && sp < kTreeMax) {
-        Frame& c = st[sp++];
+      if (pdf > R(0) && !fs.is_black() && absdot(wi, si.sn) != R(0) && sp < sp_max) {
+        Frame& c = frame(sp++);
         c.o = si.p; c.lo = si.p_lo; c.d = vnormalize(wi);
         c.beta = beta * (fs * absdot(wi, si.sn) / pdf);
         c.skip = self_prim<R>(hit); c.depth = depth + 1; c.phase = 0;

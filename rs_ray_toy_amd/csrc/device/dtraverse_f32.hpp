@@ -34,9 +34,6 @@
 #ifndef RRT_NODE_STEPS
 #define RRT_NODE_STEPS 2
 #endif
-#ifndef RRT_RG_REFILL
-#define RRT_RG_REFILL 32u
-#endif
 #ifndef RRT_TR_REFILL
 #define RRT_TR_REFILL 16u
 #endif
@@ -59,6 +56,9 @@ struct alignas(64) PairNode {
   uint32_t pad;
 };
 constexpr uint32_t kLeafBit = 0x80000000u;
+// t_max of the pool's shadow rays (spawn_ray_to: 1 - SHADOW_EPSILON with a unit direction, Q9): the any-hit kernels give every pool shadow
+// ray this length, and the host's any-hit start lists (build_pairs()) derive their reach from the same constant
+constexpr float kShadowTmax = 1.0f - 0.0001f;
 typedef float v2f __attribute__((ext_vector_type(2)));
 
 struct F4 { float x, y, z, w; };
@@ -174,7 +174,7 @@ template <bool POOL_SHADOW>
 RRT_DEV uint32_t lane_ray_begin(const TravScene& ts, const Pools<float>& p, bool pool_shadow, uint32_t idx, LaneRay& r, int* start_tri) {
   const float4 ro = (POOL_SHADOW && pool_shadow) ? p.sray_o[idx] : p.ray_o[idx], rd = (POOL_SHADOW && pool_shadow) ? p.sray_d[idx] : p.ray_d[idx];
   V3<float> lo;
-  ray_tail(ro, (POOL_SHADOW && pool_shadow) ? 1.0f - 0.0001f : Const<float>::inf, &r.tmax, &lo);
+  ray_tail(ro, (POOL_SHADOW && pool_shadow) ? kShadowTmax : Const<float>::inf, &r.tmax, &lo);
   const int sk = (int)__float_as_uint(rd.w);
   r.oxy = v2f{ro.x, ro.y}; r.ozz = v2f{ro.z, ro.z}; r.dx = rd.x; r.dy = rd.y; r.dz = rd.z;
   r.lx = lo.x; r.ly = lo.y; r.lz = lo.z;
@@ -516,17 +516,9 @@ __global__ void __launch_bounds__(kPtBlock) k_trace_pt_f32(TravScene ts, Pools<f
 }  // namespace rrtd
 
 // ------------------------------------------------------------------------------------------------------------
-// Persistent-thread camera ray generation (fp32 product path).
-// generate_ray_differential (camera.rs:582-628) traces the main ray through 13 lens interfaces and then 2-4
-// auxiliary rays; 70 % of the main rays die at some interface (29 % at the second one, 16 % at the third, ...), so
-// with one sample per lane a wave runs all 13 steps at ~50 % lane utilisation, and the auxiliary traces at ~30 %.
-// Here every lane is a state machine over (trace, interface): a lane whose sample is decided (dead or alive) pulls
-// the next sample of its wave's reserved range at once, so all lanes execute useful interface steps. The arithmetic
-// per interface is that of trace_from_film / generate_ray in dmath.hpp (same operation order: identical results).
+// Camera ray generation of the fp32 product path: shared pieces.
 // ------------------------------------------------------------------------------------------------------------
 namespace rrtd {
-
-constexpr int kRgBlock = 256;
 
 struct RgLane {
   V3<float> o, d;      // ray in lens space
@@ -535,62 +527,7 @@ struct RgLane {
   int phase;           // 0 main, 1 x+0.05, 2 x-0.05, 3 y+0.05, 4 y-0.05
 };
 
-// start one trace: generate_ray up to the call of trace_lenses_from_film (camera.rs:534-556) + flip_z
-RRT_DEV void rg_begin(const SceneDev<float>& s, float pfx, float pfy, float lx, float ly, RgLane* L, float* cos4_area) {
-  const float sx = pfx / (float)s.xres, sy = pfy / (float)s.yres;
-  const float p2x = s.extent[0] * (1.0f - sx) + s.extent[2] * sx, p2y = s.extent[1] * (1.0f - sy) + s.extent[3] * sy;
-  const V3<float> p_film(-p2x, p2y, 0.0f);
-  const float r_film = sqrtf(p_film.x * p_film.x + p_film.y * p_film.y);
-  const float* pb = (r_film / (s.diagonal / 2.0f) >= 1.0f) ? s.pupil63 : s.pupil0;
-  const float plx = pb[0] * (1.0f - lx) + pb[2] * lx, ply = pb[1] * (1.0f - ly) + pb[3] * ly;
-  const float sin_t = r_film != 0.0f ? p_film.y / r_film : 0.0f, cos_t = r_film != 0.0f ? p_film.x / r_film : 1.0f;
-  const float area = (pb[2] - pb[0]) * (pb[3] - pb[1]);
-  const V3<float> p_rear(cos_t * plx - sin_t * ply, sin_t * plx + cos_t * ply, s.lens[s.n_lens - 1].thickness);
-  RayT<float> rf;
-  rf.o = p_film;
-  rf.d = vnormalize(p_rear - p_film);
-  const float cos_theta = vnormalize(rf.d).z;
-  const float cos4 = (cos_theta * cos_theta) * (cos_theta * cos_theta);
-  if (s.simple_weighting) *cos4_area = cos4 * area / ((s.pupil0[2] - s.pupil0[0]) * (s.pupil0[3] - s.pupil0[1]));
-  else { const float rz = s.lens[s.n_lens - 1].thickness; *cos4_area = (s.shutter_close - s.shutter_open) * (cos4 * area) / rz * rz; }
-  const RayT<float> r = flip_z(rf);
-  L->o = r.o; L->d = r.d; L->element_z = 0.0f; L->i = s.n_lens - 1;
-}
-
-// one interface of trace_lenses_from_film (camera.rs:163-211); false = the ray is blocked
-RRT_DEV bool rg_step(const float4* lens_s, RgLane* L) {
-  const int i = L->i;
-  const float4 el = lens_s[i];   // curvature_radius, thickness, eta, aperture_radius
-  L->element_z -= el.y;
-  float t = 0.0f;
-  V3<float> n;
-  const bool is_stop = el.x == 0.0f;
-  RayT<float> r; r.o = L->o; r.d = L->d;
-  if (is_stop) {
-    if (r.d.z >= 0.0f) return false;
-    t = (L->element_z - r.o.z) / r.d.z;
-  } else {
-    if (!intersect_spherical(el.x, L->element_z + el.x, r, &t, &n)) return false;
-  }
-  if (!(t >= 0.0f)) return false;
-  const V3<float> p_hit = r.o + r.d * t;
-  const float r2 = p_hit.x * p_hit.x + p_hit.y * p_hit.y;
-  if (r2 >= el.w * el.w) return false;
-  L->o = p_hit;
-  if (!is_stop) {
-    V3<float> w;
-    const float eta_prev = (i > 0) ? lens_s[i - 1].z : 0.0f;
-    const float eta_t = (i > 0 && eta_prev != 0.0f) ? eta_prev : 1.0f;
-    if (!refract(vnormalize(-r.d), n, el.z / eta_t, &w)) return false;
-    L->d = w;
-  }
-  L->i = i - 1;
-  return true;
-}
-
-// Stage 1, dense (one thread per slot, every lane busy): get_camerasample (samplers/mod.rs:28-34) = Halton index and
-// the four film / lens dimensions, plus the initial path state. All stores are coalesced in slot order, which is why
-// the sample of every slot is written: 6 streamed words per slot (one 128-bit sample record, index, weight). `dims_out` (optional): the five sampler dimensions per slot, [pixel][sample] order (rrt_camera_samples)
+// per pixel of the pass: Halton pixel offset (halton.rs:75-105) and the packed pixel coordinates - no division by runtime values per sample
 static __global__ void __launch_bounds__(kBlock) k_pixel_offsets(SceneDev<float> s, Pools<float> p, PassDesc pd) {
   const uint32_t pl = blockIdx.x * blockDim.x + threadIdx.x;
   if (pl >= pd.npix) return;
@@ -598,186 +535,6 @@ static __global__ void __launch_bounds__(kBlock) k_pixel_offsets(SceneDev<float>
   pass_pixel(pd, pd.pix_begin + pl, &px, &py);
   p.pix_off[2 * pl] = halton_pixel_offset(s, px, py);
   p.pix_off[2 * pl + 1] = (py << 16) | px;
-}
-// grid: x = pixel blocks, y = sample of the pass (no division by runtime values per slot)
-static __global__ void __launch_bounds__(kBlock) k_sample_f32(SceneDev<float> s, Pools<float> p, PassDesc pd, double* dims_out) {
-  const uint32_t pl = blockIdx.x * blockDim.x + threadIdx.x, sl = blockIdx.y;
-  if (pl >= pd.npix) return;
-  const uint32_t slot = sl * pd.npix + pl;
-  const uint2 po = reinterpret_cast<const uint2*>(p.pix_off)[pl];
-  const uint32_t px = po.y & 0xffffu, py = po.y >> 16;
-  const uint32_t index = po.x + (pd.s_begin + sl) * s.stride;
-  const double d0 = halton_dim(s, index, 0), d1 = halton_dim(s, index, 1), d2 = halton_cam_dim(s, index, 0), d3 = halton_cam_dim(s, index, 1);
-  p.samp[slot] = make_float4((float)px + to_real<float>(d0), (float)py + to_real<float>(d1), to_real<float>(d2) + 0.5f, to_real<float>(d3) + 0.5f);   // p_film, p_lens (Q5)
-  p.hindex[slot] = index;
-  p.weight[slot] = 0.0f;
-  if (dims_out) { double* dd = dims_out + 5 * (size_t)(pl * pd.ns + sl); dd[0] = d0; dd[1] = d1; dd[2] = d2; dd[3] = d3; dd[4] = halton_dim(s, index, 4); }
-}
-
-// Stage 2, persistent threads: the MAIN lens trace of every sample (generate_ray, camera.rs:534-580). 69 % of the
-// samples are blocked at some interface (29 % at the second, 16 % at the third, ...): a lane whose sample is decided
-// takes the next sample of its wave's reserved range, so the 13-interface loop runs with full lanes. A sample that
-// gets through writes its camera ray (by slot, until stage 4 knows whether it lives) and its weight.
-static __global__ void __launch_bounds__(kRgBlock) k_raygen_pt_f32(SceneDev<float> s, Pools<float> p, PassDesc pd, uint32_t* work) {
-  __shared__ float4 lens_s[32];
-  const uint32_t tid = threadIdx.x, lane = tid & 63u;
-  if (tid < (uint32_t)s.n_lens) { const LensElem<float> e = s.lens[tid]; lens_s[tid] = make_float4(e.curvature_radius, e.thickness, e.eta, e.aperture_radius); }
-  __syncthreads();
-  const uint32_t total = pd.npix * pd.ns;
-  bool busy = false, exhausted = false;
-  uint32_t slot = 0, lo = 0, hi = 0;
-  float w_main = 0;
-  RgLane L; L.i = -1; L.phase = 0; L.element_z = 0;
-  const uint32_t n_waves = gridDim.x * (kRgBlock / 64);
-  uint32_t grain = (total / (4u * n_waves) + 63u) & ~63u;
-  grain = grain < 64u ? 64u : (grain > 1024u ? 1024u : grain);
-
-  while (true) {
-    // ---- refill: new samples start their trace together --------------------------------------------------------------
-    const uint64_t idle = __ballot(!busy);
-    const uint32_t n_idle = (uint32_t)__popcll(idle);
-    if (!exhausted && n_idle >= RRT_RG_REFILL) {
-      if (lo == hi) {
-        uint32_t base = 0;
-        if (lane == 0) base = atomicAdd(work, grain);
-        base = __shfl(base, 0);
-        lo = base; hi = base + grain < total ? base + grain : total;
-        if (base >= total) { exhausted = true; lo = hi = 0; }
-      }
-      if (!exhausted) {
-        const uint32_t take = (hi - lo) < n_idle ? (hi - lo) : n_idle;
-        const uint32_t rank = (uint32_t)__popcll(idle & ((1ull << lane) - 1ull));
-        if (!busy && rank < take) {
-          slot = lo + rank;
-          const float4 cs = p.samp[slot];
-          rg_begin(s, cs.x, cs.y, cs.z, cs.w, &L, &w_main);
-          busy = true;
-        }
-        lo += take;
-      }
-    }
-    if (__ballot(busy) == 0ull) { if (exhausted) break; else continue; }
-    // ---- one lens interface per busy lane -------------------------------------------------------------------------
-    if (busy) {
-      const bool ok = rg_step(lens_s, &L);
-      if (!ok) busy = false;
-      else if (L.i < 0) {
-        if (w_main != 0.0f) {   // ray out of the lens = flip_z, camera_to_world (double normalise), ray.d.normalize() (camera.rs:558-565)
-          RayT<float> rl; rl.o = L.o; rl.d = L.d;
-          const RayT<float> rc = flip_z(rl);
-          const V3<float> wo = aff_pt(s.cam_m, rc.o);
-          const V3<float> wd = vnormalize(vnormalize(vnormalize(aff_vec(s.cam_m, rc.d))));
-          store_ray<float>(p.nray_o, p.nray_d, slot, wo, V3<float>(), wd, Const<float>::inf, -1);
-          p.weight[slot] = w_main;   // dead samples keep stage 1's 0
-        }
-        busy = false;
-      }
-    }
-  }
-}
-
-// Stage 3: samples whose main ray got through (weight > 0) -> staging queue q_next, in slot order. Each wave scans
-// kCompactRun consecutive 64-slot groups, reserves its output range with ONE atomic and then writes, so a 268 M-slot
-// frame issues 65 k atomics on the queue counter instead of 4 M (which serialise on one L2 atomic unit).
-constexpr uint32_t kCompactRun = 64;
-static __global__ void __launch_bounds__(kBlock) k_compact_alive(Pools<float> p, uint32_t total) {
-  const uint32_t lane = threadIdx.x & 63u;
-  const uint32_t wave = (blockIdx.x * blockDim.x + threadIdx.x) >> 6;
-  const uint64_t base_slot = (uint64_t)wave * 64u * kCompactRun;
-  if (base_slot >= total) return;
-  // the 64 liveness masks of the run are kept in registers (one per lane: lane k holds the ballot of group k), so the weights
-  // are read once, eight independent loads in flight at a time
-  uint64_t my_mask = 0;
-  uint32_t n_alive = 0;
-  for (uint32_t k0 = 0; k0 < kCompactRun; k0 += 8) {
-    float w[8];
-#pragma unroll
-    for (uint32_t j = 0; j < 8; j++) {
-      const uint64_t slot = base_slot + (uint64_t)(k0 + j) * 64u + lane;
-      w[j] = slot < total ? p.weight[slot] : 0.0f;
-    }
-#pragma unroll
-    for (uint32_t j = 0; j < 8; j++) {
-      const uint64_t m = __ballot(w[j] > 0.0f);
-      if (lane == k0 + j) my_mask = m;
-      n_alive += (uint32_t)__popcll(m);
-    }
-  }
-  if (n_alive == 0) return;
-  uint32_t out = 0;
-  if (lane == 0) out = atomicAdd(&p.counters[C_NEXT], n_alive);
-  out = __shfl(out, 0);
-  for (uint32_t k = 0; k < kCompactRun; k++) {
-    const uint64_t m = __shfl(my_mask, (int)k);
-    if ((m >> lane) & 1ull) p.q_next[out + (uint32_t)__popcll(m & ((1ull << lane) - 1ull))] = QEnt{(uint32_t)(base_slot + (uint64_t)k * 64u + lane), 0u, 0u, 0u};
-    out += (uint32_t)__popcll(m);
-  }
-}
-
-// Stage 4, dense over the staging queue: the auxiliary rays of generate_ray_differential (camera.rs:582-628) at
-// p_film + 0.05 px in x (then - 0.05 if that one is blocked), then the same in y. Nearly every main-ray survivor
-// passes x+ and y+, so all lanes run the same 2 x 13 interfaces. A sample whose x or y pair is blocked both ways
-// gets weight 0; the others enter q_active with ray, path record and a zeroed L. `enqueue` = 0 for AOIntegrator.
-RRT_DEV bool rg_trace(const SceneDev<float>& s, const float4* lens_s, float pfx, float pfy, float lx, float ly, RayT<float>* out = nullptr) {
-  RgLane L; L.phase = 0;
-  float w = 0.0f;
-  rg_begin(s, pfx, pfy, lx, ly, &L, &w);
-  while (L.i >= 0) if (!rg_step(lens_s, &L)) return false;
-  if (out) {   // the auxiliary ray itself (textured scenes: ray differentials), as generate_ray leaves it (camera.rs:558-565)
-    RayT<float> rl; rl.o = L.o; rl.d = L.d;
-    const RayT<float> rc = flip_z(rl);
-    out->o = aff_pt(s.cam_m, rc.o);
-    out->d = vnormalize(vnormalize(vnormalize(aff_vec(s.cam_m, rc.d))));
-  }
-  return w != 0.0f;
-}
-static __global__ void __launch_bounds__(kRgBlock) k_raygen_aux_f32(SceneDev<float> s, Pools<float> p, int enqueue) {
-  __shared__ float4 lens_s[32];
-  __shared__ uint32_t push_lds[kRgBlock / 64 + 1];
-  const uint32_t tid = threadIdx.x;
-  const uint32_t n = p.counters[C_NEXT];
-  if (blockIdx.x * blockDim.x >= n) return;   // the grid is sized for the worst case
-  if (tid < (uint32_t)s.n_lens) { const LensElem<float> e = s.lens[tid]; lens_s[tid] = make_float4(e.curvature_radius, e.thickness, e.eta, e.aperture_radius); }
-  __syncthreads();
-  const uint32_t i = blockIdx.x * blockDim.x + tid;
-  bool alive = false;
-  uint32_t slot = 0;
-  if (i < n) {
-    slot = p.q_next[i].slot;
-    const float4 cs = p.samp[slot];
-    const float pfx = cs.x, pfy = cs.y, lx = cs.z, ly = cs.w;
-    const bool diffs = p.rdx_o != nullptr;   // block-uniform
-    RayT<float> aux, auy;
-    float epsx = 0.05f, epsy = 0.05f;
-    bool okx = rg_trace(s, lens_s, pfx + 0.05f, pfy, lx, ly, diffs ? &aux : nullptr);
-    if (!okx) { epsx = -0.05f; okx = rg_trace(s, lens_s, pfx - 0.05f, pfy, lx, ly, diffs ? &aux : nullptr); }
-    bool oky = false;
-    if (okx) {
-      oky = rg_trace(s, lens_s, pfx, pfy + 0.05f, lx, ly, diffs ? &auy : nullptr);
-      if (!oky) { epsy = -0.05f; oky = rg_trace(s, lens_s, pfx, pfy - 0.05f, lx, ly, diffs ? &auy : nullptr); }
-    }
-    alive = okx && oky;
-    if (!alive) p.weight[slot] = 0.0f;
-    if (alive && diffs) {   // rx / ry (camera.rs:597-598, 613-614), then scale_differentials (geometry.rs:1883-1888); see k_raygen_aux
-      const float4 mo = p.nray_o[slot], md = p.nray_d[slot];
-      const V3<float> o(mo.x, mo.y, mo.z), d(md.x, md.y, md.z);
-      V3<float> rxo = o + (aux.o - o) / epsx, rxd = d + (aux.d - d) / epsx;
-      V3<float> ryo = o + (auy.o - o) / epsy, ryd = d + (auy.d - d) / epsy;
-      rxo = o + (rxo - o) * s.diff_scale; ryo = o + (ryo - o) * s.diff_scale;
-      rxd = d + (rxd - d) * s.diff_scale; ryd = d + (ryd - d) * s.diff_scale;
-      p.rdx_o[slot] = make_float4(rxo.x, rxo.y, rxo.z, 0.0f); p.rdx_d[slot] = make_float4(rxd.x, rxd.y, rxd.z, 0.0f);
-      p.rdy_o[slot] = make_float4(ryo.x, ryo.y, ryo.z, 0.0f); p.rdy_d[slot] = make_float4(ryd.x, ryd.y, ryd.z, 0.0f);
-    }
-  }
-  const bool enq = alive && enqueue;
-  const uint32_t q = block_push(&p.counters[C_ACTIVE], enq, push_lds);
-  (void)block_push(&p.counters[C_CAMERA_RAYS], alive, push_lds);
-  if (enq) {
-    p.q_active[q] = QEnt{slot, 5u, p.hindex[slot], 0u};   // five camera dimensions consumed, bounce 0
-    p.path[q] = make_float4(1.0f, 1.0f, 1.0f, 1.0f);      // beta, eta_scale
-    p.ray_o[q] = p.nray_o[slot]; p.ray_d[q] = p.nray_d[slot];
-  }
-  if (alive) p.L[slot] = make_float4(0.0f, 0.0f, 0.0f, 0.0f);
 }
 
 }  // namespace rrtd
@@ -916,9 +673,9 @@ static __global__ void __launch_bounds__(kRgDense) k_raygen_main_f32(SceneDev<fl
   rg_lens_to_lds(s, &lens, tid);
   if (tid < (uint32_t)s.n_lens) safe_s[tid] = safe_lim ? safe_lim[tid] : make_float2(0.0f, 0.0f);   // 16 c_i = 0: never safe
   __syncthreads();
-  // grid: x = sample of the pass, y = pixel block - blocks are dispatched x first, so the survivors reach the queue pixel block by pixel
-  // block (all samples of 1 024 neighbouring pixels together): the queue is in image order, which the XCD-aware traversal relies on
-  const uint32_t pl = blockIdx.y * blockDim.x + tid, sl = blockIdx.x;
+  // grid: x = sample of the pass, (y, z) = pixel block - blocks are dispatched x first, so the survivors reach the queue pixel block by pixel
+  // block (all samples of 512 neighbouring pixels together): the queue is in image order, which the XCD-aware traversal relies on
+  const uint32_t pl = (blockIdx.z * gridDim.y + blockIdx.y) * blockDim.x + tid, sl = blockIdx.x;
   bool alive = false;
   uint32_t slot = 0, index = 0;
   float pfx = 0, pfy = 0, lx = 0, ly = 0, w = 0;

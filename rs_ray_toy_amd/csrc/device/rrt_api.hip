@@ -1,7 +1,7 @@
 // extern "C" device entry points of include/rrt.h: argument checks, precision dispatch, error mapping.
 #include "rrt_impl.hpp"
 
-namespace rrt { void set_last_error(const std::string& msg); }
+namespace rrt { void set_last_error(const std::string& msg); void comm_cache_release(int device); }
 
 struct rrt_handle { rrtd::HandleBase* impl; };
 
@@ -44,9 +44,13 @@ int rrt_create(int device, const rrt_scene_desc* desc, int precision, rrt_handle
 
 void rrt_destroy(rrt_handle* h) {
   if (!h) return;
+  rrt::comm_cache_release(h->impl->device());   // communicators rrt_film_gather_all cached for this device (rrt_comm.hip)
   delete h->impl;
   delete h;
 }
+
+size_t rrt_warning_count(const rrt_handle* h) { return h ? h->impl->warnings.size() : 0; }
+const char* rrt_warning(const rrt_handle* h, size_t i) { return (h && i < h->impl->warnings.size()) ? h->impl->warnings[i].c_str() : nullptr; }
 
 void* rrt_stream(rrt_handle* h) { return h ? (void*)h->impl->stream() : nullptr; }
 

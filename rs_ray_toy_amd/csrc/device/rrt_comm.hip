@@ -13,6 +13,7 @@
 #include <dlfcn.h>
 #include <rccl/rccl.h>
 
+#include <cstdlib>
 #include <mutex>
 
 #include "rrt_impl.hpp"
@@ -32,6 +33,7 @@ struct Rccl {
   decltype(&::ncclCommInitRank) CommInitRank = nullptr;
   decltype(&::ncclCommInitAll) CommInitAll = nullptr;
   decltype(&::ncclCommDestroy) CommDestroy = nullptr;
+  decltype(&::ncclCommAbort) CommAbort = nullptr;
   decltype(&::ncclGroupStart) GroupStart = nullptr;
   decltype(&::ncclGroupEnd) GroupEnd = nullptr;
   decltype(&::ncclSend) Send = nullptr;
@@ -45,13 +47,23 @@ const Rccl& rccl() {
   static std::string failure;
   std::call_once(once, []() {
     void* lib = nullptr;
-    for (const char* name : {"librccl.so.1", "librccl.so", "/opt/rocm/lib/librccl.so.1"}) if ((lib = dlopen(name, RTLD_NOW | RTLD_GLOBAL))) break;
-    if (!lib) { failure = std::string("RCCL not found (dlopen librccl.so.1): ") + (dlerror() ? dlerror() : "?"); return; }
+    std::string tried;
+    // RRT_RCCL_LIBRARY: the one library to bind (a deployment that ships its own RCCL; tests point it at a missing file)
+    const char* forced = getenv("RRT_RCCL_LIBRARY");
+    for (const char* name : {"librccl.so.1", "librccl.so", "/opt/rocm/lib/librccl.so.1"}) {
+      const char* path = (forced && *forced) ? forced : name;
+      if ((lib = dlopen(path, RTLD_NOW | RTLD_GLOBAL))) break;
+      const char* e = dlerror();   // (one call: dlerror() clears the message it returns)
+      if (tried.empty()) tried = e ? e : "?";
+      if (forced && *forced) break;
+    }
+    if (!lib) { failure = "RCCL not found (dlopen librccl.so.1): " + tried; return; }
     auto sym = [&](const char* n) { void* f = dlsym(lib, n); if (!f && failure.empty()) failure = std::string("RCCL symbol missing: ") + n; return f; };
     api.GetUniqueId = (decltype(api.GetUniqueId))sym("ncclGetUniqueId");
     api.CommInitRank = (decltype(api.CommInitRank))sym("ncclCommInitRank");
     api.CommInitAll = (decltype(api.CommInitAll))sym("ncclCommInitAll");
     api.CommDestroy = (decltype(api.CommDestroy))sym("ncclCommDestroy");
+    api.CommAbort = (decltype(api.CommAbort))sym("ncclCommAbort");
     api.GroupStart = (decltype(api.GroupStart))sym("ncclGroupStart");
     api.GroupEnd = (decltype(api.GroupEnd))sym("ncclGroupEnd");
     api.Send = (decltype(api.Send))sym("ncclSend");
@@ -75,6 +87,16 @@ int guarded(F&& fn) {
   catch (const rrtd::DeviceError& e) { rrt::set_last_error(e.what()); return RRT_EDEVICE; }
   catch (const std::invalid_argument& e) { rrt::set_last_error(e.what()); return RRT_EINVAL; }
   catch (const std::exception& e) { rrt::set_last_error(e.what()); return RRT_EINVAL; }
+}
+
+// communicators of rrt_film_gather_all (one process, all GPUs): created on first use, kept while handles on those devices live
+// (rrt::comm_cache_release, called from rrt_destroy), keyed by the device list
+std::mutex g_cache_mu;
+std::vector<int> g_cache_devs;
+std::vector<ncclComm_t> g_cache_comms;
+void cache_drop_locked(bool abort) {
+  for (ncclComm_t c : g_cache_comms) if (c) { if (abort) (void)rccl().CommAbort(c); else (void)rccl().CommDestroy(c); }
+  g_cache_comms.clear(); g_cache_devs.clear();
 }
 
 // one rank's part of the collective, inside an open ncclGroup; `films[r]` only matters on the rank that owns it
@@ -145,7 +167,7 @@ int rrt_comm_create(const uint8_t id[RRT_COMM_ID_BYTES], int rank, int world, in
 void rrt_comm_destroy(rrt_comm* c) {
   if (!c) return;
   (void)hipSetDevice(c->device);
-  try { (void)rccl().CommDestroy(c->comm); } catch (const NcclError&) {}
+  if (c->comm) { try { (void)rccl().CommDestroy(c->comm); } catch (const NcclError&) {} }   // (null: aborted after a failed collective)
   delete c;
 }
 
@@ -153,43 +175,58 @@ int rrt_film_gather(rrt_handle* h, rrt_comm* c, void* film_xyzw_device, int root
   if (!h || !c || !film_xyzw_device) { rrt::set_last_error("rrt_film_gather: null argument"); return RRT_EINVAL; }
   if (root < 0 || root >= c->world) { rrt::set_last_error("rrt_film_gather: root out of range"); return RRT_EINVAL; }
   if (h->impl->device() != c->device) { rrt::set_last_error("rrt_film_gather: handle and communicator live on different devices"); return RRT_EINVAL; }
+  if (!c->comm) { rrt::set_last_error("rrt_film_gather: the communicator was aborted by an earlier failed collective"); return RRT_EDEVICE; }
   return guarded([&]() {
     HIP_CHECK(hipSetDevice(c->device));
     NCCL_CHECK(rccl().GroupStart());
+    // A failure inside the group leaves it partly enqueued: launching that part (ncclGroupEnd) could leave a peer waiting in a
+    // recv nobody matches. Abort the communicator instead - the peers' calls then fail too instead of hanging - and refuse it from now on.
     try { enqueue_gather(h->impl, c->comm, c->rank, c->world, film_xyzw_device, root); }
-    catch (...) { (void)rccl().GroupEnd(); throw; }
+    catch (...) { (void)rccl().CommAbort(c->comm); c->comm = nullptr; (void)rccl().GroupEnd(); throw; }   // (GroupEnd only closes this thread's group: the aborted communicator launches nothing)
     NCCL_CHECK(rccl().GroupEnd());
   });
 }
 
 // One process that owns all GPUs of the node (what the reference's single binary becomes): communicators come from
-// ncclCommInitAll over the handles' devices and are kept for the process lifetime (keyed by the device list).
+// ncclCommInitAll over the handles' devices and are kept until a handle on one of those devices is destroyed (keyed by the device
+// list). n == 1: the frame is already where it belongs, nothing is sent and RCCL is not even loaded.
 int rrt_film_gather_all(rrt_handle* const* handles, void* const* films_device, int n, int root) {
   if (!handles || !films_device || n < 1 || root < 0 || root >= n) { rrt::set_last_error("rrt_film_gather_all: bad argument"); return RRT_EINVAL; }
   for (int i = 0; i < n; i++) if (!handles[i] || !films_device[i]) { rrt::set_last_error("rrt_film_gather_all: null handle / film"); return RRT_EINVAL; }
+  if (n == 1) return RRT_OK;
   return guarded([&]() {
-    static std::mutex mu;
-    static std::vector<int> devs;
-    static std::vector<ncclComm_t> comms;
-    std::lock_guard<std::mutex> lock(mu);
+    std::lock_guard<std::mutex> lock(g_cache_mu);
     std::vector<int> want(n);
     for (int i = 0; i < n; i++) want[i] = handles[i]->impl->device();
     for (int i = 0; i < n; i++) for (int j = 0; j < i; j++) if (want[i] == want[j]) throw std::invalid_argument("rrt_film_gather_all: two handles on one device (RCCL needs one rank per GPU)");
-    if (want != devs) {
-      for (ncclComm_t c : comms) (void)rccl().CommDestroy(c);
-      comms.assign(n, nullptr); devs.clear();
-      NCCL_CHECK(rccl().CommInitAll(comms.data(), n, want.data()));
-      devs = want;
+    if (want != g_cache_devs) {
+      cache_drop_locked(false);
+      g_cache_comms.assign(n, nullptr);
+      NCCL_CHECK(rccl().CommInitAll(g_cache_comms.data(), n, want.data()));
+      g_cache_devs = want;
     }
     NCCL_CHECK(rccl().GroupStart());
     try {
       for (int i = 0; i < n; i++) {
         HIP_CHECK(hipSetDevice(want[i]));
-        enqueue_gather(handles[i]->impl, comms[i], i, n, films_device[i], root);
+        enqueue_gather(handles[i]->impl, g_cache_comms[i], i, n, films_device[i], root);
       }
-    } catch (...) { (void)rccl().GroupEnd(); throw; }
+    } catch (...) { cache_drop_locked(true); (void)rccl().GroupEnd(); throw; }   // (see rrt_film_gather: never launch a partly enqueued group)
     NCCL_CHECK(rccl().GroupEnd());
   });
 }
 
 }  // extern "C"
+
+// rrt_destroy (rrt_api.hip): a handle on `device` goes away - so do the cached communicators that span that device
+namespace rrt {
+void comm_cache_release(int device) {
+  std::lock_guard<std::mutex> lock(g_cache_mu);
+  if (g_cache_comms.empty()) return;   // (the usual case; RCCL is not touched, not even loaded)
+  bool spans = false;
+  for (int d : g_cache_devs) spans |= d == device;
+  if (!spans) return;
+  try { cache_drop_locked(false); } catch (const NcclError&) { g_cache_comms.clear(); g_cache_devs.clear(); }
+}
+size_t comm_cache_size() { std::lock_guard<std::mutex> lock(g_cache_mu); return g_cache_comms.size(); }
+}  // namespace rrt

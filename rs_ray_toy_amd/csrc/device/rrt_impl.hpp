@@ -46,6 +46,7 @@ struct HandleBase {
   virtual void render_bands_begin(int rank, int world, void* film_device) = 0;
   virtual void render_end(rrt_render_stats* stats) = 0;
   virtual void set_option(const std::string& key, double v) = 0;
+  std::vector<std::string> warnings;   // rrt_warning(): non-fatal diagnostics of the handle's creation
 };
 
 template <typename T>
@@ -359,7 +360,7 @@ class Handle : public HandleBase {
     if (key == "max_paths") { if (v < 64) throw std::invalid_argument("max_paths must be >= 64"); max_paths_ = (size_t)v; }
     else if (key == "count_traversal") count_traversal_ = v != 0;
     else if (key == "persistent_traversal") { persistent_ = v != 0; if (v >= 1) trav_mode_ = (int)v; }
-    else if (key == "raygen_pt") raygen_pt_ = (int)v;   // 0: generic two-stage kernels, 1: four-kernel persistent-thread version, 2 (default): dense two-stage kernels with the lean lens arithmetic
+    else if (key == "raygen_pt") raygen_pt_ = v != 0 ? 2 : 0;   // 0: generic two-stage kernels (the reference's operation order), otherwise (default): dense two-stage kernels with the lean lens arithmetic
     else if (key == "pt_split_closest") pt_split_closest_ = (uint32_t)v;
     else if (key == "pt_split_any") pt_split_any_ = (uint32_t)v;
     else if (key == "overlap_shadow") overlap_shadow_ = v != 0;
@@ -527,7 +528,14 @@ class Handle : public HandleBase {
     HIP_CHECK(hipMemsetAsync(totals_.p, 0, 8 * sizeof(unsigned long long), st_));
     HIP_CHECK(hipMemsetAsync(counters_.p, 0, C_COUNT * sizeof(uint32_t), st_));
 
-    const size_t P = std::min(max_paths_, std::max<size_t>(rpix * (size_t)std::max<uint64_t>(s_total, 1), 64));
+    size_t P = std::min(max_paths_, std::max<size_t>(rpix * (size_t)std::max<uint64_t>(s_total, 1), 64));
+    if ((desc_.integrator.type == RRT_INT_DIRECT || desc_.integrator.type == RRT_INT_DEBUG) && (has_transmissive_ || tex_depth_ > 0) && desc_.integrator.max_depth > kTreeMax) {
+      // k_direct_tree keeps (max_depth - kTreeMax) overflow frames per slot of a pass: a quarter of the free memory at most
+      size_t free_b = 0, total_b = 0;
+      HIP_CHECK(hipMemGetInfo(&free_b, &total_b));
+      const size_t per_slot = (size_t)(desc_.integrator.max_depth - kTreeMax) * sizeof(TreeFrame<R>);
+      P = std::max<size_t>(64, std::min(P, (free_b / 4) / per_slot));
+    }
     ensure_pools(P);
     const size_t group = std::min(rpix, cap_);                           // pixels per group
     const uint64_t s_chunk = std::max<uint64_t>(1, cap_ / group);         // samples per pass
@@ -610,8 +618,15 @@ class Handle : public HandleBase {
         } else if (integ == RRT_INT_DIRECT || integ == RRT_INT_DEBUG) {
           if (has_transmissive_ || tex_depth_ > 0) {   // binary recursion with depth-first sampler dimensions / inherited ray differentials: one thread per camera sample
             size_t e2 = tick(3);
-            if (tex_depth_ > 0) hipLaunchKernelGGL((k_direct_tree<R, true>), dim3(grid), dim3(kBlock), 0, st_, scene_, pool_, totals_.p);
-            else hipLaunchKernelGGL((k_direct_tree<R, false>), dim3(grid), dim3(kBlock), 0, st_, scene_, pool_, totals_.p);
+            // frames below level kTreeMax of the per-sample recursion live in a strided global array, sized for this pass
+            TreeFrame<R>* deep = nullptr;
+            if (max_depth > kTreeMax) {
+              const size_t need = (size_t)(max_depth - kTreeMax) * nslots;
+              if (tree_deep_.n < need) { HIP_CHECK(hipStreamSynchronize(st_)); tree_deep_.alloc(need); }
+              deep = tree_deep_.p;
+            }
+            if (tex_depth_ > 0) hipLaunchKernelGGL((k_direct_tree<R, true>), dim3(grid), dim3(kBlock), 0, st_, scene_, pool_, totals_.p, deep, (uint32_t)nslots);
+            else hipLaunchKernelGGL((k_direct_tree<R, false>), dim3(grid), dim3(kBlock), 0, st_, scene_, pool_, totals_.p, deep, (uint32_t)nslots);
             tock(e2);
           } else {
           const bool all = integ == RRT_INT_DEBUG || desc_.integrator.light_strategy == RRT_STRATEGY_ALL;
@@ -723,7 +738,7 @@ class Handle : public HandleBase {
   size_t max_paths_ = (size_t)1 << 28;   // clamped to half of the free HBM at creation (sized for 288 GB parts)
   bool deep_ = false, count_traversal_ = false, persistent_ = true;
   bool pairs_ok_ = false;
-  uint32_t trav_grid_ = 0, pt_grid_ = 0, rg_grid_ = 0;
+  uint32_t trav_grid_ = 0, pt_grid_ = 0;
   int raygen_pt_ = 2;
   bool has_transmissive_ = false, has_translucent_ = false;
   int trav_mode_ = 3;   // 1 = LDS-treelet grid-stride kernel, 2 = persistent-thread kernel, 3 = by queue size
@@ -766,6 +781,7 @@ class Handle : public HandleBase {
   DevBuf<typename Vec4T<R>::type> vpool_;
   DevBuf<R> rpool_;
   DevBuf<uint32_t> upool_, counters_, deep_stack_;
+  DevBuf<TreeFrame<R>> tree_deep_;   // k_direct_tree: frames of recursion levels past kTreeMax, [level][slot of the pass]
   DevBuf<unsigned long long> totals_;
   DevBuf<R> film_;       // per pixel: running RGB contribution sum + filter weight sum of the frame being rendered
   DevBuf<R> film_xyz_;   // the same merged to XYZ, staging for a host film
@@ -773,8 +789,10 @@ class Handle : public HandleBase {
   // which materials the aggregate really uses (declared-but-unused ones never reach a kernel)
   void scan_materials(const rrt_scene_desc* d) {
     has_transmissive_ = has_translucent_ = false;
+    bool transmissive_sphere = false;
     for (size_t i = 0; i < d->n_prims; i++) {
       const rrt_material& m = d->materials[d->prims[i].material];
+      if (d->prims[i].type == RRT_PRIM_SPHERE && (m.type == RRT_MAT_GLASS || m.type == RRT_MAT_TRANSLUCENT)) transmissive_sphere = true;
       auto black = [](const double* c) { return !(c[0] > 0.0) && !(c[1] > 0.0) && !(c[2] > 0.0); };
       if (m.type == RRT_MAT_GLASS) {
         has_transmissive_ = true;
@@ -785,16 +803,20 @@ class Handle : public HandleBase {
         if (black(m.reflect) && black(m.transmit)) throw PanicError("translucent.rs:66 null BSDF: path.rs:103 `bounces -= 1` underflows at the first bounce");
       }
     }
+    // sphere.rs has no epsilon: a ray spawned on a sphere re-hits it at t ~ 0 on a last-bit coin, and every refraction through a
+    // transmissive sphere tosses one. The f64 mode replays the reference's coins; fp32 has its own, and the chain through a glass
+    // sphere amplifies them (no fp32 statement is made for such scenes)
+    if (transmissive_sphere && std::is_same<R, float>::value)
+      warnings.push_back("RRT_F32: sphere primitives with Glass / Translucent materials - the reference's result depends on last-bit decisions of "
+                         "sphere.rs:124-259 (no epsilon) that fp32 cannot replay; no parity is claimed for these pixels, use RRT_F64");
   }
   void check_renderable() {
     if (tex_depth_ > kTexDepth) throw UnsupportedError("texture graphs deeper than " + std::to_string(kTexDepth) + " levels");
     if (tex_depth_ > 0 && (desc_.integrator.type == RRT_INT_DIRECT || desc_.integrator.type == RRT_INT_DEBUG)) {
       // specular children inherit ray differentials (integrator/mod.rs:183-201, 238-292): the per-sample recursion kernel carries them
-      if (desc_.integrator.max_depth > kTreeMax) throw UnsupportedError("DirectLighting / Debug with textured materials: max_depth above 16");
       if (deep_) throw UnsupportedError("DirectLighting / Debug with textured materials on a BVH deeper than 64");
     }
     if (has_transmissive_ && (desc_.integrator.type == RRT_INT_DIRECT || desc_.integrator.type == RRT_INT_DEBUG)) {
-      if (desc_.integrator.max_depth > kTreeMax) throw UnsupportedError("DirectLighting / Debug with transmissive materials: max_depth above 16");
       if (deep_) throw UnsupportedError("DirectLighting / Debug with transmissive materials on a BVH deeper than 64");
     }
     if (desc_.sampler.type == RRT_SAMPLER_STRATIFIED) {
@@ -854,6 +876,10 @@ class Handle : public HandleBase {
     std::vector<InstDev<R>> insts;
     std::unordered_map<int32_t, uint32_t> inst_of;
     uint32_t inst_index = 0;
+    // RRT_INSTANCES_KEEP / _FLATTEN (rrt.h): the f64 parity mode replays TransformedPrimitive::intersect for EVERY instance (the
+    // reference's evaluation order: exact box / face ties break as they do there), the fp32 product flattens the rigid ones
+    if ((d->flags & RRT_INSTANCES_KEEP) && (d->flags & RRT_INSTANCES_FLATTEN)) throw std::invalid_argument("RRT_INSTANCES_KEEP and RRT_INSTANCES_FLATTEN are exclusive");
+    const bool keep_all = (d->flags & RRT_INSTANCES_KEEP) != 0u || (std::is_same<R, double>::value && (d->flags & RRT_INSTANCES_FLATTEN) == 0u);
     for (size_t i = 0; i < d->n_prim_order; i++) {
       const uint32_t pi = d->prim_order[i];
       const rrt_prim& pr = d->prims[pi];
@@ -886,7 +912,7 @@ class Handle : public HandleBase {
       bool kept = false;   // non-rigid instance: not flattened, the ray is transformed per test like the reference does (Q15)
       if (pr.instance >= 0) {
         m = d->xforms[pr.instance].m; mi = d->xforms[pr.instance].m_inv;
-        if (!is_rigid(m)) {
+        if (keep_all || !is_rigid(m)) {
           auto it = inst_of.find(pr.instance);
           if (it == inst_of.end()) {
             InstDev<R> I{};
@@ -896,7 +922,7 @@ class Handle : public HandleBase {
             it = inst_of.emplace(pr.instance, (uint32_t)insts.size()).first;
             insts.push_back(I);
           }
-          if (it->second >= 0x8000u || pr.material >= 0x10000u) throw UnsupportedError("more than 32 768 non-rigid instances / 65 536 materials");
+          if (it->second >= 0x8000u || pr.material >= 0x10000u) throw UnsupportedError("more than 32 768 kept (non-rigid, or RRT_INSTANCES_KEEP / RRT_F64) instances / 65 536 materials");
           kept = true; inst_index = it->second;
         }
       }
@@ -1268,11 +1294,14 @@ class Handle : public HandleBase {
     }
     HIP_CHECK(hipGetLastError());
   }
-  // camera ray generation: persistent-thread kernel in fp32, two-stage (main trace, compaction, auxiliary traces) in f64
+  // camera ray generation: the dense lean-arithmetic kernels in fp32 (dtraverse_f32.hpp), the generic two-stage kernels (main trace, auxiliary traces; the
+  // reference's operation order) in f64 and for what the dense ones do not cover
   void launch_raygen(const PassDesc& pd, uint32_t grid, double* dims_out, int enqueue) {
     if constexpr (std::is_same<R, float>::value) {
-      const bool pt_ok = scene_.n_lens <= 32 && scene_.sampler_type == RRT_SAMPLER_HALTON && scene_.xres < 65536 && scene_.yres < 65536 && pd.ns <= 65535u;
-      if (raygen_pt_ >= 2 && pt_ok && (pd.npix + kRgDense - 1) / kRgDense <= 65535u) {
+      // the dense fp32 kernels cover Halton scenes with lenses of up to 32 interfaces on films below 65 536 px per side; everything else
+      // (StratifiedSampler, longer lens tables) takes the generic kernels below, which have no such limits
+      const bool pt_ok = scene_.n_lens <= 32 && scene_.sampler_type == RRT_SAMPLER_HALTON && scene_.xres < 65536 && scene_.yres < 65536;
+      if (raygen_pt_ >= 1 && pt_ok) {
         const uint32_t total = pd.npix * pd.ns;
         if (pix_off_.n < 2 * (size_t)pd.npix) { HIP_CHECK(hipStreamSynchronize(st_)); pix_off_.alloc(2 * (size_t)pd.npix); }
         pool_.pix_off = pix_off_.p;
@@ -1282,31 +1311,12 @@ class Handle : public HandleBase {
         HIP_CHECK(hipMemsetAsync(pool_.weight, 0, (size_t)total * sizeof(R), st_));   // dead samples: weight 0 (Q2), nothing else is written for them
         {   // dense two-stage version with the lean lens arithmetic
           const float2* safe_r2 = (aux_margin_ && tex_depth_ == 0) ? reinterpret_cast<const float2*>(lens_safe_.p) : nullptr;   // textured scenes keep the auxiliary rays themselves (ray differentials)
-          hipLaunchKernelGGL(k_raygen_main_f32, dim3(pd.ns, (pd.npix + kRgDense - 1) / kRgDense), dim3(kRgDense), 0, st_, scene_, pool_, pd, write_samp, dims_out, safe_r2, aux_delta_, aux_pupil_, enqueue);
+          // pixel blocks over grid y and z (a grid dimension holds at most 65 535 blocks; a pass has up to 2^28 / 512 of them)
+          const uint32_t n_pb = (pd.npix + kRgDense - 1) / kRgDense, gz = (n_pb + 65534u) / 65535u, gy = (n_pb + gz - 1) / gz;
+          hipLaunchKernelGGL(k_raygen_main_f32, dim3(pd.ns, gy, gz), dim3(kRgDense), 0, st_, scene_, pool_, pd, write_samp, dims_out, safe_r2, aux_delta_, aux_pupil_, enqueue);
           hipLaunchKernelGGL(k_raygen_aux2_f32, dim3((total + kRgDense - 1) / kRgDense), dim3(kRgDense), 0, st_, scene_, pool_, enqueue);
           hipLaunchKernelGGL(k_rotate, dim3(1), dim3(1), 0, st_, counters_.p, 4);   // q_next was only a staging queue
         }
-        HIP_CHECK(hipGetLastError());
-        return;
-      }
-      if (raygen_pt_ && pt_ok) {
-        if (rg_grid_ == 0) {
-          int per_cu = 0, cus = 0;
-          HIP_CHECK(hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, dev_));
-          HIP_CHECK(hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu, k_raygen_pt_f32, kRgBlock, 0));
-          rg_grid_ = (uint32_t)(std::max(1, per_cu) * std::max(1, cus));
-        }
-        const uint32_t total = pd.npix * pd.ns;
-        const uint32_t g = std::max(1u, std::min((total + kRgBlock - 1) / kRgBlock, rg_grid_));
-        if (pix_off_.n < 2 * (size_t)pd.npix) { HIP_CHECK(hipStreamSynchronize(st_)); pix_off_.alloc(2 * (size_t)pd.npix); }
-        pool_.pix_off = pix_off_.p;
-        hipLaunchKernelGGL(k_pixel_offsets, dim3((pd.npix + kBlock - 1) / kBlock), dim3(kBlock), 0, st_, scene_, pool_, pd);
-        hipLaunchKernelGGL(k_sample_f32, dim3((pd.npix + kBlock - 1) / kBlock, pd.ns), dim3(kBlock), 0, st_, scene_, pool_, pd, dims_out);
-        hipLaunchKernelGGL(k_raygen_pt_f32, dim3(g), dim3(kRgBlock), 0, st_, scene_, pool_, pd, &counters_.p[C_WORK_AUX]);
-        const uint32_t n_cw = (total + 64u * kCompactRun - 1) / (64u * kCompactRun);   // waves
-        hipLaunchKernelGGL(k_compact_alive, dim3((n_cw * 64u + kBlock - 1) / kBlock), dim3(kBlock), 0, st_, pool_, total);
-        hipLaunchKernelGGL(k_raygen_aux_f32, dim3((total + kRgBlock - 1) / kRgBlock), dim3(kRgBlock), 0, st_, scene_, pool_, enqueue);
-        hipLaunchKernelGGL(k_rotate, dim3(1), dim3(1), 0, st_, counters_.p, 4);   // q_next was only a staging queue
         HIP_CHECK(hipGetLastError());
         return;
       }
@@ -1427,7 +1437,7 @@ class Handle : public HandleBase {
         pairs.swap(re);
       } else trav_.n_treelet = 0;
       // any-hit start lists (TravScene::any_list): per triangle, the pair nodes between the root and its leaf whose OFF-path child is within
-      // reach of a shadow ray (1 - 1e-4 long, Q9; 1.02 with room for the fp32 box rounding, the test's widening and |d| = 1 +- 1e-6), top down,
+      // reach of a shadow ray (kShadowTmax long, Q9; + 0.02 + 8 ulp of the largest scene coordinate, see `reach` below), top down,
       // at most kAnyList of them; the ordinary walk resumes at the next such node (or at the leaf itself when the list holds them all).
       std::vector<uint32_t> lists;
       if (n_int > 0 && (nodes[0].meta >> 2) == 0) {
@@ -1445,7 +1455,14 @@ class Handle : public HandleBase {
           for (int k = 0; k < 3; k++) { const double g = std::max(0.0, std::max((double)a.bmin[k] - (double)b.bmax[k], (double)b.bmin[k] - (double)a.bmax[k])); d2 += g * g; }
           return d2;
         };
-        const double reach2 = 1.02 * 1.02;
+        // Reach of a pool shadow ray from its triangle's leaf box: its length kShadowTmax, 0.02 for what the fp32 evaluation adds relative
+        // to it (|d| = 1 +- 1e-6, the boxes' outward rounding, the slab test's widening factor g), plus what is ABSOLUTE in world units: the
+        // ray's fp32 origin word lies within an ulp of its triangle - hence of the leaf box - and the plane distances are differences of
+        // coordinates of the size M = the largest root-box coordinate: 8 ulp(M). At coordinates of 1e5 that is 0.06, not covered by 0.02.
+        double coord_max = 0.0;
+        for (int k = 0; k < 3; k++) coord_max = std::max(coord_max, std::max(std::fabs((double)nodes[0].bmin[k]), std::fabs((double)nodes[0].bmax[k])));
+        const double reach = (double)kShadowTmax + 0.02 + 8.0 * coord_max * 1.1920929e-7;
+        const double reach2 = reach * reach;
         // iterative pre-order walk carrying the path of interior nodes from the root to the current node's parent
         struct Step { uint32_t node; uint32_t depth; };
         std::vector<uint32_t> path;

@@ -814,6 +814,16 @@ size_t rrt_scene_warning_count(const rrt_scene* s) { return s ? s->data.warnings
 const char* rrt_scene_warning(const rrt_scene* s, size_t i) { return (s && i < s->data.warnings.size()) ? s->data.warnings[i].c_str() : nullptr; }
 
 const char* rrt_last_error(void) { return last_error_cstr(); }
-const char* rrt_version(void) { return "rs_ray_toy_amd 0.1 (abi 1, gfx950)"; }
+int rrt_scene_film(const rrt_scene* s, int32_t* xres, int32_t* yres, double* scale) {
+  if (!s) { set_last_error("rrt_scene_film: null scene"); return RRT_EINVAL; }
+  if (xres) *xres = s->data.desc.film.xres;
+  if (yres) *yres = s->data.desc.film.yres;
+  if (scale) *scale = s->data.desc.film.scale;
+  return RRT_OK;
+}
+
+#define RRT_STR2(x) #x
+#define RRT_STR(x) RRT_STR2(x)
+const char* rrt_version(void) { return "rs_ray_toy_amd 0.3 (abi " RRT_STR(RRT_ABI_VERSION) ", gfx950)"; }
 
 }  // extern "C"

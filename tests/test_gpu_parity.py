@@ -5,11 +5,12 @@ bit-exact in f64 mode; floating point within the tolerance written next to each 
 path is held to statistical closeness because a path's discrete decisions (which triangle, which lobe,
 roulette) flip for O(1e-5) of samples under fp32 rounding.
 
-The device flattens rigid instances to world space (the reference transforms the ray per primitive). The two
-evaluations agree except on exact ties (a hit on a face coplanar with a flat leaf box: gap of ~1e-16), which
-each breaks by its own last-bit rounding. The f64 device mode is therefore compared bit-for-bit with the
-oracle's flat=True evaluation; tests/test_oracle.py bounds how often flat and per-primitive evaluation differ
-and shows that every such ray is a tie.
+The reference transforms the ray per primitive (TransformedPrimitive, primitives.rs:115-139). The f64 device mode replays exactly
+that for every instance (RRT_INSTANCES_KEEP is its default) and is compared bit-for-bit with the oracle's reference-order
+evaluation. The fp32 product flattens rigid instances to world space; the two evaluations agree except on exact ties (a hit on a
+face coplanar with a flat leaf box: gap of ~1e-16), which each breaks by its own last-bit rounding - tests/test_oracle.py bounds how
+often they differ and shows that every such ray is a tie, and test_flattened_f64_matches_the_flat_oracle holds the flattened
+evaluation (RRT_INSTANCES_FLATTEN in f64) to the oracle's flat=True one bit for bit.
 """
 import os
 
@@ -17,7 +18,8 @@ import numpy as np
 import pytest
 
 import oracle_lib as O
-from rs_ray_toy_amd import RRT_F32, RRT_F64, RRT_FIXED_BVH, Renderer, RrtPanic, RrtUnsupported, Scene, scenes
+from rs_ray_toy_amd import (RRT_F32, RRT_F64, RRT_FIXED_BVH, RRT_INSTANCES_FLATTEN, RRT_INSTANCES_KEEP, Renderer, RrtPanic, RrtUnsupported,
+                            Scene, scenes)
 
 pytestmark = pytest.mark.gpu
 
@@ -51,7 +53,7 @@ def _rays_for(scene, n, seed):
 def test_trace_closest_f64_exact(which, cfg2_scene, hf_scene):
     sc = cfg2_scene if which == "cfg2" else hf_scene
     o, d, tmax, _ = _rays_for(sc, 4096, 11)
-    ref = O.trace_closest(sc, o, d, tmax, flat=True)
+    ref = O.trace_closest(sc, o, d, tmax)
     r = Renderer(sc, 0, RRT_F64)
     got = r.trace_closest(o, d, tmax, counters=True)
     r.close()
@@ -63,6 +65,45 @@ def test_trace_closest_f64_exact(which, cfg2_scene, hf_scene):
     # same operation order, IEEE f64 add/mul/div only, no FMA contraction on either side: bit-exact
     assert np.array_equal(got["t"], ref["t"])
     assert np.array_equal(got["u"][hit], ref["u"][hit]) and np.array_equal(got["v"][hit], ref["v"][hit])
+
+
+def test_flattened_f64_matches_the_flat_oracle(cfg2_scene, workdir):
+    """RRT_INSTANCES_FLATTEN in the f64 mode = the evaluation the fp32 product uses (rigid instances moved to world space once), held to
+    the oracle's flat=True evaluation bit for bit: rays (winner, t, u, v, counters, occlusion) and a frame."""
+    sc = cfg2_scene
+    o, d, tmax, _ = _rays_for(sc, 4096, 11)
+    ref = O.trace_closest(sc, o, d, tmax, flat=True)
+    r = Renderer(sc, 0, RRT_F64, flags=RRT_INSTANCES_FLATTEN)
+    got = r.trace_closest(o, d, tmax, counters=True)
+    occ = r.trace_any(o, d, np.full(len(tmax), 1.0 - 1e-4))
+    film = r.render()
+    r.close()
+    hit = ref["prim"] >= 0
+    assert np.array_equal(got["prim"], ref["prim"]) and np.array_equal(got["nodes"], ref["nodes"]) and np.array_equal(got["prims"], ref["prims"])
+    assert np.array_equal(got["t"], ref["t"]) and np.array_equal(got["u"][hit], ref["u"][hit]) and np.array_equal(got["v"][hit], ref["v"][hit])
+    assert np.array_equal(occ, O.trace_any(sc, o, d, np.full(len(tmax), 1.0 - 1e-4), flat=True)["occluded"])
+    ref_film = O.render(sc, flat=True)
+    assert np.array_equal(film[..., 3], ref_film[..., 3])
+    diff = np.abs(film[..., :3] - ref_film[..., :3]).max(-1) / np.abs(ref_film[..., :3]).max()
+    assert (diff > 1e-9).mean() < 0.005, (diff > 1e-9).mean()
+
+
+def test_kept_instances_fp32(workdir):
+    """RRT_INSTANCES_KEEP in the fp32 mode: every instance through the per-primitive ray transform (the reference's order) on the generic
+    kernels, against the oracle's reference-order evaluation within the fp32 bar (tilted cubes: no exact ties)."""
+    cfg, root = scenes.cfg2(workdir, xres=64, yres=64, nsamp=9, max_depth=4)
+    for inst in cfg["Aggregate"]["primitives"][0]["instances"]:
+        inst["rotation_axis"] = [1.0, 2.0, 3.0]
+    sc = Scene.loads(cfg, root)
+    ref = O.render(sc)
+    r = Renderer(sc, 0, RRT_F32, flags=RRT_INSTANCES_KEEP)
+    film = r.render().astype(np.float64)
+    r.close()
+    assert np.array_equal(film[..., 3], ref[..., 3])
+    diff = np.abs(film[..., :3] - ref[..., :3]).max(-1) / np.abs(ref[..., :3]).max()
+    assert (diff < 1e-4).mean() > 0.99 and np.median(diff) < 1e-5, ((diff < 1e-4).mean(), np.median(diff))
+    with pytest.raises(Exception):
+        Renderer(sc, 0, RRT_F32, flags=RRT_INSTANCES_KEEP | RRT_INSTANCES_FLATTEN)
 
 
 @pytest.mark.parametrize("which", ["cfg2", "hf"])
@@ -113,7 +154,7 @@ def test_trace_any(prec, hf_scene):
     sc = hf_scene
     o, d, tmax, skip = _rays_for(sc, 4096, 23)
     tmax = np.full(len(tmax), 1.0 - 1e-4)                      # shadow rays keep t_max = 1 - SHADOW_EPSILON (Q9)
-    ref = O.trace_any(sc, o, d, tmax, flat=True)
+    ref = O.trace_any(sc, o, d, tmax)
     r = Renderer(sc, 0, prec)
     got = r.trace_any(o, d, tmax, skip_prim=skip if prec == RRT_F32 else None)
     r.close()
@@ -186,7 +227,7 @@ TIE_PRONE = ("cfg2_path", "cfg3_literal")
 def test_render_f64_matches_oracle(case, workdir):
     cfg, root = RENDER_CASES[case](workdir)
     sc = Scene.loads(cfg, root, flags=RRT_FIXED_BVH if "cfg4" in case or "cfg5" in case else 0)
-    ref, st_ref = O.render(sc, stats=True, flat=True)
+    ref, st_ref = O.render(sc, stats=True)
     r = Renderer(sc, 0, RRT_F64)
     film, st = r.render(stats=True)
     r.close()
@@ -306,7 +347,7 @@ def test_other_integrators(integrator, workdir):
     for inst in cfg["Aggregate"]["primitives"][0]["instances"]:
         inst["rotation_axis"] = [1.0, 2.0, 3.0]   # generic axes: no face stays axis-aligned, no box/face ties
     sc = Scene.loads(cfg, root)
-    ref = O.render(sc, flat=True)
+    ref = O.render(sc)
     r = Renderer(sc, 0, RRT_F64)
     film = r.render()
     r.close()
@@ -428,12 +469,12 @@ def test_non_rigid_triangle_instances(which, workdir):
         cfg["Aggregate"]["primitives"][0]["material_name"] = "mat_metal" if which == "path_metal" else "mat_plastic"
     sc = Scene.loads(cfg, root)
     o, d, tmax, _ = _rays_for(sc, 2048, 17)
-    ref_t = O.trace_closest(sc, o, d, tmax, flat=True)      # flat: rigid instances flattened like on the device, non-rigid ones per primitive
-    ref_a = O.trace_any(sc, o, d, tmax, flat=True)
+    ref_t = O.trace_closest(sc, o, d, tmax)      # flat: rigid instances flattened like on the device, non-rigid ones per primitive
+    ref_a = O.trace_any(sc, o, d, tmax)
     r = Renderer(sc, 0, RRT_F64)
     got = r.trace_closest(o, d, tmax, counters=True)
     occ = r.trace_any(o, d, tmax)
-    ref, st_ref = O.render(sc, stats=True, flat=True)
+    ref, st_ref = O.render(sc, stats=True)
     film, st = r.render(stats=True)
     r.close()
     hit = ref_t["prim"] >= 0
@@ -460,13 +501,22 @@ def test_non_rigid_triangle_instances(which, workdir):
     assert (d32 < 1e-3).mean() > 0.97 and abs(f32[..., :3].mean() / ref_o[..., :3].mean() - 1.0) < 0.02
 
 
-@pytest.mark.parametrize("which", ["cfg4", "cfg5", "cfg2", "cfg3_direct"])
+@pytest.mark.parametrize("which", ["cfg4", "cfg4_far", "cfg5", "cfg2", "cfg3_direct"])
 def test_any_hit_entry_nodes_change_nothing(which, workdir):
     """Shadow rays are 1 - 1e-4 long (Q9) and start on a triangle: the fp32 any-hit kernels start them at the first ancestor of that
     triangle's leaf whose other child is within reach, instead of at the root (TravScene::any_entry) - every ancestor contains the origin
     and passes its box test, every skipped sibling is more than a unit away and fails it, and an occlusion query does not depend on the
     order. Bar: frames with and without the shortcut are identical bit for bit, query counts included."""
     if which == "cfg4": cfg, root = scenes.cfg4(workdir, xres=128, yres=128, nsamp=9, max_depth=6, n=96)
+    elif which == "cfg4_far":
+        # the scene 1e5 units from the origin (an instance translation; camera moved along): fp32 coordinates there have an ulp of 0.008, which
+        # the lists' reach must cover on top of the ray length (rrt_impl.hpp build_pairs(): 8 ulp of the largest coordinate)
+        cfg, root = scenes.cfg4(workdir, xres=128, yres=128, nsamp=9, max_depth=6, n=96)
+        far = np.array([1.0e5, -7.0e4, 3.0e4])
+        cfg["Aggregate"]["primitives"][0]["instances"] = [{"world_pos": list(far)}]
+        cfg["Camera"]["world_pos"] = list(np.array(cfg["Camera"]["world_pos"], float) + far)
+        cfg["Camera"]["look"] = list(np.array(cfg["Camera"]["look"], float) + far)
+        cfg["lights"] = [{"light_type": "distant", "l": {"values": [3.0, 2.5, 2.0]}, "from": [20.0, 30.0, 10.0], "to": [35.0, 0.0, 0.0]}]
     elif which == "cfg5": cfg, root = scenes.cfg5(workdir, xres=96, yres=96, nsamp=9, max_depth=6, n=64)
     elif which == "cfg2": cfg, root = scenes.cfg2(workdir, xres=128, yres=128, nsamp=9, max_depth=4)
     else:
@@ -540,6 +590,27 @@ AUX_CASES = {
     "cfg3_wide_filter": lambda wd: (lambda c: (c[0]["Film"].__setitem__("Filter", {"filter_type": "TriangleFilter", "radius": [2.0, 2.0]}), c)[1])(
         scenes.cfg3(wd, xres=200, yres=120, nsamp=9)),
 }
+
+
+def _random_lens(seed):
+    """scene.json's double Gauss with every radius, thickness and aperture perturbed (+-15 / 20 / 30 %), a random stop and focus distance: the
+    margins of calibrate_aux_margins() are a calibrated heuristic (16x the displacement measured over 16 384 host samples of THIS lens, not a
+    proven bound), so they are validated on prescriptions nobody tuned them on - rims and near-critical interfaces move with the prescription."""
+    def make(wd):
+        rng = np.random.default_rng(seed)
+        cfg, root = scenes.cfg2(wd, xres=256, yres=160, nsamp=9, max_depth=2)
+        ld = np.array(scenes.LENS_DATA, float).reshape(-1, 4)
+        ld[:, 0] *= rng.uniform(0.85, 1.15, len(ld))
+        ld[:, 1] *= rng.uniform(0.8, 1.2, len(ld))
+        ld[:, 3] *= rng.uniform(0.7, 1.1, len(ld))
+        cfg["Camera"]["lens_data"] = [float(x) for x in ld.reshape(-1)]
+        cfg["Camera"]["aperture_diameter"] = float(rng.uniform(8.0, 50.0))
+        cfg["Camera"]["focus_distance"] = float(rng.uniform(10.0, 60.0))
+        return cfg, root
+    return make
+
+
+AUX_CASES.update({f"random_lens_{seed}": _random_lens(seed) for seed in range(1, 9)})
 
 
 @pytest.mark.parametrize("which", sorted(AUX_CASES))
@@ -616,7 +687,7 @@ def test_wide_filters(which, workdir):
     cfg, root = scenes.cfg4(workdir, xres=48, yres=40, nsamp=5, max_depth=3, n=24)
     cfg["Film"]["Filter"] = WIDE_FILTERS[which]
     sc = Scene.loads(cfg, root, flags=RRT_FIXED_BVH)
-    ref = O.render(sc, flat=True)
+    ref = O.render(sc)
     scale = np.abs(ref[..., :3]).max()
     assert scale > 0 and ref[..., 3].min() > 0
     r = Renderer(sc, 0, RRT_F64)
@@ -682,7 +753,7 @@ def test_transmissive_materials_path(which, workdir):
     sc = Scene.loads(cfg, root)
     m = sc.desc.materials[sc.desc.prims[0].material]
     assert m.type in (5, 6) and (which != "glass" or (list(m.kt) == [0.8, 0.9, 1.0] and m.index == 1.5))
-    ref, st_ref = O.render(sc, stats=True, flat=True)
+    ref, st_ref = O.render(sc, stats=True)
     assert ref[..., :3].max() > 0
     r = Renderer(sc, 0, RRT_F64)
     film, st = r.render(stats=True)
@@ -715,7 +786,7 @@ def test_transmissive_materials_direct(which, workdir):
     _with_material(cfg, "mat_t", TRANSMISSIVE[mat])
     cfg["Aggregate"]["primitives"][0]["material_name"] = "mat_t"
     sc = Scene.loads(cfg, root)
-    ref, st_ref = O.render(sc, stats=True, flat=True)
+    ref, st_ref = O.render(sc, stats=True)
     assert ref[..., :3].max() > 0
     if mat == "glass":   # the recursion really runs: specular children were traced
         assert st_ref.closest_queries > st_ref.camera_rays
@@ -731,6 +802,39 @@ def test_transmissive_materials_direct(which, workdir):
     r.close()
     d32 = np.abs(f32[..., :3] - ref[..., :3]).max(-1) / np.abs(ref[..., :3]).max()
     assert (d32 < 1e-4).mean() > 0.99 and np.median(d32) < 1e-5, ((d32 < 1e-4).mean(), d32.max())
+
+
+def test_deep_direct_trees_use_the_overflow_frames(workdir):
+    """DirectLighting in a mirror-walled enclosure around a matte and a glass cube at max_depth 22: every camera sample's recursion (k_direct_tree, taken
+    because of the glass) is a mirror chain deeper than the 16 frames a thread keeps privately, so the deeper frames live in the strided
+    global array. Same tree, same sampler dimensions, same query counts as the oracle's recursion (integrator/mod.rs:150-301)."""
+    cfg, root = _cfg3_tilted(workdir)
+    cfg["Film"]["xres"], cfg["Film"]["yres"] = 40, 40
+    cfg["Sampler"]["nsamp"] = 5
+    cfg["Integrator"] = {"integrator_type": "DirectLighting", "light_strategy": "one", "max_depth": 22}
+    _with_material(cfg, "mat_t", TRANSMISSIVE["glass"])
+    _with_material(cfg, "mat_m", ("MirrorMaterial", {"kr": [0.95, 0.9, 0.85]}, {}, {}))
+    import copy
+    cube, box = cfg["Aggregate"]["primitives"]                    # the matte cube is what the light reaches; the walls are mirrors
+    box["material_name"] = "mat_m"
+    glass = copy.deepcopy(cube)
+    glass["material_name"] = "mat_t"
+    glass["instances"] = [{"world_pos": [33.0, 1.5, 1.0], "rotation_axis": [2.0, 1.0, 3.0], "rotation_angle": 25}]
+    cfg["Aggregate"]["primitives"].append(glass)
+    sc = Scene.loads(cfg, root)
+    ref, st_ref = O.render(sc, stats=True)
+    assert ref[..., :3].max() > 0 and st_ref.closest_queries > 18 * st_ref.camera_rays      # chains beyond 16 levels
+    for prec in (RRT_F64, RRT_F32):
+        r = Renderer(sc, 0, prec)
+        film, st = r.render(stats=True)
+        r.close()
+        assert np.array_equal(film[..., 3].astype(np.float64), ref[..., 3])
+        diff = np.abs(film[..., :3].astype(np.float64) - ref[..., :3]).max(-1) / np.abs(ref[..., :3]).max()
+        if prec == RRT_F64:
+            assert (st.camera_rays, st.closest_queries, st.any_queries) == (st_ref.camera_rays, st_ref.closest_queries, st_ref.any_queries)
+            assert diff.max() < 1e-9, diff.max()
+        else:
+            assert (diff < 1e-4).mean() > 0.98 and np.median(diff) < 1e-5, ((diff < 1e-4).mean(), diff.max())
 
 
 @pytest.mark.parametrize("which", ["dims4_jitter", "dims20_nojitter", "golden_scene_json"])
@@ -751,7 +855,7 @@ def test_stratified_sampler(which, workdir):
         sc = Scene.loads(cfg, root, flags=RRT_FIXED_BVH)
         rect = (0, 0, 48, 40)
     assert sc.desc.sampler.type == 1
-    ref, st_ref = O.render(sc, rect, stats=True, flat=True)
+    ref, st_ref = O.render(sc, rect, stats=True)
     r = Renderer(sc, 0, RRT_F64)
     dims, rays, w = r.camera_samples(rect, 1, 4)
     rdims, rrays, rw = O.camera_samples(sc, rect, 1, 4)
@@ -800,7 +904,7 @@ def test_sphere_primitives_trace_f64_exact(workdir):
     sc = Scene.loads(cfg, root, flags=RRT_FIXED_BVH)
     assert sc.desc.n_spheres >= 4
     o, d, tmax = O.random_rays(sc, 20000, 77)
-    ref = O.trace_closest(sc, o, d, tmax, flat=True)
+    ref = O.trace_closest(sc, o, d, tmax)
     assert (ref["prim"] >= 0).mean() > 0.2
     r = Renderer(sc, 0, RRT_F64)
     got = r.trace_closest(o, d, tmax, counters=True)
@@ -809,7 +913,7 @@ def test_sphere_primitives_trace_f64_exact(workdir):
     assert np.array_equal(got["t"][hit], ref["t"][hit])
     assert np.array_equal(got["nodes"], ref["nodes"]) and np.array_equal(got["prims"], ref["prims"])
     tm = np.full(len(o), 1.0 - 1e-4)
-    ref_any = O.trace_any(sc, o, d, tm, flat=True)
+    ref_any = O.trace_any(sc, o, d, tm)
     got_any = r.trace_any(o, d, tm)
     assert np.array_equal(np.asarray(got_any).astype(bool), ref_any["occluded"])
     r.close()
@@ -834,7 +938,7 @@ def test_sphere_primitives_render(which, workdir):
         cfg, root = _sphere_zoo(workdir, integ)
         flags = RRT_FIXED_BVH
     sc = Scene.loads(cfg, root, flags=flags)
-    ref, st_ref = O.render(sc, stats=True, flat=True)
+    ref, st_ref = O.render(sc, stats=True)
     assert ref[..., :3].max() > 0
     r = Renderer(sc, 0, RRT_F64)
     film, st = r.render(stats=True)
@@ -916,7 +1020,7 @@ def test_fp32_difference_found_by_the_fuzz_sweep_is_one_sample_on_a_shared_edge(
     r64 = Renderer(sc, 0, RRT_F64)
     f64 = r64.render()
     r64.close()
-    assert (np.abs(f64[..., :3] - O.render(sc, flat=True)[..., :3]).max() / scale) < 1e-9
+    assert (np.abs(f64[..., :3] - O.render(sc)[..., :3]).max() / scale) < 1e-9
     r = Renderer(sc, 0, RRT_F32)
     f32 = r.render().astype(np.float64)
     d32 = np.abs(f32[..., :3] - ref[..., :3]).max(-1) / scale
@@ -1098,7 +1202,7 @@ def test_textured_materials(which, workdir):
     cfg, root = _tex_case(which, workdir)
     sc = Scene.loads(cfg, root)
     assert sc.desc.n_textures > 0 and any(t >= 0 for m in sc.desc.materials[:sc.desc.n_materials] for t in list(m.tex) + [m.bump])
-    ref, st_ref = O.render(sc, stats=True, flat=True)
+    ref, st_ref = O.render(sc, stats=True)
     assert ref[..., :3].max() > 0
     r = Renderer(sc, 0, RRT_F64)
     film, st = r.render(stats=True)
@@ -1162,7 +1266,7 @@ def test_textured_scene_across_features(which, workdir):
         cfg["Sampler"] = {"sampler_type": "StratifiedSampler", "xsamp": 3, "ysamp": 3, "jitter": True, "dimension": 6}
         cfg["Film"]["Filter"] = {"filter_type": "GaussianFilter", "radius": [1.5, 1.5], "alpha": 1.0}
     sc = Scene.loads(cfg, root)
-    ref = O.render(sc, flat=True)
+    ref = O.render(sc)
     scale = np.abs(ref[..., :3]).max()
     if which == "stratified_gaussian_passes":
         for prec, tol in ((RRT_F64, 1e-9), (RRT_F32, 1e-4)):
@@ -1264,7 +1368,7 @@ def test_stratified_dimension_counters_overflow_is_refused(workdir):
     r.close()
     cfg["Integrator"]["max_depth"] = 3          # a shallow tree stays within the counters and matches the oracle
     sc = Scene.loads(cfg, root)
-    ref = O.render(sc, flat=True)
+    ref = O.render(sc)
     r = Renderer(sc, 0, RRT_F64)
     film = r.render()
     r.close()
@@ -1278,7 +1382,7 @@ def test_edge_configurations_found_by_the_sweeps(workdir):
     cfg, root = _cfg3_tilted(workdir)
     cfg["Film"]["Filter"] = {"filter_type": "BoxFilter", "radius": [0.2, 0.35]}
     sc = Scene.loads(cfg, root)
-    ref = O.render(sc, flat=True)
+    ref = O.render(sc)
     assert ref[..., 3].min() < 3 * 4 and ref[..., 3].max() <= 3 * 4      # fewer than the 4 samples reach some pixels
     for prec, tol in ((RRT_F64, 1e-9), (RRT_F32, 1e-4)):
         r = Renderer(sc, 0, prec)

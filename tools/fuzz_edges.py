@@ -61,7 +61,7 @@ for name, make in CASES.items():
         print(f"load refused  {name}: {str(e)[:90]}"); continue
     for rect in (None, RECTS.get(name)):
         if rect is None and name in RECTS and False: continue
-        try: ref, oe = O.render(sc, rect, flat=True), None
+        try: ref, oe = O.render(sc, rect), None   # reference order: the f64 device mode keeps every instance
         except O.OracleError as e: ref, oe = None, str(e)
         for prec, pname in ((RRT_F64, "f64"), (RRT_F32, "f32")):
             try:

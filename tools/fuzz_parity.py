@@ -142,7 +142,7 @@ for case in range(n_cases):
         with open(os.path.join(wd, "scene.json"), "w") as fjs: json.dump(cfg, fjs)
         print("scene written to", wd, "flags", "fixed-bvh" if sc.desc.flags & 3 else "compat-bvh")
     try:
-        ref = O.render(sc, rect, flat=True)
+        ref = O.render(sc, rect, flat=F32)   # f64 device mode: the reference's per-primitive order; fp32 product: rigid instances flattened
         o_err = None
     except O.OracleError as e:
         ref, o_err = None, str(e)
