@@ -4,12 +4,14 @@
 One "step" = one full frame of BASELINE config 4 (procedural 100 352-triangle heightfield, Path integrator
 max_depth 8, HaltonSampler nsamp 257 = 256 effective spp, RealisticCamera) rendered by the HIP wavefront path.
 With N > 1 ranks (torchrun, one process per GPU) the film is partitioned into interleaved 16-row bands, every
-rank renders its bands into a device film, and one RCCL reduce over xGMI reassembles the image on rank 0
-(bands are disjoint, so the sum is a gather); that collective is inside the timed region. Total work is fixed:
-strong scaling.
+rank renders its bands into a device film, and ONE collective per frame reassembles the image on rank 0: the
+product's own rrt_film_gather (C ABI, rs_ray_toy_amd/csrc/device/rrt_comm.hip: grouped ncclSend / ncclRecv of the
+band rows over xGMI, enqueued on the frame's stream) on an rrt_comm whose id rank 0 broadcasts through
+torch.distributed; `--dist-backend gloo` (rehearsal with more ranks than GPUs) keeps torch.distributed.reduce.
+The collective is inside the timed region. Total work is fixed: strong scaling.
 
 Inputs are resident in HBM before the timed region (scene upload + pool allocation happen in setup/warm-up).
-The JSON line carries `roofline` for the dominant kernel (k_closest: BVH traversal + triangle tests) and
+The JSON line carries `roofline` for the dominant kernel (closest-hit BVH traversal + triangle tests) and
 `cpu_baseline` (the f64 oracle on the host cores, bounded sample, rank 0 at N=1 only).
 """
 import argparse
@@ -120,7 +122,8 @@ def main():
     import torch.distributed as dist
 
     from rs_ray_toy_amd import RRT_F32, RRT_FIXED_BVH, Renderer, RrtError, Scene, scenes
-    from rs_ray_toy_amd.partition import band_rects, reduce_film
+    from rs_ray_toy_amd.api import Comm
+    from rs_ray_toy_amd.partition import reduce_film
 
     rank = int(os.environ.get("RANK", "0"))
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
@@ -162,37 +165,51 @@ def main():
     r = handles[0]
     films = [torch.zeros((H, W, 4), dtype=torch.float32, device=f"cuda:{local_rank}") for _ in range(nfl)]
     film = films[0]
+    # The frame's one collective. RCCL ranks: the product's rrt_film_gather on an rrt_comm (ncclCommInitRank behind the C ABI; the id travels
+    # from rank 0 through torch.distributed). gloo rehearsal (ranks may share a GPU, which RCCL does not allow): torch.distributed.reduce.
+    comm = None
+    collective = "none (one rank)"
+    if world > 1 and args.dist_backend == "nccl":
+        ident = torch.zeros(128, dtype=torch.uint8, device=f"cuda:{local_rank}")
+        if rank == 0:
+            ident = torch.tensor(list(Comm.new_id()), dtype=torch.uint8, device=f"cuda:{local_rank}")
+        dist.broadcast(ident, 0)
+        comm = Comm(bytes(ident.cpu().tolist()), rank, world, local_rank)
+        collective = "rrt_film_gather (C ABI: grouped ncclSend/ncclRecv of the band rows to rank 0 over RCCL, on the frame's stream)"
+    elif world > 1:
+        collective = "torch.distributed.reduce over gloo (rehearsal: ranks may share a device)"
+
+    def frame_begin(k):
+        """Enqueue one frame on handle k: this rank's bands into films[k], then (RCCL ranks) the gather to rank 0 on the same stream."""
+        films[k].zero_()                              # (ordered after that film's previous use on torch's stream)
+        torch.cuda.current_stream().synchronize()     # the handle's streams do not wait for torch's stream
+        handles[k].render_bands_begin(rank, world, films[k].data_ptr())
+        if comm is not None:
+            comm.gather(handles[k], films[k].data_ptr(), 0)
+
+    def frame_end(k):
+        st = handles[k].render_end(stats=True)        # waits for the frame and, behind it on the stream, the gather
+        if world > 1 and comm is None:
+            reduce_film(films[k], world)              # gloo: disjoint bands, the sum reassembles the frame on rank 0
+        return {kk: getattr(st, kk) for kk, _ in st._fields_}
 
     def step(collect=False):
-        film.zero_()
-        torch.cuda.current_stream().synchronize()
-        st = r.render_bands_device(rank, world, film.data_ptr(), stats=collect)
-        agg = {k: getattr(st, k) for k, _ in st._fields_} if collect else None
-        reduce_film(film, world)  # disjoint bands: the sum reassembles the frame on rank 0 (RCCL over xGMI)
-        return agg
+        frame_begin(0)
+        agg = frame_end(0)
+        return agg if collect else None
 
     frame_log = []   # per-frame statistics of the frames run_frames() completed (kernel timings: HIP events on the handle's streams)
 
     def run_frames(n):
         """n frames (steps), at most `nfl` in flight: frame i renders on handle i % nfl while frame i - 1 finishes on the other one;
         each frame ends with its film reduced to rank 0, all inside the caller's timed region."""
-        if nfl == 1:
-            for _ in range(n):
-                frame_log.append(step(collect=True))
-            return
-        def end(k):
-            st = handles[k].render_end(stats=True)
-            frame_log.append({kk: getattr(st, kk) for kk, _ in st._fields_})
-            reduce_film(films[k], world)
         for i in range(n):
             k = i % nfl
             if i >= nfl:
-                end(k)
-            films[k].zero_()                              # (ordered after that film's previous reduce on torch's stream)
-            torch.cuda.current_stream().synchronize()     # the handle's streams do not wait for torch's stream
-            handles[k].render_bands_begin(rank, world, films[k].data_ptr())
+                frame_log.append(frame_end(k))
+            frame_begin(k)
         for i in range(max(0, n - nfl), n):
-            end(i % nfl)
+            frame_log.append(frame_end(i % nfl))
 
     def sync():
         torch.cuda.synchronize()
@@ -213,7 +230,7 @@ def main():
             for k in range(nfl):
                 films[k].zero_()
                 torch.cuda.current_stream().synchronize()
-                handles[k].render_bands_begin(rank, world, films[k].data_ptr())
+                handles[k].render_bands_begin(rank, world, films[k].data_ptr())   # (no collective here: see above)
                 handles[k].render_end()
         except RrtError as e:
             print(f"[rank {rank}] {nfl} frames in flight not possible here ({e})", file=sys.stderr)
@@ -291,9 +308,11 @@ def main():
         launch_s = ms_closest * 1e-3 / (n_launch / world) if ms_closest > 0 else float("inf")
         achieved = (bytes_closest / n_launch) / launch_s / 1e9
         # `traffic`: fabric-side bytes per launch from the committed PMC passes of this same workload and this same device code
-        # (tools/profile_round.sh: separate --pmc FETCH_SIZE / WRITE_SIZE runs, x1024, reads x2 per the gfx950 note; Infinity-Cache hits
-        # are included). A file measured on other kernel sources is ignored (null) rather than quoted stale.
+        # (tools/profile_round.sh: separate --pmc FETCH_SIZE / WRITE_SIZE runs, x1024; reads x the factor calibrated on a known-byte
+        # 64-B-node gather, tools/micro/fetch_calib.hip -> profiles/r3_fetch_calibration.txt; Infinity-Cache hits are included). A file
+        # measured on other kernel sources is ignored (null) rather than quoted stale.
         traffic = lane_util = tcp_acc = tcp_insts = None
+        pmc_fetch_factor = (None, None)
         if args.res == 1024 and args.spp == 256 and args.depth == 8 and world == 1:
             import glob
             src = kernel_source_hash()
@@ -302,36 +321,52 @@ def main():
                     j = json.load(f)
                 if j.get("source_hash") == src:
                     traffic = round(j["closest"]["hbm_bytes"] / n_launch, 1)
+                    pmc_fetch_factor = (j.get("fetch_size_factor"), j.get("fetch_size_factor_source"))
                     lane_util = j.get("closest", {}).get("valu_lane_util")
                     tcp_acc = j.get("closest", {}).get("tcp_accesses")
                     tcp_insts = j.get("closest", {}).get("vmem_rd_insts")
                     break
-        # What can actually bind this kernel: the 11 MB BVH is served by L2 / Infinity Cache, so the bytes above never reach HBM
-        # (hbm_frac); what it does is gather one 64-B pair-node line per two nodes and one 48-B triangle per test, per lane.
+        # What binds this kernel. The 11 MB BVH is served by the LDS treelet, the vector L1, the L2 and the Infinity Cache, so SURVEY 8d's byte
+        # model (every node / triangle a ray touches priced as an HBM byte) is no bandwidth at all - it came out above the HBM peak - and the
+        # HBM position is an order of magnitude lower (`hbm`). What the kernel does per lane is GATHER: one 64-B pair-node line per two nodes
+        # visited, one 48-B triangle per test, 48 B of ray + hit records per query. The ceiling that applies is the guide's row-gather rate out
+        # of the XCD's L2 (MI355X_MICROARCH.md "Indexed rows: gather": 16.8-18.8 TB/s chip-wide; Infinity-Cache-resident rows: 8.6 TB/s).
         gather_bytes = 64.0 * tot["closest_nodes"] / 2.0 + 48.0 * tot["closest_prims"] + 48.0 * tot["closest_queries"]
         gather = (gather_bytes / n_launch) / launch_s / 1e9
-        roofline = {"kernel": "k_trace_pt_f32<false> + k_trace_pairs_f32<false> (closest-hit BVH traversal, one pair per bounce)", "bound": "hbm",
-                    "achieved": round(achieved, 2), "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": round(achieved / HBM_PEAK_GBS, 4), "traffic": traffic,
-                    "algorithmic_bytes_per_launch": round(bytes_closest / n_launch, 1),
+        as_ran_s = mx_tot["ms_closest"] * 1e-3 * world / n_launch
+        alone_s = mx_tot["ms_closest_isolated"] * 1e-3 * world / n_launch
+        fetch_factor = fetch_src = None
+        if traffic is not None:
+            fetch_factor, fetch_src = pmc_fetch_factor
+        roofline = {"kernel": "k_trace_pt_f32<false> + k_trace_pairs_f32<false> (closest-hit BVH traversal, one pair per bounce)",
+                    "bound": "l2_gather",
+                    "achieved": round(gather, 1), "peak": GATHER_L2_GBS, "unit": "GB/s", "frac": round(gather / GATHER_L2_GBS, 4),
+                    "traffic": traffic,
+                    "what": "gathered bytes per launch (64-B pair-node lines: nodes visited / 2; 48-B triangles tested; 48 B ray + hit record per query; exact device "
+                            "counters of a counting frame of this workload) / average launch duration, against the L2-resident row-gather rate of the guide",
+                    "gathered_bytes_per_launch": round(gather_bytes / n_launch, 1),
                     "avg_launch_ms": round(launch_s * 1e3, 4), "launches": int(n_launch),
-                    "as_ran": {"frames_in_flight": nfl, "avg_launch_ms": round(mx_tot["ms_closest"] * world / n_launch, 4),
-                               "frac": round((bytes_closest / n_launch) / (mx_tot["ms_closest"] * 1e-3 * world / n_launch) / 1e9 / HBM_PEAK_GBS, 4) if mx_tot["ms_closest"] > 0 else None},
-                    "hbm_frac": None if traffic is None else round(traffic / launch_s / 1e9 / HBM_PEAK_GBS, 4),
-                    "gather": {"achieved": round(gather, 1), "unit": "GB/s of 64-B pair-node lines + 48-B triangles + ray / hit records",
-                               "peak_l2": GATHER_L2_GBS, "peak_infinity_cache": GATHER_IC_GBS,
-                               "frac_l2": round(gather / GATHER_L2_GBS, 4), "frac_infinity_cache": round(gather / GATHER_IC_GBS, 4)},
+                    "measured": "HIP events on the handle's stream around every closest-hit launch, frames ONE AT A TIME after the timed region (shadow launches beside "
+                                "them on the second stream, as in the product): the configuration in which an event pair = rocprofv3's per-dispatch duration "
+                                "(profiles/*_kernel_stats_1flight.csv)",
+                    "frac_infinity_cache_rate": round(gather / GATHER_IC_GBS, 4), "peak_infinity_cache": GATHER_IC_GBS,
+                    # the same events inside the timed region (frames in flight share the chip: an event pair then also holds the wait for compute units)
+                    "as_ran": {"frames_in_flight": nfl, "avg_launch_ms": round(as_ran_s * 1e3, 4),
+                               "frac": round((gather_bytes / n_launch) / as_ran_s / 1e9 / GATHER_L2_GBS, 4) if as_ran_s > 0 else None},
+                    # the same launches with the shadow launches back on the main stream and one frame at a time: the kernel alone on the chip
+                    "alone": {"avg_launch_ms": round(alone_s * 1e3, 4), "frac": round((gather_bytes / n_launch) / alone_s / 1e9 / GATHER_L2_GBS, 4) if alone_s > 0 else None},
+                    # HBM position: fabric-side bytes per launch from the committed PMC passes (Infinity-Cache hits included: an upper bound of the HBM bytes)
+                    "hbm": None if traffic is None else {"bytes_per_launch": traffic, "GBps": round(traffic / launch_s / 1e9, 1), "peak": HBM_PEAK_GBS,
+                                                          "frac": round(traffic / launch_s / 1e9 / HBM_PEAK_GBS, 4), "fetch_size_factor": fetch_factor, "fetch_size_factor_source": fetch_src},
+                    # SURVEY 8d's algorithmic-byte figure, kept for the record: NOT a bandwidth (cache-resident tree), its ratio to the HBM peak is not a fraction of anything
+                    "survey_8d": {"algorithmic_bytes_per_launch": round(bytes_closest / n_launch, 1), "GBps_if_every_byte_came_from_hbm": round(achieved, 1),
+                                  "ratio_to_hbm_peak": round(achieved / HBM_PEAK_GBS, 4), "bytes_per_query": round(bytes_closest / max(1.0, tot["closest_queries"]), 1),
+                                  "note": "28 B ray + 16 B hit + 32 B per node visited + 48 B per triangle tested; not a bandwidth: the tree never leaves the caches"},
                     "valu_lane_util": lane_util,
                     # The unit this kernel keeps busiest is the CU's vector L1 (TCP): a 16-byte load whose 64 lanes read their own BVH nodes occupies
                     # it for 39 cycles (tools/micro/tcp_gather2.hip, L1 hits), 0.61 cycles per lane-level access; accesses per launch from the
                     # committed PMC pass (TCP_TOTAL_CACHE_ACCESSES). frac = TCP cycles needed / (256 CUs x launch duration x 2.4 GHz), L1 misses not priced.
-                    "l1_gather": None if tcp_acc is None else l1_gather_bound(tcp_acc / n_launch, None if tcp_insts is None else tcp_insts / n_launch, launch_s,
-                                                                               mx_tot["ms_closest_isolated"] * 1e-3 * world / n_launch),
-                    "note": "achieved / frac price every node and triangle a ray touches as an HBM byte (the SURVEY 8d definition); the BVH is cache "
-                            "resident (LDS treelet, vector L1, L2), so that figure can exceed 1 and is not a bandwidth: hbm_frac (PMC bytes) is the HBM "
-                            "position, l1_gather (lane-level vector-L1 accesses x their measured cost) the unit that binds",
-                    # the same launches with the shadow launches back on the main stream and one frame at a time: the kernel alone on the chip
-                    "alone_avg_launch_ms": round(mx_tot["ms_closest_isolated"] * world / n_launch, 4),
-                    "bytes_per_query": round(bytes_closest / max(1.0, tot["closest_queries"]), 1),
+                    "l1_gather": None if tcp_acc is None else l1_gather_bound(tcp_acc / n_launch, None if tcp_insts is None else tcp_insts / n_launch, launch_s, alone_s),
                     "nodes_per_query": round(tot["closest_nodes"] / max(1.0, tot["closest_queries"]), 2),
                     "tris_per_query": round(tot["closest_prims"] / max(1.0, tot["closest_queries"]), 2)}
         cpu = None
@@ -342,8 +377,9 @@ def main():
             "value": round(value, 3), "unit": "Mrays/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
             "ms_per_step": round(ms_per_step, 3), "higher_is_better": True, "scaling": "strong", "vs_baseline": None,
             "dtype": "f32", "data": "synthetic",
-            "config": {"workload": "BASELINE cfg4: procedural heightfield %d triangles, %dx%d, %d spp, Path max_depth %d, HaltonSampler, RealisticCamera, box filter; %s BVH; film in interleaved 16-row bands, RCCL reduce to rank 0; %d frame(s) in flight" % (
+            "config": {"workload": "BASELINE cfg4: procedural heightfield %d triangles, %dx%d, %d spp, Path max_depth %d, HaltonSampler, RealisticCamera, box filter; %s BVH; film in interleaved 16-row bands, one gather to rank 0 per frame; %d frame(s) in flight" % (
                 scene.desc.n_prims, W, H, args.spp, args.depth, "reference-exact (Q26/Q27)" if args.compat_bvh else "fixed-bvh", nfl),
+                "collective": collective, "comm_world": (comm.world if comm is not None else world),
                 "triangles": int(scene.desc.n_prims), "bvh_nodes": int(scene.desc.n_bvh_nodes), "bvh_depth": int(scene.desc.bvh_depth)},
             "roofline": roofline, "cpu_baseline": cpu,
             "camera_mrays_per_s": round(tot["camera_rays"] / (ms_per_step * 1e-3) / 1e6, 3),
@@ -355,6 +391,8 @@ def main():
             "host_scene_build_s": round(t_build, 3),
         }
         print(json.dumps(out))
+    if comm is not None:
+        comm.close()
     if world > 1:
         dist.destroy_process_group()
 

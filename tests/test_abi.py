@@ -124,6 +124,37 @@ def test_collective_entry_points_refuse_bad_arguments():
     lib.rrt_comm_destroy(None)
 
 
+def test_missing_rccl_is_a_device_error_with_a_message(tmp_path):
+    """RCCL is bound with dlopen at the first collective call (rrt_comm.hip). Where it cannot be found the call fails with RRT_EDEVICE and the
+    loader's message - in a fresh process, because the binding is resolved once per process."""
+    code = (
+        "import ctypes as C, sys\n"
+        f"sys.path.insert(0, {ROOT!r})\n"
+        "from rs_ray_toy_amd import _abi as A\n"
+        "lib = A.lib()\n"
+        "buf = (C.c_uint8 * A.RRT_COMM_ID_BYTES)()\n"
+        "rc = lib.rrt_comm_id(buf)\n"
+        "msg = lib.rrt_last_error().decode()\n"
+        "assert rc == A.RRT_EDEVICE, rc\n"
+        "assert 'RCCL not found' in msg and 'no_such_rccl' in msg, msg\n"
+        "assert lib.rrt_comm_id(buf) == A.RRT_EDEVICE\n"      # and again: the failure is remembered, not re-derived from a cleared dlerror()
+        "print('ok')\n")
+    env = dict(os.environ, RRT_RCCL_LIBRARY=str(tmp_path / "no_such_rccl.so"))
+    out = subprocess.run(["python", "-c", code], env=env, capture_output=True, text=True, timeout=300)
+    assert out.returncode == 0 and "ok" in out.stdout, out.stderr
+
+
+def test_scene_film_accessor(tmp_path):
+    from rs_ray_toy_amd import Scene, scenes
+    cfg, root = scenes.cfg2(str(tmp_path), xres=48, yres=32, nsamp=3)
+    cfg["Film"]["scale"] = 2.5
+    sc = Scene.loads(cfg, root)
+    w, h, s = C.c_int32(), C.c_int32(), C.c_double()
+    assert A.lib().rrt_scene_film(sc._h, C.byref(w), C.byref(h), C.byref(s)) == A.RRT_OK
+    assert (w.value, h.value, s.value) == (48, 32, 2.5)
+    assert A.lib().rrt_scene_film(sc._h, None, None, None) == A.RRT_OK and A.lib().rrt_scene_film(None, None, None, None) == A.RRT_EINVAL
+
+
 STRUCTS = {"rrt_xform": A.Xform, "rrt_tri": A.Tri, "rrt_sphere": A.Sphere, "rrt_prim": A.Prim, "rrt_material": A.Material, "rrt_texture": A.Texture, "rrt_image": A.Image, "rrt_image_level": A.ImageLevel,
            "rrt_light": A.Light, "rrt_bvh_node": A.BvhNode, "rrt_lens_elem": A.LensElem, "rrt_camera": A.Camera,
            "rrt_film": A.Film, "rrt_sampler": A.Sampler, "rrt_integrator": A.Integrator, "rrt_scene_desc": A.SceneDesc,

@@ -95,6 +95,43 @@ def test_rccl_collective_through_the_c_abi(workdir):
         r.close()
 
 
+@pytest.mark.parametrize("filt", [None, {"filter_type": "TriangleFilter", "radius": [2.0, 2.0]}], ids=["box", "triangle"])
+def test_film_gather_all_over_every_device_of_the_box(workdir, filt):
+    """rrt_film_gather_all over rrt_device_count() devices - 1 on this pool's boxes (nothing to send, RCCL not needed), N on a node, where
+    this is the test that runs the grouped ncclSend / ncclRecv gather (box) and the ncclReduce (wide filter) between real ranks: one handle
+    per device renders its bands, the collective reassembles the frame on device 0, and it must equal the single-handle frame. The cached
+    communicators go away with the handles (rrt_destroy)."""
+    import ctypes as C
+    from rs_ray_toy_amd import RRT_F32, Renderer, Scene, scenes
+    from rs_ray_toy_amd import _abi as A
+    n = A.lib().rrt_device_count()
+    assert n >= 1
+    cfg, root = scenes.cfg2(workdir, xres=96, yres=80, nsamp=9, max_depth=3)
+    if filt:
+        cfg["Film"]["Filter"] = filt
+    sc = Scene.loads(cfg, root)
+    W, H = sc.resolution
+    rs = [Renderer(sc, i, RRT_F32) for i in range(n)]
+    films = [torch.zeros((H, W, 4), dtype=torch.float32, device=f"cuda:{i}") for i in range(n)]
+    torch.cuda.synchronize()
+    for i in range(n):
+        rs[i].render_bands_begin(i, n, films[i].data_ptr())
+    handles = (C.c_void_p * n)(*[r._h for r in rs])
+    ptrs = (C.c_void_p * n)(*[f.data_ptr() for f in films])
+    assert A.lib().rrt_film_gather_all(handles, ptrs, n, 0) == A.RRT_OK, A.lib().rrt_last_error()
+    for i in reversed(range(n)):
+        rs[i].render_end()
+    got = films[0].cpu().numpy()
+    full = rs[0].render()
+    if filt is None or n == 1:
+        assert np.array_equal(got, full)
+    else:
+        assert np.array_equal(got[..., 3], full[..., 3])
+        np.testing.assert_allclose(got, full, rtol=2e-6, atol=1e-7 * full.max())
+    for r in rs:
+        r.close()
+
+
 def test_native_command_line_matches_the_python_host(tmp_path):
     """rrt_render <scene.json> <out.png> (main.rs:55-61 / deploy_render renderprocess.rs:92-105 in C++ over the C ABI) writes the very
     PNG the Python mirror writes, for the reference's own samples/scene.json (StratifiedSampler, Debug integrator, 640x360)."""
@@ -104,7 +141,8 @@ def test_native_command_line_matches_the_python_host(tmp_path):
     a, b = str(tmp_path / "cli.png"), str(tmp_path / "py.png")
     p = subprocess.run([exe, scene, a], capture_output=True, text=True, timeout=600)
     assert p.returncode == 0, p.stderr
-    deploy_render(scene, b)
+    _, st = deploy_render(scene, b)
+    assert p.stdout.strip() == f"{st.camera_rays} rays generated"      # integrator/mod.rs:137
     assert open(a, "rb").read() == open(b, "rb").read()
     assert subprocess.run([exe, scene], capture_output=True).returncode == 2          # usage
     q = subprocess.run([exe, str(tmp_path / "missing.json"), a], capture_output=True, text=True)

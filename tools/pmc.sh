@@ -1,5 +1,5 @@
 #!/bin/bash
-# usage: tools/pmc.sh <outdir> <program args...>   (runs separate --pmc passes; summaries via tools/pmc_summary.py)
+# usage: tools/pmc.sh <outdir> <program args...>   (runs separate --pmc passes; summaries: tools/pmc_kernels.py <outdir> and tools/pmc_traffic.py <outdir>)
 set -e
 out=$1; shift
 cd /tmp && export TMPDIR=/tmp && cd $GRAFT_REPO_ROOT
