@@ -320,8 +320,9 @@ def main():
                 with open(pmc) as f:
                     j = json.load(f)
                 if j.get("source_hash") == src:
-                    traffic = round(j["closest"]["hbm_bytes"] / n_launch, 1)
-                    pmc_fetch_factor = (j.get("fetch_size_factor"), j.get("fetch_size_factor_source"))
+                    # gathers at the calibrated x1; the coalesced ray-record reads (32 B per query) are tallied at half: + 16 B per query
+                    traffic = round((j["closest"]["hbm_bytes"] + 16.0 * tot["closest_queries"]) / n_launch, 1)
+                    pmc_fetch_factor = ((j.get("fetch_size_factor") or {}).get("closest"), j.get("fetch_size_factor_source"))
                     lane_util = j.get("closest", {}).get("valu_lane_util")
                     tcp_acc = j.get("closest", {}).get("tcp_accesses")
                     tcp_insts = j.get("closest", {}).get("vmem_rd_insts")

@@ -51,11 +51,17 @@ struct alignas(64) PairNode {
   float xy0[4];               // first child (linear index + 1):  bmin.x, bmin.y, bmax.x, bmax.y
   float xy1[4];               // second child:                    bmin.x, bmin.y, bmax.x, bmax.y
   float zz[4];                // first child bmin.z, bmax.z, second child bmin.z, bmax.z
-  uint32_t id0, id1;          // child words: interior = byte offset of its PairNode (bit 31 clear); leaf = kLeafBit | n_prims << 19 | first triangle
+  uint32_t id0, id1;          // child words: interior = byte offset of its PairNode (bit 31 clear); leaf = kLeafBit | kSpecialLeaf? | n_prims << 19 | first triangle
   uint32_t axis;              // split axis (bvh.rs:183-236: dir_is_neg[axis] visits the second child first)
   uint32_t pad;
 };
 constexpr uint32_t kLeafBit = 0x80000000u;
+// Leaf word = kLeafBit | kSpecialLeaf? | n_prims (11 bits) << 19 | first primitive (19 bits). kSpecialLeaf: the leaf holds a primitive that is
+// not a world-space triangle - a sphere (Tri::plane == kSphereMark) or a triangle of a kept instance (Tri::material & kInstFlag, tested in
+// object space through the instance's own ray transform, primitives.rs:115-139) - and takes the rare path special_leaf_f32(); only the
+// MIXED instantiations of the kernels look at the bit (scenes without such primitives never set it).
+constexpr uint32_t kSpecialLeaf = 0x40000000u;
+constexpr uint32_t kLeafCountMask = 0x7ffu;
 // t_max of the pool's shadow rays (spawn_ray_to: 1 - SHADOW_EPSILON with a unit direction, Q9): the any-hit kernels give every pool shadow
 // ray this length, and the host's any-hit start lists (build_pairs()) derive their reach from the same constant
 constexpr float kShadowTmax = 1.0f - 0.0001f;
@@ -158,6 +164,9 @@ struct TravScene {
   // not go down through it), word 7 = how many of those there are. They start on the lane's stack. The boxes tested, the leaves visited and
   // the triangles tested are the reference's, less the tests that cannot pass; an occlusion query is order independent. Null = off.
   const uint4* any_list;
+  // mixed scenes (kSpecialLeaf): the records the generic per-primitive tests of dkernels.hpp read
+  const SphereDev<float>* spheres;
+  const InstDev<float>* insts;
 };
 
 // A lane's position in the walk is one child word: an interior node to visit (byte offset of its PairNode, < kIdle), a leaf to test
@@ -215,10 +224,53 @@ RRT_DEV PairStep pair_step_f32(const float4 a, const float4 b, const float4 c, c
   return st;
 }
 
-// Every triangle of a leaf in ordered_prims order; each accepted hit overwrites the previous one and t_max (Q10). ANY: true at the first hit.
+// A leaf that holds a sphere or a triangle of a kept instance (kSpecialLeaf), primitive by primitive in ordered_prims order with the generic
+// tests of dkernels.hpp (what traverse_closest / traverse_any do in a leaf): Sphere::intersect / intersect_p behind Geometric /
+// TransformedPrimitive (sphere.rs:51-259), Triangle::intersect through the instance's ray transform (primitives.rs:115-139, Q15), plain
+// triangles as usual. Rare path: NOT inlined, arguments and results by value, so that its registers (atan2, two affine transforms ...) and
+// its address-taken temporaries stay out of the traversal loop, whose occupancy is what the kernel lives on.
+struct SpecialOut { float tmax, hu, hv; int hit; bool found; };
 template <bool ANY>
+__attribute__((noinline)) __device__ SpecialOut special_leaf_f32(const Tri<float>* tris, const SphereDev<float>* spheres, const InstDev<float>* insts, uint32_t word,
+                                                                  float ox, float oy, float oz, float dx, float dy, float dz, float lx, float ly, float lz,
+                                                                  float tmax, uint32_t skip_plane, int hit, float hu, float hv) {
+  SpecialOut out{tmax, hu, hv, hit, false};
+  RayCtx<float> r = make_ctx(V3<float>(ox, oy, oz), V3<float>(dx, dy, dz), tmax, V3<float>(lx, ly, lz));
+  uint32_t lf = word & 0x7ffffu, ln = (word >> 19) & kLeafCountMask;
+  do {
+    const Tri<float> tr = tris[lf];
+    float t, u, v;
+    if (tr.plane == kSphereMark) {
+      if (sphere_prim_hit<float, ANY>(spheres[tr.shade], r.o, r.d, &t, &u)) {
+        if (ANY) { out.found = true; return out; }
+        r.tmax = t; out.hit = (int)lf; out.hu = u; out.hv = 0.0f;   // u carries the root branch
+      }
+    } else if (tr.plane != skip_plane) {
+      if (is_inst_tri(tr)) {   // object-space test, object-space t copied to the world ray (Q15)
+        const RayCtx<float> ro = inst_ray(insts[inst_of(tr)], r);
+        if (ANY) { if (tri_any(tr, ro)) { out.found = true; return out; } }
+        else if (tri_closest(tr, ro, &t, &u, &v)) { r.tmax = t; out.hit = (int)lf; out.hu = u; out.hv = v; }
+      } else {
+        if (ANY) { if (tri_any(tr, r)) { out.found = true; return out; } }
+        else if (tri_closest(tr, r, &t, &u, &v)) { r.tmax = t; out.hit = (int)lf; out.hu = u; out.hv = v; }
+      }
+    }
+    lf++; ln--;
+  } while (ln != 0);
+  out.tmax = r.tmax;
+  return out;
+}
+
+// Every triangle of a leaf in ordered_prims order; each accepted hit overwrites the previous one and t_max (Q10). ANY: true at the first hit.
+template <bool ANY, bool MIXED>
 RRT_DEV bool leaf_step_f32(const TravScene& ts, uint32_t word, LaneRay& r, int* hit, float* hu, float* hv) {
-  uint32_t lf = word & 0x7ffffu, ln = (word >> 19) & 0xfffu;
+  if (MIXED && (word & kSpecialLeaf) != 0u) {
+    const SpecialOut so = special_leaf_f32<ANY>(reinterpret_cast<const Tri<float>*>(ts.tris), ts.spheres, ts.insts, word, r.oxy.x, r.oxy.y, r.ozz.x, r.dx, r.dy, r.dz,
+                                                r.lx, r.ly, r.lz, r.tmax, r.skip_plane, *hit, *hu, *hv);
+    r.tmax = so.tmax; *hit = so.hit; *hu = so.hu; *hv = so.hv;
+    return so.found;
+  }
+  uint32_t lf = word & 0x7ffffu, ln = (word >> 19) & kLeafCountMask;
   // (Measured and dropped: the next triangle's loads in flight while this one is tested - 12 more registers, 7 waves per SIMD: +0.5 ms per frame.)
   do {
     float t, u, v;
@@ -236,7 +288,7 @@ RRT_DEV bool leaf_step_f32(const TravScene& ts, uint32_t word, LaneRay& r, int* 
 //              are the pool's closest-ray arrays and the verdict is written to occluded[i] (public rrt_trace_any).
 // Grid-stride form for small queues: the wave alternates between "every lane walks interior nodes until it holds a leaf" and "every lane
 // tests its leaf" (while-while); the BFS top of the tree is read from LDS.
-template <bool ANY>
+template <bool ANY, bool MIXED = false>
 __global__ void __launch_bounds__(kTravBlock) k_trace_pairs_f32(TravScene ts, Pools<float> p, const uint32_t* queue, const uint32_t* count,
                                                                  uint32_t n_fixed, uint8_t* occluded, uint32_t n_lo, uint32_t n_hi) {
   {  // queue-size regime of this kernel (the other traversal kernel is launched next to it for the other regime)
@@ -299,7 +351,7 @@ __global__ void __launch_bounds__(kTravBlock) k_trace_pairs_f32(TravScene ts, Po
         else pop();
       }
       if (is_leaf(cur)) {
-        found = leaf_step_f32<ANY>(ts, cur, r, &hit, &hu, &hv);
+        found = leaf_step_f32<ANY, MIXED>(ts, cur, r, &hit, &hu, &hv);
         if (ANY && found) cur = kIdle;
         else pop();
       }
@@ -353,7 +405,7 @@ __device__ unsigned long long g_pt_stats[2][16];
 #else
 #define PT_STAT(i, v)
 #endif
-template <bool ANY>
+template <bool ANY, bool MIXED = false>
 __global__ void __launch_bounds__(kPtBlock) k_trace_pt_f32(TravScene ts, Pools<float> p, const uint32_t* queue, const uint32_t* count,
                                                             uint32_t n_fixed, uint32_t* work, uint8_t* occluded, uint32_t n_lo, uint32_t n_hi) {
   {
@@ -503,7 +555,7 @@ __global__ void __launch_bounds__(kPtBlock) k_trace_pt_f32(TravScene ts, Pools<f
       if (is_leaf(cur)) {
         PT_STAT(5, 1);
         // the whole leaf (1-3 triangles) in one step: fewer scheduling rounds than one triangle per step
-        if (leaf_step_f32<ANY>(ts, cur, r, &hit, &hu, &hv)) finish(true);
+        if (leaf_step_f32<ANY, MIXED>(ts, cur, r, &hit, &hu, &hv)) finish(true);
         else pop();
       }
     }

@@ -738,6 +738,7 @@ class Handle : public HandleBase {
   size_t max_paths_ = (size_t)1 << 28;   // clamped to half of the free HBM at creation (sized for 288 GB parts)
   bool deep_ = false, count_traversal_ = false, persistent_ = true;
   bool pairs_ok_ = false;
+  bool mixed_ = false;   // the tree has kSpecialLeaf leaves (spheres, kept instances): the MIXED instantiations of the pair-node kernels
   uint32_t trav_grid_ = 0, pt_grid_ = 0;
   int raygen_pt_ = 2;
   bool has_transmissive_ = false, has_translucent_ = false;
@@ -1085,10 +1086,8 @@ class Handle : public HandleBase {
       }
     }
 
-    nodes_.upload(nodes, st_); tris_.upload(tris, st_); build_pairs(nodes, tris.size()); shades_.upload(shades, st_); spheres_.upload(spheres, st_);
+    nodes_.upload(nodes, st_); tris_.upload(tris, st_); spheres_.upload(spheres, st_); insts_.upload(insts, st_); build_pairs(nodes, tris); shades_.upload(shades, st_);
     materials_.upload(mats, st_); textures_.upload(texs, st_); images_.upload(imgs, st_); image_texels_.upload(texels, st_);
-    if (!spheres.empty() || !insts.empty()) pairs_ok_ = false;   // the fp32 pair-node kernels test world-space triangles only: scenes with spheres or non-rigid instances use the generic kernels
-    insts_.upload(insts, st_);
     { const AuxMargins am = calibrate_aux_margins(d); lens_safe_.upload(am.lim, st_); aux_delta_ = am.delta; aux_pupil_ = am.pupil; }
     lights_.upload(lights, st_); light_cdf_.upload(cdf_r, st_); lens_.upload(lens, st_); hdims_.upload(hd, st_); perms_.upload(perms, st_);
     HIP_CHECK(hipStreamSynchronize(st_));  // host vectors go out of scope below
@@ -1335,7 +1334,8 @@ class Handle : public HandleBase {
       if (trav_grid_ == 0) {
         int per_cu = 0, cus = 0;
         HIP_CHECK(hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, dev_));
-        HIP_CHECK(hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu, k_trace_pairs_f32<false>, kTravBlock, 0));
+        if (mixed_) HIP_CHECK(hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu, (k_trace_pairs_f32<false, true>), kTravBlock, 0));
+        else HIP_CHECK(hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu, (k_trace_pairs_f32<false, false>), kTravBlock, 0));
         trav_grid_ = (uint32_t)(std::max(1, per_cu) * std::max(1, cus));
         if (scene_.stack_depth > (uint32_t)kStackLds) {   // any-hit launches have their own columns: they may run beside a closest-hit launch
           overflow_.alloc((size_t)(scene_.stack_depth - kStackLds) * (size_t)trav_grid_ * kTravBlock * 2);
@@ -1358,7 +1358,8 @@ class Handle : public HandleBase {
         if (pt_grid_ == 0) {
           int per_cu = 0, cus = 0;
           HIP_CHECK(hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, dev_));
-          HIP_CHECK(hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu, k_trace_pt_f32<false>, kPtBlock, 0));
+          if (mixed_) HIP_CHECK(hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu, (k_trace_pt_f32<false, true>), kPtBlock, 0));
+          else HIP_CHECK(hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu, (k_trace_pt_f32<false, false>), kPtBlock, 0));
           pt_grid_ = (uint32_t)(std::max(1, per_cu) * std::max(1, cus));
           if (pairs_ok_ && scene_.stack_depth > (uint32_t)kPtStack) pt_overflow_.alloc((size_t)(scene_.stack_depth - kPtStack) * (size_t)pt_grid_ * kPtBlock * 2);
           if (pairs_ok_ && scene_.stack_depth > (uint32_t)kPtStackAny) pt_overflow_any_.alloc((size_t)(scene_.stack_depth - kPtStackAny) * (size_t)pt_grid_ * kPtBlock * 2);
@@ -1368,27 +1369,43 @@ class Handle : public HandleBase {
         t2.overflow_stride = pt_grid_ * kPtBlock;
         const uint32_t g2 = std::max(1u, std::min(grid_in, pt_grid_));
         uint32_t* work = &counters_.p[any ? C_WORK8_SHADOW : C_WORK8_CLOSEST];   // 8 cursors, one 128-B line each
-        if (any) hipLaunchKernelGGL((k_trace_pt_f32<true>), dim3(g2), dim3(kPtBlock), 0, stream, t2, pool_, queue, count, n_fixed, work, occluded, lo_pt, 0xffffffffu);
-        else hipLaunchKernelGGL((k_trace_pt_f32<false>), dim3(g2), dim3(kPtBlock), 0, stream, t2, pool_, queue, count, n_fixed, work, occluded, lo_pt, 0xffffffffu);
+        if (mixed_) {
+          if (any) hipLaunchKernelGGL((k_trace_pt_f32<true, true>), dim3(g2), dim3(kPtBlock), 0, stream, t2, pool_, queue, count, n_fixed, work, occluded, lo_pt, 0xffffffffu);
+          else hipLaunchKernelGGL((k_trace_pt_f32<false, true>), dim3(g2), dim3(kPtBlock), 0, stream, t2, pool_, queue, count, n_fixed, work, occluded, lo_pt, 0xffffffffu);
+        } else {
+          if (any) hipLaunchKernelGGL((k_trace_pt_f32<true, false>), dim3(g2), dim3(kPtBlock), 0, stream, t2, pool_, queue, count, n_fixed, work, occluded, lo_pt, 0xffffffffu);
+          else hipLaunchKernelGGL((k_trace_pt_f32<false, false>), dim3(g2), dim3(kPtBlock), 0, stream, t2, pool_, queue, count, n_fixed, work, occluded, lo_pt, 0xffffffffu);
+        }
       }
       if (trav_mode_ != 2) {
-        if (any) hipLaunchKernelGGL((k_trace_pairs_f32<true>), dim3(grid), dim3(kTravBlock), 0, stream, trav_, pool_, queue, count, n_fixed, occluded, 0u, hi_gs);
-        else hipLaunchKernelGGL((k_trace_pairs_f32<false>), dim3(grid), dim3(kTravBlock), 0, stream, trav_, pool_, queue, count, n_fixed, occluded, 0u, hi_gs);
+        if (mixed_) {
+          if (any) hipLaunchKernelGGL((k_trace_pairs_f32<true, true>), dim3(grid), dim3(kTravBlock), 0, stream, trav_, pool_, queue, count, n_fixed, occluded, 0u, hi_gs);
+          else hipLaunchKernelGGL((k_trace_pairs_f32<false, true>), dim3(grid), dim3(kTravBlock), 0, stream, trav_, pool_, queue, count, n_fixed, occluded, 0u, hi_gs);
+        } else {
+          if (any) hipLaunchKernelGGL((k_trace_pairs_f32<true, false>), dim3(grid), dim3(kTravBlock), 0, stream, trav_, pool_, queue, count, n_fixed, occluded, 0u, hi_gs);
+          else hipLaunchKernelGGL((k_trace_pairs_f32<false, false>), dim3(grid), dim3(kTravBlock), 0, stream, trav_, pool_, queue, count, n_fixed, occluded, 0u, hi_gs);
+        }
       }
       HIP_CHECK(hipGetLastError());
     }
   }
   // re-pack the linear BVH into pair nodes (see dtraverse_f32.hpp)
-  void build_pairs(const std::vector<Node<R>>& nodes, size_t n_tris) {
+  void build_pairs(const std::vector<Node<R>>& nodes, const std::vector<Tri<R>>& tris) {
     if constexpr (std::is_same<R, float>::value) {
-      pairs_ok_ = false;
+      pairs_ok_ = false; mixed_ = false;
+      const size_t n_tris = tris.size();
       if (nodes.empty() || n_tris >= (1u << 19)) return;
+      // leaves that hold a sphere or a triangle of a kept instance carry kSpecialLeaf in their word (the MIXED kernels' rare path)
+      auto special_leaf = [&](uint32_t first, uint32_t n) {
+        for (uint32_t t = first; t < first + n && t < n_tris; t++) if (tris[t].plane == kSphereMark || (tris[t].material & kInstFlag) != 0u) return true;
+        return false;
+      };
       std::vector<uint32_t> compact(nodes.size(), 0xffffffffu);
       uint32_t n_int = 0;
       for (size_t i = 0; i < nodes.size(); i++) {
         const uint32_t np = nodes[i].meta >> 2;
         if (np == 0) compact[i] = n_int++;
-        else if (np >= 4096) return;
+        else if (np > kLeafCountMask) return;
       }
       struct Pair {   // host-side form; packed into the kernels' PairNode below
         float b0min[3], b0max[3], b1min[3], b1max[3];
@@ -1481,7 +1498,7 @@ class Handle : public HandleBase {
           uint32_t words[8];
           for (uint32_t& w : words) w = kIdle;
           uint32_t n_flagged = 0;
-          words[0] = kLeafBit | (np << 19) | nd.offset;   // every deciding node fits the list: only the leaf itself is left
+          words[0] = kLeafBit | (special_leaf(nd.offset, np) ? kSpecialLeaf : 0u) | (np << 19) | nd.offset;   // every deciding node fits the list: only the leaf itself is left
           for (size_t k = 0; k < path.size(); k++) {
             const uint32_t a = path[k];
             const uint32_t on = (k + 1 < path.size()) ? path[k + 1] : st.node;
@@ -1499,7 +1516,12 @@ class Handle : public HandleBase {
       // the kernels' form: plane coordinates paired for the packed slab arithmetic, children as ready-made stack words
       if ((uint64_t)n_int * 64u >= kIdle) return;
       std::vector<PairNode> packed(n_int);
-      auto child_word = [](uint32_t ref, uint32_t n_prims) { return n_prims ? (kLeafBit | (n_prims << 19) | ref) : ref * 64u; };
+      auto child_word = [&](uint32_t ref, uint32_t n_prims) {
+        if (!n_prims) return ref * 64u;
+        const bool sp = special_leaf(ref, n_prims);
+        mixed_ |= sp;
+        return kLeafBit | (sp ? kSpecialLeaf : 0u) | (n_prims << 19) | ref;
+      };
       for (uint32_t i = 0; i < n_int; i++) {
         const Pair& s = pairs[i];
         PairNode& d = packed[i];
@@ -1517,7 +1539,8 @@ class Handle : public HandleBase {
       trav_.pairs = pairs_.p;
       trav_.tris = reinterpret_cast<const float*>(tris_.p);
       for (int k = 0; k < 3; k++) { trav_.root_box[k] = nodes[0].bmin[k]; trav_.root_box[3 + k] = nodes[0].bmax[k]; }
-      trav_.root_id = (nodes[0].meta >> 2) ? (kLeafBit | ((nodes[0].meta >> 2) << 19) | nodes[0].offset) : 0u;
+      trav_.root_id = (nodes[0].meta >> 2) ? child_word(nodes[0].offset, nodes[0].meta >> 2) : 0u;
+      trav_.spheres = spheres_.p; trav_.insts = insts_.p;
       trav_.n_nodes = (uint32_t)nodes.size();
       pairs_ok_ = true;
     }

@@ -440,6 +440,40 @@ def test_full_size_frame_properties(workdir):
     assert diff.mean() < 1e-4, diff.mean()
 
 
+def test_mixed_scene_keeps_the_pair_node_kernels(workdir):
+    """One sphere and one scaled cube among BASELINE config 4's 100 352 triangles must not send the whole scene to the generic kernels:
+    leaves that hold such a primitive carry a flag (kSpecialLeaf) and take a rare path inside the pair-node kernels. Bars: the mixed
+    scene's frame within 10 % of the plain scene's frame time at a size where the kernels, not the launches, are what is timed (512^2,
+    64 spp), and its image - on the pixels the two extra primitives do not touch - equal to the plain scene's."""
+    import copy, time
+    def build(mixed):
+        cfg, root = scenes.cfg4(workdir, xres=512, yres=512, nsamp=65, max_depth=8)
+        if mixed:
+            write = scenes.write_cube(workdir)
+            cfg["objs"] = cfg["objs"] + [{"filename": "cube.obj", "obj_name": "cube_01"}]
+            cfg["Aggregate"]["primitives"] = cfg["Aggregate"]["primitives"] + [
+                {"primitive_type": "sphere", "material_name": "mat_matte", "radius": 0.4, "instances": [{"world_pos": [33.0, 2.5, -1.0]}]},
+                {"primitive_type": "triangle", "material_name": "mat_matte", "obj_name": "cube_01",
+                 "instances": [{"world_pos": [37.0, 2.5, 1.5], "rotation_axis": [1.0, 2.0, 3.0], "rotation_angle": 20, "scale": [0.4, 0.25, 0.4]}]}]
+        return Scene.loads(cfg, root, flags=RRT_FIXED_BVH)
+    films, ms = {}, {}
+    for mixed in (False, True):
+        sc = build(mixed)
+        r = Renderer(sc, 0, RRT_F32)
+        r.render()                                     # pools, first-launch costs
+        best = 1e9
+        for _ in range(3):
+            film, st = r.render(stats=True)
+            best = min(best, st.ms_total)
+        r.close()
+        films[mixed], ms[mixed] = film.astype(np.float64), best
+    print(f"mixed scene: {ms[True]:.2f} ms against {ms[False]:.2f} ms for the plain one ({ms[True] / ms[False]:.3f} x)")
+    assert ms[True] < 1.10 * ms[False], (ms[True], ms[False])
+    scale = films[False][..., :3].max()
+    changed = (np.abs(films[True][..., :3] - films[False][..., :3]).max(-1) / scale > 1e-3).mean()
+    assert 0.0005 < changed < 0.25, changed            # the two primitives are seen (and shadow / light their neighbourhood), the rest of the frame is not disturbed
+
+
 def _non_rigid(wd, integrator):
     cfg, root = scenes.cfg2(wd, xres=72, yres=72, nsamp=9, max_depth=3)
     inst = cfg["Aggregate"]["primitives"][0]["instances"]
@@ -456,8 +490,9 @@ def test_non_rigid_triangle_instances(which, workdir):
     """`scale` on a mesh instance (renderprocess.rs:242-252): TransformedPrimitive::intersect (primitives.rs:115-139) tests the triangle with
     the ray moved into the instance's space and RE-NORMALISED there (transform.rs:525-537), copies that object-space t to the world ray
     (Q15: boxes are then pruned with a distance in the wrong space) and transforms the interaction back, leaving wo un-normalised.
-    The device replays exactly that for non-rigid instances (rigid ones are flattened). f64 mode: hits, t, counters bit for bit and
-    frames to 1e-9 against the oracle; fp32 on the generic kernels within the triangle scenes' bar.
+    The device replays exactly that for non-rigid instances (fp32: rigid ones are flattened; f64: every instance is kept). f64 mode: hits, t,
+    counters bit for bit and frames to 1e-9 against the oracle; fp32 - pair-node kernels with the kept instances on their rare path, and the
+    generic kernels - within the triangle scenes' bar.
     path_metal / path_plastic: the path integrator samples the BSDF with `wo = -ray.d` (path.rs:126), the WORLD ray's direction, while
     estimate_direct evaluates it with the interaction's un-normalised wo - on a scaled instance the two differ, and every lobe but the
     Lambertian one sees it (fuzz seed 703 case 95 found the device using the interaction's wo for both: 75 % of the pixels off by up to 6e-3)."""
@@ -469,7 +504,7 @@ def test_non_rigid_triangle_instances(which, workdir):
         cfg["Aggregate"]["primitives"][0]["material_name"] = "mat_metal" if which == "path_metal" else "mat_plastic"
     sc = Scene.loads(cfg, root)
     o, d, tmax, _ = _rays_for(sc, 2048, 17)
-    ref_t = O.trace_closest(sc, o, d, tmax)      # flat: rigid instances flattened like on the device, non-rigid ones per primitive
+    ref_t = O.trace_closest(sc, o, d, tmax)      # the reference's order: every instance per primitive, like the f64 device mode
     ref_a = O.trace_any(sc, o, d, tmax)
     r = Renderer(sc, 0, RRT_F64)
     got = r.trace_closest(o, d, tmax, counters=True)
@@ -491,14 +526,22 @@ def test_non_rigid_triangle_instances(which, workdir):
     scale = np.abs(ref[..., :3]).max()
     assert scale > 0
     assert (np.abs(film[..., :3] - ref[..., :3]).max() / scale) < 1e-9
-    r = Renderer(sc, 0, RRT_F32)
-    f32 = r.render().astype(np.float64)
-    r.close()
-    ref_o = O.render(sc)                                       # the reference's own order throughout
-    d32 = np.abs(f32[..., :3] - ref_o[..., :3]).max(-1) / scale
-    assert np.array_equal(f32[..., 3], ref_o[..., 3])
-    print(f"non-rigid {which}: fp32 within 1e-4: {(d32 < 1e-4).mean():.4f}, max {d32.max():.2e}, mean ratio {f32[..., :3].mean() / ref_o[..., :3].mean():.5f}")
-    assert (d32 < 1e-3).mean() > 0.97 and abs(f32[..., :3].mean() / ref_o[..., :3].mean() - 1.0) < 0.02
+    # fp32: the pair-node kernels (kept instances take their rare path, kSpecialLeaf) in both forms, and the generic kernels
+    ref_o = ref                                                # the reference's own order throughout
+    frames = {}
+    for mode in (3, 2, 1, 0):
+        r = Renderer(sc, 0, RRT_F32)
+        if mode != 3:
+            r.set_option("persistent_traversal", mode)         # 2: persistent-thread kernel whatever the queue size, 1: grid-stride, 0: generic
+        f32 = r.render().astype(np.float64)
+        r.close()
+        frames[mode] = f32
+        d32 = np.abs(f32[..., :3] - ref_o[..., :3]).max(-1) / scale
+        assert np.array_equal(f32[..., 3], ref_o[..., 3])
+        print(f"non-rigid {which} traversal mode {mode}: fp32 within 1e-4: {(d32 < 1e-4).mean():.4f}, max {d32.max():.2e}, mean ratio {f32[..., :3].mean() / ref_o[..., :3].mean():.5f}")
+        assert (d32 < 1e-3).mean() > 0.97 and abs(f32[..., :3].mean() / ref_o[..., :3].mean() - 1.0) < 0.02
+    dm = np.abs(frames[2][..., :3] - frames[1][..., :3]).max(-1) / scale      # the two pair-node kernels make the same decisions
+    assert (dm < 1e-6).mean() > 0.995, (dm < 1e-6).mean()
 
 
 @pytest.mark.parametrize("which", ["cfg4", "cfg4_far", "cfg5", "cfg2", "cfg3_direct"])
@@ -918,12 +961,17 @@ def test_sphere_primitives_trace_f64_exact(workdir):
     assert np.array_equal(np.asarray(got_any).astype(bool), ref_any["occluded"])
     r.close()
     # fp32: same winners except where fp32 rounding decides (grazing rays)
-    r = Renderer(sc, 0, RRT_F32)
-    got32 = r.trace_closest(o, d, tmax)
-    r.close()
-    assert (got32["prim"] == ref["prim"]).mean() > 0.999
-    both = (got32["prim"] == ref["prim"]) & hit
-    np.testing.assert_allclose(got32["t"][both], ref["t"][both], rtol=2e-4)
+    for mode in (3, 2, 1, 0):
+        r = Renderer(sc, 0, RRT_F32)
+        if mode != 3:
+            r.set_option("persistent_traversal", mode)
+        got32 = r.trace_closest(o, d, tmax)
+        any32 = r.trace_any(o, d, tm)
+        r.close()
+        assert (got32["prim"] == ref["prim"]).mean() > 0.999, mode
+        both = (got32["prim"] == ref["prim"]) & hit
+        np.testing.assert_allclose(got32["t"][both], ref["t"][both], rtol=2e-4)
+        assert (np.asarray(any32).astype(bool) == ref_any["occluded"]).mean() > 0.999, mode
 
 
 @pytest.mark.parametrize("which", ["cfg1", "zoo_direct", "zoo_path", "zoo_debug"])
@@ -953,13 +1001,16 @@ def test_sphere_primitives_render(which, workdir):
     # fp32 product: keeps the same un-epsilon'd test, so spawned rays self-hit with the same ~50 % odds but on
     # different samples: the image agrees with the oracle in the mean, not pixel by pixel (cfg1 at 2 spp is itself
     # noisy: 15 %; the zoo's spheres cover less of the frame: 5 %).
-    r = Renderer(sc, 0, RRT_F32)
-    film32 = r.render()
-    r.close()
-    assert np.array_equal(film32[..., 3].astype(np.float64), ref[..., 3])
-    ratio = film32[..., :3].mean() / ref[..., :3].mean()
-    print(f"spheres {which}: fp32 mean / oracle mean = {ratio:.4f}")
-    assert abs(ratio - 1.0) < (0.15 if which == "cfg1" else 0.05), ratio
+    for mode in (3, 2, 1, 0):      # default (by queue size), persistent-thread pair-node kernel, grid-stride pair-node kernel, generic kernels
+        r = Renderer(sc, 0, RRT_F32)
+        if mode != 3:
+            r.set_option("persistent_traversal", mode)
+        film32 = r.render()
+        r.close()
+        assert np.array_equal(film32[..., 3].astype(np.float64), ref[..., 3])
+        ratio = film32[..., :3].mean() / ref[..., :3].mean()
+        print(f"spheres {which}, traversal mode {mode}: fp32 mean / oracle mean = {ratio:.4f}")
+        assert abs(ratio - 1.0) < (0.15 if which == "cfg1" else 0.05), ratio
 
 
 SPHERE_MATERIALS = {

@@ -1,7 +1,12 @@
 """HBM traffic per kernel family from rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE passes (one directory per pass).
 
-rocprofv3 reports both counters in KiB-like units of 1024 B (derived from TCC_EA0_RDREQ / WRREQ); per
-MI355X_MICROARCH.md (HBM section) FETCH_SIZE on gfx950 tallies 128-B requests at 64 B, so reads are doubled.
+rocprofv3 reports both counters in KiB-like units of 1024 B (derived from TCC_EA0_RDREQ / WRREQ). Per MI355X_MICROARCH.md (HBM section)
+FETCH_SIZE on gfx950 tallies the 128-B requests of a wide coalesced streaming read at 64 B (x2), and "other access widths are uncalibrated":
+tools/micro/fetch_calib.hip (profiles/r3_fetch_calibration.txt) calibrates the traversal kernels' shape - every lane reading the four 16-byte
+words of its own 64-byte node, each node once out of 2 GiB: FETCH_SIZE x 1024 = 1.003 x the bytes (64-B requests, tallied in full; Infinity-Cache
+hits are counted: an 8 MiB table read 16 times over reports its L2 misses). So the traversal families get x1 on their gathers; their coalesced
+part - the 32 B of ray record per query - is tallied at half, which the caller adds from its query count (bench.py). The streaming families
+(raygen, shading, film: coalesced 16-byte-per-lane records) keep x2.
 The profiled command is `bench.py --steps 1 --warmup 0 --frames-in-flight 1`; its first frame is the counting frame (generic
 counting kernels), the product kernels appear in the others (their number is derived from the dispatch count).
 """
@@ -26,12 +31,17 @@ for f in glob.glob(f"{root}/pass*/**/*counter_collection.csv", recursive=True):
                 tot[k][r["Counter_Name"]] += float(r["Counter_Value"]); disp[k][r["Counter_Name"]] += 1
 # product frames in the profiled run = closest-hit dispatches / 16 (8 bounces x the two regime kernels; the counting frame uses the generic kernels)
 FRAMES = max(1, round(disp["closest"]["FETCH_SIZE"] / 16))
-out = {"units": "bytes per frame; FETCH_SIZE x1024 x2 (gfx950 correction), WRITE_SIZE x1024", "frames_profiled": FRAMES, "source_hash": kernel_source_hash()}
+out = {"units": "bytes per frame; FETCH_SIZE x1024 x factor (traversal gathers x1, streaming families x2: profiles/r3_fetch_calibration.txt), WRITE_SIZE x1024",
+       "fetch_size_factor": {"closest": 1.0, "any": 1.0, "raygen": 2.0, "shade": 2.0, "film": 2.0},
+       "fetch_size_factor_source": "profiles/r3_fetch_calibration.txt (tools/micro/fetch_calib.hip): 64-B-node gather 1.003, coalesced 16 B per lane 0.500 of the known bytes",
+       "coalesced_record_note": "closest / any: the coalesced ray-record reads (32 B per query) are tallied at half by FETCH_SIZE; + 16 B x queries restores them (bench.py does)",
+       "frames_profiled": FRAMES, "source_hash": kernel_source_hash()}
 for k in fam:
     nf = FRAMES if k in ("closest", "any") else FRAMES + 1     # raygen / shading / film kernels also run in the counting frame
-    rd = tot[k]["FETCH_SIZE"] * 1024 * 2 / nf
+    raw = tot[k]["FETCH_SIZE"] * 1024 / nf
+    rd = raw * out["fetch_size_factor"][k]
     wr = tot[k]["WRITE_SIZE"] * 1024 / nf
-    out[k] = {"read_bytes": rd, "write_bytes": wr, "hbm_bytes": rd + wr, "dispatches_per_frame": disp[k]["FETCH_SIZE"] / nf}
+    out[k] = {"fetch_size_raw_bytes": raw, "read_bytes": rd, "write_bytes": wr, "hbm_bytes": rd + wr, "dispatches_per_frame": disp[k]["FETCH_SIZE"] / nf}
 # lane-level accesses of the vector L1 (TCP): what the traversal kernels queue for (tools/micro/tcp_gather2.hip: 0.61 cycles of the CU's TCP each)
 for k in fam:
     acc = tot[k].get("TCP_TOTAL_CACHE_ACCESSES_sum", 0.0)
