@@ -19,7 +19,8 @@ template <typename R> struct ShadeBlock { static constexpr int n = 256; };
 #define RRT_SHADE_BLOCK 256
 #endif
 template <> struct ShadeBlock<float> { static constexpr int n = RRT_SHADE_BLOCK; };
-enum { ERR_SHADING_NORMAL = 1, ERR_BETA = 4, ERR_NULL_BSDF = 8, ERR_MIPMAP = 16, ERR_HALTON_DIMS = 32, ERR_ST_DIMS = 64, ERR_NO_LIGHTS = 128 };
+enum { ERR_SHADING_NORMAL = 1, ERR_BETA = 4, ERR_NULL_BSDF = 8, ERR_MIPMAP = 16, ERR_HALTON_DIMS = 32, ERR_ST_DIMS = 64, ERR_NO_LIGHTS = 128,
+       ERR_KIND_SET = 256 /* a material produced a lobe outside the shading kernel's kind set (dmath.hpp): host-side selection error */ };
 static_assert(ERR_ST_DIMS == kErrStDims, "error bit shared with dmath.hpp");
 static_assert(ERR_HALTON_DIMS == kErrHaltonDims, "error bit shared with dmath.hpp");
 
@@ -749,20 +750,20 @@ RRT_DEV Surf<R> build_surface(const SceneDev<R>& s, int prim, V3<R> o, V3<R> d, 
   return si;
 }
 
-template <typename R, int NL>
-RRT_DEV void build_bsdf(const SceneDev<R>& s, const Surf<R>& si, Bsdf<R, NL>* b, bool allow_multiple_lobes = true) {  // Bsdf::new reflection.rs:215-226
+template <typename R, int NL, uint32_t KM>
+RRT_DEV bool build_bsdf(const SceneDev<R>& s, const Surf<R>& si, Bsdf<R, NL, KM>* b, bool allow_multiple_lobes = true) {  // Bsdf::new reflection.rs:215-226
   b->ns = si.sn;
   b->ss = vnormalize(si.sdpdu);
   b->ng = si.n;
   b->ts = cross(b->ns, b->ss);
-  build_lobes(s.materials[si.material], b, allow_multiple_lobes);
+  return build_lobes(s.materials[si.material], b, allow_multiple_lobes);
 }
 // textured scenes: compute_differentials (interaction.rs:209), then the material's textures at this hit, then the lobes.
 // Returns false for a Glass / Translucent whose evaluated colours are all black: the reference leaves `bsdf` None there
 // and path.rs:103 underflows `bounces` (constant materials are checked on the host).
-template <typename R, int NL>
+template <typename R, int NL, uint32_t KM>
 RRT_DEV bool build_bsdf_tex(const SceneDev<R>& s, Surf<R>& si, const SurfExt<R>& ext, const DiffRay<R>& rd, TexCtx<R>* c,
-                            Bsdf<R, NL>* b, bool allow_multiple_lobes = true) {
+                            Bsdf<R, NL, KM>* b, bool allow_multiple_lobes = true) {
   c->p = si.p; c->u = ext.u; c->v = ext.v;
   c->pd = V3<double>((double)si.p.x + (double)si.p_lo.x, (double)si.p.y + (double)si.p_lo.y, (double)si.p.z + (double)si.p_lo.z);
   compute_differentials(c, si.n, ext.dpdu, ext.dpdv, rd);
@@ -891,8 +892,8 @@ RRT_DEV bool sphere_hit_for_pdf(const Light<R>& L, V3<R> ro, V3<R> rd, V3<R>* p_
 // Returns true and fills the shadow ray + contribution when a visibility test is needed.
 // The BSDF-sampling half (:483-556) can only add `li * f * weight / pdf` with li = 0 (no primitive carries an
 // area light, Q18; DiffuseAreaLight::le is the trait default 0), so it is not executed: see DESIGN.md.
-template <typename R, int NL>
-RRT_DEV bool estimate_direct_light(const Surf<R>& si, const Bsdf<R, NL>& bsdf, const Light<R>& L, R ul0, R ul1, V3<R>* so, V3<R>* sd, Rgb<R>* ld) {
+template <typename R, int NL, uint32_t KM>
+RRT_DEV bool estimate_direct_light(const Surf<R>& si, const Bsdf<R, NL, KM>& bsdf, const Light<R>& L, R ul0, R ul1, V3<R>* so, V3<R>* sd, Rgb<R>* ld) {
   const uint32_t flags = BXDF_ALL & ~BXDF_SPECULAR;
   V3<R> wi, p1, n1;
   R light_pdf = R(0);
@@ -929,10 +930,14 @@ RRT_DEV uint32_t sample_light_discrete(const SceneDev<R>& s, R u) {
 #ifndef RRT_SHADE_WAVES
 #define RRT_SHADE_WAVES 4
 #endif
+#ifndef RRT_SHADE_WAVES_LAMBERT
+#define RRT_SHADE_WAVES_LAMBERT 5   // the Lambert-only instantiation needs 99 VGPRs
+#endif
 // TEX: the scene has materials that evaluate a texture per hit (SurfExt + ray differentials of the camera ray at bounce 0;
 // `ray = isect.spawn_ray(wi).into()` drops them afterwards, path.rs:163).
-template <typename R, int NL, bool TEX = false>
-__global__ void __launch_bounds__(ShadeBlock<R>::n) __attribute__((amdgpu_waves_per_eu(TEX ? 1 : RRT_SHADE_WAVES, 8))) k_shade_path(SceneDev<R> s, Pools<R> p) {
+// KM: the lobe kinds the scene's materials can produce (dmath.hpp "Lobe-kind sets"); kAllKinds = the general kernel.
+template <typename R, int NL, bool TEX = false, uint32_t KM = kAllKinds>
+__global__ void __launch_bounds__(ShadeBlock<R>::n) __attribute__((amdgpu_waves_per_eu(TEX ? 1 : (KM == kKindsLambert ? RRT_SHADE_WAVES_LAMBERT : RRT_SHADE_WAVES), 8))) k_shade_path(SceneDev<R> s, Pools<R> p) {
   __shared__ uint32_t push_lds[ShadeBlock<R>::n / 64 + 1];
   const uint32_t n = p.counters[C_ACTIVE];
   using V4 = typename Vec4T<R>::type;
@@ -962,7 +967,7 @@ __global__ void __launch_bounds__(ShadeBlock<R>::n) __attribute__((amdgpu_waves_
       Surf<R> si = build_surface(s, prim, o, d, h.x, h.z, h.w, TEX ? &ext : nullptr);
       if (!si.ok) { atomicOr(&p.counters[C_ERROR], (uint32_t)ERR_SHADING_NORMAL); }
       else {
-        Bsdf<R, NL> bsdf;
+        Bsdf<R, NL, KM> bsdf;
         if (TEX) {
           DiffRay<R> dr;
           if (bounces == 0) {
@@ -972,7 +977,7 @@ __global__ void __launch_bounds__(ShadeBlock<R>::n) __attribute__((amdgpu_waves_
           }
           TexCtx<R> tc;
           if (!build_bsdf_tex(s, si, ext, dr, &tc, &bsdf)) atomicOr(&p.counters[C_ERROR], (uint32_t)(tc.err ? ERR_MIPMAP : ERR_NULL_BSDF));
-        } else build_bsdf(s, si, &bsdf);
+        } else if (!build_bsdf(s, si, &bsdf)) atomicOr(&p.counters[C_ERROR], (uint32_t)ERR_KIND_SET);
         const V4 st_b = p.path[i];
         index = qe.index;
         Rgb<R> beta(st_b.x, st_b.y, st_b.z);

@@ -639,7 +639,20 @@ template <typename R> RRT_DEV Rgb<R> fresnel_eval(const Lobe<R>& l, R cos_i) {  
   if (l.fr == FR_DIELECTRIC) return Rgb<R>(fr_dielectric(cos_i, l.eta_i.r, l.eta_t.r));
   return fr_conductor(rabs(cos_i), l.eta_i, l.eta_t, l.k);
 }
-template <typename R> RRT_DEV Rgb<R> lobe_f(const Lobe<R>& l, V3<R> wo, V3<R> wi) {
+// Lobe-kind sets. A scene's materials fix which BxDFs can ever exist at its hits; the shading kernels are instantiated for a few such sets
+// (KM = bit mask over LOBE_*, ~0u = every kind) so that the code - and above all the registers - of the kinds a scene cannot produce are not
+// part of its kernel (Lambert-only scenes: 128 -> 99 VGPRs, 4 -> 5 waves per SIMD in the latency-bound path shading kernel). Same arithmetic
+// per kind in every instantiation. The host picks the set from the materials the aggregate uses (rrt_impl.hpp shade_spec()); build_lobes
+// drops a lobe whose kind is outside the kernel's set and raises an error flag instead of running into the `unreachable` below.
+constexpr uint32_t kAllKinds = 0xffffffffu;
+constexpr uint32_t kind_bit(uint32_t k) { return 1u << k; }
+constexpr uint32_t kKindsLambert = kind_bit(LOBE_LAMBERT);
+constexpr uint32_t kKindsGlossy = kind_bit(LOBE_LAMBERT) | kind_bit(LOBE_OREN_NAYAR) | kind_bit(LOBE_MICROFACET);
+template <uint32_t KM> RRT_DEV bool kind_in(uint32_t kind) { return KM == kAllKinds || kind == LOBE_NONE || (kind < 32u && ((KM >> kind) & 1u) != 0u); }
+#define RRT_KIND_SET(KM, l) do { if (!kind_in<KM>((l).kind)) __builtin_unreachable(); } while (0)
+
+template <typename R, uint32_t KM = kAllKinds> RRT_DEV Rgb<R> lobe_f(const Lobe<R>& l, V3<R> wo, V3<R> wi) {
+  RRT_KIND_SET(KM, l);
   switch (l.kind) {
     case LOBE_LAMBERT: return l.r / R(RRT_PI);
     case LOBE_OREN_NAYAR: {  // reflection.rs:917-941
@@ -681,7 +694,8 @@ template <typename R> RRT_DEV Rgb<R> lobe_f(const Lobe<R>& l, V3<R> wo, V3<R> wi
     default: return Rgb<R>();  // SpecularReflection / SpecularTransmission / FresnelSpecular ::f
   }
 }
-template <typename R> RRT_DEV R lobe_pdf(const Lobe<R>& l, V3<R> wo, V3<R> wi) {
+template <typename R, uint32_t KM = kAllKinds> RRT_DEV R lobe_pdf(const Lobe<R>& l, V3<R> wo, V3<R> wi) {
+  RRT_KIND_SET(KM, l);
   if (l.kind == LOBE_MICROFACET) {  // reflection.rs:1019-1025
     if (!same_hemisphere(wo, wi)) return R(0);
     V3<R> wh = vnormalize(wo + wi);
@@ -699,7 +713,8 @@ template <typename R> RRT_DEV R lobe_pdf(const Lobe<R>& l, V3<R> wo, V3<R> wi) {
   }
   return same_hemisphere(wo, wi) ? abs_cos_theta(wi) / R(RRT_PI) : R(0);  // BxDF::pdf default :492-498
 }
-template <typename R> RRT_DEV Rgb<R> lobe_sample_f(const Lobe<R>& l, V3<R> wo, V3<R>* wi, R u0, R u1, R* pdf, uint32_t* sampled) {
+template <typename R, uint32_t KM = kAllKinds> RRT_DEV Rgb<R> lobe_sample_f(const Lobe<R>& l, V3<R> wo, V3<R>* wi, R u0, R u1, R* pdf, uint32_t* sampled) {
+  RRT_KIND_SET(KM, l);
   if (l.kind == LOBE_SPEC_TRANS || l.kind == LOBE_FRESNEL_SPEC) {  // reflection.rs:690-716, :754-795, mode = Radiance
     R fr = R(0);
     if (l.kind == LOBE_FRESNEL_SPEC) {
@@ -723,8 +738,8 @@ template <typename R> RRT_DEV Rgb<R> lobe_sample_f(const Lobe<R>& l, V3<R> wo, V
   if (l.kind == LOBE_LAMBERT_TRANS) {  // :857-869
     *wi = cosine_sample_hemisphere(u0, u1);
     if (wo.z > R(0)) wi->z *= R(-1);
-    *pdf = lobe_pdf(l, wo, *wi);
-    return lobe_f(l, wo, *wi);
+    *pdf = lobe_pdf<R, KM>(l, wo, *wi);
+    return lobe_f<R, KM>(l, wo, *wi);
   }
   if (l.kind == LOBE_MICROFACET_TRANS) {  // :1098-1123
     if (wo.z == R(0)) return Rgb<R>();
@@ -732,8 +747,8 @@ template <typename R> RRT_DEV Rgb<R> lobe_sample_f(const Lobe<R>& l, V3<R> wo, V
     if (dot(wo, wh) < R(0)) return Rgb<R>();
     const R eta = cos_theta(wo) > R(0) ? l.a / l.b : l.b / l.a;
     if (!refract(wo, wh, eta, wi)) return Rgb<R>();
-    *pdf = lobe_pdf(l, wo, *wi);
-    return lobe_f(l, wo, *wi);
+    *pdf = lobe_pdf<R, KM>(l, wo, *wi);
+    return lobe_f<R, KM>(l, wo, *wi);
   }
   if (l.kind == LOBE_MICROFACET) {  // reflection.rs:993-1018
     if (wo.z == R(0)) return Rgb<R>();
@@ -742,7 +757,7 @@ template <typename R> RRT_DEV Rgb<R> lobe_sample_f(const Lobe<R>& l, V3<R> wo, V
     *wi = reflect(wo, wh);
     if (!same_hemisphere(wo, *wi)) return Rgb<R>();
     *pdf = tr_pdf(l, wo, wh) / (R(4) * dot(wo, wh));
-    return lobe_f(l, wo, *wi);
+    return lobe_f<R, KM>(l, wo, *wi);
   }
   if (l.kind == LOBE_SPEC_REFL) {  // reflection.rs:639-650
     *wi = V3<R>(-wo.x, -wo.y, wo.z);
@@ -751,8 +766,8 @@ template <typename R> RRT_DEV Rgb<R> lobe_sample_f(const Lobe<R>& l, V3<R> wo, V
   }
   *wi = cosine_sample_hemisphere(u0, u1);  // BxDF::sample_f default :427-443
   if (wo.z < R(0)) wi->z *= R(-1);
-  *pdf = lobe_pdf(l, wo, *wi);
-  return lobe_f(l, wo, *wi);
+  *pdf = lobe_pdf<R, KM>(l, wo, *wi);
+  return lobe_f<R, KM>(l, wo, *wi);
 }
 template <typename R> RRT_DEV R roughness_to_alpha(R roughness) {  // microfacet.rs:12-20
   roughness = rmax(roughness, R(1e-3));
@@ -765,8 +780,9 @@ template <typename R> RRT_DEV R roughness_to_alpha(R roughness) {  // microfacet
 // fully unrolled: with `lobes[n++]` / `lobes[chosen]` the array lived in scratch memory (212 B per lane) and each field
 // access was a memory round trip in the most latency-bound kernel of the frame. Relative order is what the reference's
 // "count-th matching component" and its sums depend on, and gaps do not change it.
-template <typename R, int NL = 2>
+template <typename R, int NL = 2, uint32_t KM = kAllKinds>
 struct Bsdf {
+  static constexpr uint32_t kinds = KM;
   V3<R> ns, ng, ss, ts;
   Lobe<R> lobes[NL];
   int n;   // number of lobes present
@@ -791,7 +807,7 @@ struct Bsdf {
 #pragma unroll
     for (int i = 0; i < NL; i++) {
       const Lobe<R>& l = lobes[i];
-      if (match(l, flags) && ((refl && (l.type & BXDF_REFLECTION)) || (!refl && (l.type & BXDF_TRANSMISSION)))) r = r + lobe_f(l, wo, wi);
+      if (match(l, flags) && ((refl && (l.type & BXDF_REFLECTION)) || (!refl && (l.type & BXDF_TRANSMISSION)))) r = r + lobe_f<R, KM>(l, wo, wi);
     }
     return r;
   }
@@ -802,7 +818,7 @@ struct Bsdf {
     R p = R(0);
     int matching = 0;
 #pragma unroll
-    for (int i = 0; i < NL; i++) if (match(lobes[i], flags)) { matching++; p += lobe_pdf(lobes[i], wo, wi); }
+    for (int i = 0; i < NL; i++) if (match(lobes[i], flags)) { matching++; p += lobe_pdf<R, KM>(lobes[i], wo, wi); }
     return matching > 0 ? p / (R)matching : R(0);
   }
   // sample_f :302-381 (Q21). *pdf_out / *sampled keep the caller's values on the wo.z == 0 early-out.
@@ -823,12 +839,12 @@ struct Bsdf {
     if (wo.z == R(0)) return Rgb<R>();
     *pdf_out = R(0);
     *sampled = bx.type;
-    Rgb<R> f = lobe_sample_f(bx, wo, &wi, ur0, u1, pdf_out, sampled);
+    Rgb<R> f = lobe_sample_f<R, KM>(bx, wo, &wi, ur0, u1, pdf_out, sampled);
     if (*pdf_out == R(0)) { *sampled = BXDF_NONE; return Rgb<R>(); }
     *wi_w = to_world(wi);
     if (!(bx.type & BXDF_REFLECTION) && matching > 1) {
 #pragma unroll
-      for (int i = 0; i < NL; i++) if (i != chosen && match(lobes[i], flags)) *pdf_out += lobe_pdf(lobes[i], wo, wi);
+      for (int i = 0; i < NL; i++) if (i != chosen && match(lobes[i], flags)) *pdf_out += lobe_pdf<R, KM>(lobes[i], wo, wi);
     }
     if (matching > 1) *pdf_out /= (R)matching;
     return f;
@@ -838,11 +854,21 @@ struct Bsdf {
 // Material::compute_scattering_functions (matte.rs:35-60, plastic.rs:42-73, metal.rs:48-89, mirror.rs:27-47,
 // debug_material.rs:37-48, glass.rs:52-112, translucent.rs:52-107) from parameter values (textured parameters are
 // evaluated first, resolve_material() in dtexture.hpp)
-template <typename R, int NL> RRT_DEV void build_lobes(const Material<R>& m, Bsdf<R, NL>* b, bool allow_multiple_lobes = true) {
+// Returns false when the material produced a lobe outside the kernel's kind set KM (a host-side mistake in shade_spec()): that lobe is dropped.
+template <typename R, int NL, uint32_t KM> RRT_DEV bool build_lobes(const Material<R>& m, Bsdf<R, NL, KM>* b, bool allow_multiple_lobes = true) {
   b->n = 0;
   b->eta = R(1);
 #pragma unroll
   for (int i = 0; i < NL; i++) { b->lobes[i].kind = LOBE_NONE; b->lobes[i].type = 0; }
+  // material types that can produce nothing but kinds outside KM are not part of this instantiation
+  constexpr bool kDiffuse = (KM & (kind_bit(LOBE_LAMBERT) | kind_bit(LOBE_OREN_NAYAR))) != 0u, kMicro = (KM & kind_bit(LOBE_MICROFACET)) != 0u;
+  constexpr bool kMirror = (KM & kind_bit(LOBE_SPEC_REFL)) != 0u, kTrans = (KM & (kind_bit(LOBE_SPEC_TRANS) | kind_bit(LOBE_FRESNEL_SPEC) | kind_bit(LOBE_LAMBERT_TRANS) | kind_bit(LOBE_MICROFACET_TRANS))) != 0u;
+  constexpr bool kDebug = (KM & (kind_bit(LOBE_DEBUG_DIFFUSE) | kind_bit(LOBE_DEBUG_SPECULAR))) != 0u;
+  const uint32_t mt = (uint32_t)m.type;
+  if ((mt == 0u && !kDiffuse) || (mt == 1u && !(kDiffuse && kMicro)) || (mt == 2u && !kMicro) || (mt == 3u && !kMirror) || ((mt == 5u || mt == 6u) && !kTrans) ||
+      (mt == 4u && !kDebug) || mt > 6u) {
+    if (KM != kAllKinds) return false;   // (ALL: the reference's `default` arm below takes every other value as the Debug material)
+  }
   switch (m.type) {
     case 0: {  // MatteMaterial
       Rgb<R> r = rgb_clamp0(Rgb<R>(m.kd));
@@ -955,6 +981,12 @@ template <typename R, int NL> RRT_DEV void build_lobes(const Material<R>& m, Bsd
       break;
     }
   }
+  bool ok = true;
+  if (KM != kAllKinds) {
+#pragma unroll
+    for (int i = 0; i < NL; i++) if (!kind_in<KM>(b->lobes[i].kind)) { b->lobes[i].kind = LOBE_NONE; b->lobes[i].type = 0; b->n--; ok = false; }
+  }
+  return ok;
 }
 
 }  // namespace rrtd

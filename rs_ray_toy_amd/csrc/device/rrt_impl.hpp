@@ -365,6 +365,7 @@ class Handle : public HandleBase {
     else if (key == "pt_split_any") pt_split_any_ = (uint32_t)v;
     else if (key == "overlap_shadow") overlap_shadow_ = v != 0;
     else if (key == "aux_margin") aux_margin_ = v != 0;
+    else if (key == "shade_spec") shade_kinds_ = v != 0 ? shade_kinds_scene_ : kAllKinds;
     else if (key == "frame_stats") frame_stats_ = v != 0;
     else if (key == "halton_tables") scene_.n_hblk = (v != 0 && hblk_.n) ? (uint32_t)kHaltonTabDims : 0u;
     else if (key == "cam_tables") { for (int w = 0; w < 3; w++) { scene_.cam_lo[w] = (v != 0 && cam_lo_.n) ? cam_lo_.p + cam_lo_off_[w] : nullptr; scene_.cam_hi[w] = (v != 0 && cam_hi_.n) ? cam_hi_.p + cam_hi_off_[w] : nullptr; } }
@@ -493,6 +494,7 @@ class Handle : public HandleBase {
     if (err & ERR_MIPMAP) throw PanicError("mipmap.rs:217 / memory.rs:84 index out of bounds in an ImageTexture lookup (EWA of the level past the last one: images with fewer than two pyramid levels, or a footprint >= the whole texture)");
     if (err & ERR_NULL_BSDF) throw PanicError("glass.rs:70 / translucent.rs:66 null BSDF (textures evaluate to black): path.rs:103 `bounces -= 1` underflows");
     if (err & ERR_BETA) throw PanicError("path.rs:146 assert!(beta.y() > 0.0 && beta.y().is_finite())");
+    if (err & ERR_KIND_SET) throw DeviceError("internal: a material produced a BxDF outside the kind set its shading kernel was selected for (shade_spec())");
   }
   void render_bands(int rank, int world, void* film_user, int film_mem, rrt_render_stats* stats) override {
     if (world < 1 || rank < 0 || rank >= world) throw std::invalid_argument("render_bands: bad rank/world");
@@ -589,6 +591,8 @@ class Handle : public HandleBase {
             e = tick(3);
             if (tex_depth_ > 0) hipLaunchKernelGGL((k_shade_path<R, 4, true>), dim3(std::min((uint32_t)((nslots + 255) / 256), 16384u)), dim3(256), 0, st_, scene_, pool_);
             else if (has_translucent_) hipLaunchKernelGGL((k_shade_path<R, 4>), dim3(std::min((uint32_t)((nslots + 255) / 256), 16384u)), dim3(256), 0, st_, scene_, pool_);
+            else if (shade_kinds_ == kKindsLambert) hipLaunchKernelGGL((k_shade_path<R, 2, false, kKindsLambert>), dim3(std::min(sgrid, 16384u)), dim3(ShadeBlock<R>::n), 0, st_, scene_, pool_);
+            else if (shade_kinds_ == kKindsGlossy) hipLaunchKernelGGL((k_shade_path<R, 2, false, kKindsGlossy>), dim3(std::min(sgrid, 16384u)), dim3(ShadeBlock<R>::n), 0, st_, scene_, pool_);
             else hipLaunchKernelGGL((k_shade_path<R, 2>), dim3(std::min(sgrid, 16384u)), dim3(ShadeBlock<R>::n), 0, st_, scene_, pool_);
             tock(e);
             if (overlap) {
@@ -742,6 +746,7 @@ class Handle : public HandleBase {
   uint32_t trav_grid_ = 0, pt_grid_ = 0;
   int raygen_pt_ = 2;
   bool has_transmissive_ = false, has_translucent_ = false;
+  uint32_t shade_kinds_scene_ = kAllKinds, shade_kinds_ = kAllKinds;   // lobe-kind set of the scene's materials / of the shading kernel in use (option "shade_spec")
   int trav_mode_ = 3;   // 1 = LDS-treelet grid-stride kernel, 2 = persistent-thread kernel, 3 = by queue size
   uint32_t pt_split_closest_ = 100000u, pt_split_any_ = 100000u;   // re-tuned with the shadow launches overlapped (tools/band_scaling.py)
   DevBuf<uint32_t> pt_overflow_, pt_overflow_any_;
@@ -791,8 +796,18 @@ class Handle : public HandleBase {
   void scan_materials(const rrt_scene_desc* d) {
     has_transmissive_ = has_translucent_ = false;
     bool transmissive_sphere = false;
+    // Lobe kinds the USED materials can produce (dmath.hpp build_lobes, same conditions): selects the instantiation of the path shading
+    // kernel - the general one unless the set fits a narrower kernel (fp32 product only; a textured parameter can change any of this per hit)
+    uint32_t kinds = 0u;
     for (size_t i = 0; i < d->n_prims; i++) {
       const rrt_material& m = d->materials[d->prims[i].material];
+      bool has_tex = m.bump >= 0;
+      for (int k = 0; k < RRT_P_COUNT; k++) has_tex |= m.tex[k] >= 0;
+      if (has_tex) kinds = kAllKinds;
+      else if (m.type == RRT_MAT_MATTE) kinds |= std::min(std::max(m.sigma, 0.0), 90.0) == 0.0 ? kind_bit(LOBE_LAMBERT) : kind_bit(LOBE_OREN_NAYAR);
+      else if (m.type == RRT_MAT_PLASTIC) kinds |= kind_bit(LOBE_LAMBERT) | kind_bit(LOBE_MICROFACET);
+      else if (m.type == RRT_MAT_METAL) kinds |= kind_bit(LOBE_MICROFACET);
+      else kinds = kAllKinds;
       if (d->prims[i].type == RRT_PRIM_SPHERE && (m.type == RRT_MAT_GLASS || m.type == RRT_MAT_TRANSLUCENT)) transmissive_sphere = true;
       auto black = [](const double* c) { return !(c[0] > 0.0) && !(c[1] > 0.0) && !(c[2] > 0.0); };
       if (m.type == RRT_MAT_GLASS) {
@@ -807,6 +822,12 @@ class Handle : public HandleBase {
     // sphere.rs has no epsilon: a ray spawned on a sphere re-hits it at t ~ 0 on a last-bit coin, and every refraction through a
     // transmissive sphere tosses one. The f64 mode replays the reference's coins; fp32 has its own, and the chain through a glass
     // sphere amplifies them (no fp32 statement is made for such scenes)
+    shade_kinds_scene_ = kAllKinds;
+    if (std::is_same<R, float>::value && kinds != 0u) {
+      if ((kinds & ~kKindsLambert) == 0u) shade_kinds_scene_ = kKindsLambert;
+      else if ((kinds & ~kKindsGlossy) == 0u) shade_kinds_scene_ = kKindsGlossy;
+    }
+    shade_kinds_ = shade_kinds_scene_;
     if (transmissive_sphere && std::is_same<R, float>::value)
       warnings.push_back("RRT_F32: sphere primitives with Glass / Translucent materials - the reference's result depends on last-bit decisions of "
                          "sphere.rs:124-259 (no epsilon) that fp32 cannot replay; no parity is claimed for these pixels, use RRT_F64");

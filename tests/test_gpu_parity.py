@@ -581,6 +581,41 @@ def test_any_hit_entry_nodes_change_nothing(which, workdir):
     assert a[..., :3].max() > 0
 
 
+@pytest.mark.parametrize("which", ["cfg4_lambert", "cfg5_glossy", "cfg2_mixed"])
+def test_shading_kernel_specialisation(which, workdir):
+    """The path shading kernel is instantiated per lobe-kind set (dmath.hpp "Lobe-kind sets"): scenes whose used materials can only produce
+    Lambertian lobes, or Lambertian / Oren-Nayar / microfacet-reflection lobes, run a kernel without the other BxDFs' code and registers; the
+    host picks the set from the materials (rrt_impl.hpp scan_materials()). Same arithmetic per lobe in every instantiation - the compiler may
+    contract multiply-adds differently, so the frames agree to fp32 rounding, not bitwise; weights and query counts are identical - and both
+    hold the fp32 bar against the oracle. cfg2_mixed uses a mirror: only the general kernel fits, the option changes nothing at all."""
+    if which == "cfg4_lambert": cfg, root = scenes.cfg4(workdir, xres=96, yres=96, nsamp=9, max_depth=6, n=64)
+    elif which == "cfg5_glossy": cfg, root = scenes.cfg5(workdir, xres=96, yres=96, nsamp=9, max_depth=8, n=64)
+    else:
+        cfg, root = scenes.cfg2(workdir, xres=96, yres=96, nsamp=9, max_depth=4)
+        for inst in cfg["Aggregate"]["primitives"][0]["instances"]:
+            inst["rotation_axis"] = [1.0, 2.0, 3.0]
+        cfg["Aggregate"]["primitives"].append({"primitive_type": "triangle", "material_name": "mat_mirror", "obj_name": "cube_01",
+                                               "instances": [{"world_pos": [33.0, 0.5, 0.0], "rotation_axis": [1, 2, 3], "rotation_angle": 20}]})
+    sc = Scene.loads(cfg, root, flags=RRT_FIXED_BVH)
+    ref = O.render(sc)
+    scale = np.abs(ref[..., :3]).max()
+    r = Renderer(sc, 0, RRT_F32)
+    spec, st_spec = r.render(stats=True)
+    r.set_option("shade_spec", 0)            # the general kernel
+    gen, st_gen = r.render(stats=True)
+    r.close()
+    assert (st_spec.camera_rays, st_spec.closest_queries, st_spec.any_queries) == (st_gen.camera_rays, st_gen.closest_queries, st_gen.any_queries)
+    assert np.array_equal(spec[..., 3], gen[..., 3])
+    d = np.abs(spec[..., :3].astype(np.float64) - gen[..., :3]).max(-1) / scale
+    if which == "cfg2_mixed":
+        assert np.array_equal(spec, gen)
+    else:
+        assert (d < 1e-6).mean() > 0.995 and np.median(d) < 1e-7, ((d < 1e-6).mean(), d.max())
+    for film in (spec, gen):
+        dd = np.abs(film[..., :3].astype(np.float64) - ref[..., :3]).max(-1) / scale
+        assert (dd < 1e-4).mean() > 0.99 and np.median(dd) < 1e-5, ((dd < 1e-4).mean(), dd.max())
+
+
 def test_camera_halton_block_tables_change_nothing(workdir):
     """The fp32 camera kernel replaces the digit loops of Halton dimensions 1-3 (bases 3, 5, 7; halton.rs:107-128, lowdiscrepancy.rs:188-227)
     by two table look-ups each - the index split into a block of low digits and the rest, SceneDev::cam_lo / cam_hi. Same integers, same f64
