@@ -930,15 +930,21 @@ RRT_DEV uint32_t sample_light_discrete(const SceneDev<R>& s, R u) {
 #ifndef RRT_SHADE_WAVES
 #define RRT_SHADE_WAVES 4
 #endif
+// The Lambert-only instantiation needs 96 VGPRs unforced; measured (shading alone / frame with two in flight, config 4): 4 waves per SIMD
+// 5.87 ms, 5: 5.58 / 37.8, 6: 5.43 / 37.7, 7: 5.35 / 37.6, 8: 5.64; with 512-thread blocks 5: 5.61 / 38.0, 6: 4.92 / 37.4, 7: 5.01 / 37.3; 1024: 6.39.
 #ifndef RRT_SHADE_WAVES_LAMBERT
-#define RRT_SHADE_WAVES_LAMBERT 5   // the Lambert-only instantiation needs 99 VGPRs
+#define RRT_SHADE_WAVES_LAMBERT 6
 #endif
+#ifndef RRT_SHADE_BLOCK_LAMBERT
+#define RRT_SHADE_BLOCK_LAMBERT 512
+#endif
+template <typename R, uint32_t KM> constexpr int shade_path_block() { return (sizeof(R) == 4 && KM == kKindsLambert) ? RRT_SHADE_BLOCK_LAMBERT : ShadeBlock<R>::n; }
 // TEX: the scene has materials that evaluate a texture per hit (SurfExt + ray differentials of the camera ray at bounce 0;
 // `ray = isect.spawn_ray(wi).into()` drops them afterwards, path.rs:163).
 // KM: the lobe kinds the scene's materials can produce (dmath.hpp "Lobe-kind sets"); kAllKinds = the general kernel.
 template <typename R, int NL, bool TEX = false, uint32_t KM = kAllKinds>
-__global__ void __launch_bounds__(ShadeBlock<R>::n) __attribute__((amdgpu_waves_per_eu(TEX ? 1 : (KM == kKindsLambert ? RRT_SHADE_WAVES_LAMBERT : RRT_SHADE_WAVES), 8))) k_shade_path(SceneDev<R> s, Pools<R> p) {
-  __shared__ uint32_t push_lds[ShadeBlock<R>::n / 64 + 1];
+__global__ void __launch_bounds__((shade_path_block<R, KM>())) __attribute__((amdgpu_waves_per_eu(TEX ? 1 : (KM == kKindsLambert ? RRT_SHADE_WAVES_LAMBERT : RRT_SHADE_WAVES), 8))) k_shade_path(SceneDev<R> s, Pools<R> p) {
+  __shared__ uint32_t push_lds[shade_path_block<R, KM>() / 64 + 1];
   const uint32_t n = p.counters[C_ACTIVE];
   using V4 = typename Vec4T<R>::type;
   // a bounded grid walks the queue (block-uniform trip count, as block_push needs): the host does not know the queue

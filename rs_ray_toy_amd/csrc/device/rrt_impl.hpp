@@ -591,7 +591,10 @@ class Handle : public HandleBase {
             e = tick(3);
             if (tex_depth_ > 0) hipLaunchKernelGGL((k_shade_path<R, 4, true>), dim3(std::min((uint32_t)((nslots + 255) / 256), 16384u)), dim3(256), 0, st_, scene_, pool_);
             else if (has_translucent_) hipLaunchKernelGGL((k_shade_path<R, 4>), dim3(std::min((uint32_t)((nslots + 255) / 256), 16384u)), dim3(256), 0, st_, scene_, pool_);
-            else if (shade_kinds_ == kKindsLambert) hipLaunchKernelGGL((k_shade_path<R, 2, false, kKindsLambert>), dim3(std::min(sgrid, 16384u)), dim3(ShadeBlock<R>::n), 0, st_, scene_, pool_);
+            else if (shade_kinds_ == kKindsLambert) {
+              constexpr uint32_t kB = (uint32_t)shade_path_block<R, kKindsLambert>();
+              hipLaunchKernelGGL((k_shade_path<R, 2, false, kKindsLambert>), dim3(std::min((uint32_t)((nslots + kB - 1) / kB), 16384u)), dim3(kB), 0, st_, scene_, pool_);
+            }
             else if (shade_kinds_ == kKindsGlossy) hipLaunchKernelGGL((k_shade_path<R, 2, false, kKindsGlossy>), dim3(std::min(sgrid, 16384u)), dim3(ShadeBlock<R>::n), 0, st_, scene_, pool_);
             else hipLaunchKernelGGL((k_shade_path<R, 2>), dim3(std::min(sgrid, 16384u)), dim3(ShadeBlock<R>::n), 0, st_, scene_, pool_);
             tock(e);

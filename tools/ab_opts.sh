@@ -8,6 +8,6 @@ for spec in "$@"; do
 import json, sys
 d = json.load(open("gpurun_out/ab_tmp.json"))
 k = d["kernel_ms_per_frame"]; r = d["roofline"]
-print(f"{sys.argv[1]:44s} frame {d['ms_per_step']:7.3f} ms  closest {k['ms_closest']:6.2f} (alone {r['alone_avg_launch_ms'] * r['launches']:6.2f})  any {k['ms_any']:6.2f}  raygen {k['ms_raygen']:6.2f}  shade {k['ms_shade']:5.2f}")
+print(f"{sys.argv[1]:44s} frame {d['ms_per_step']:7.3f} ms  closest {k['ms_closest']:6.2f} (alone {r['alone']['avg_launch_ms'] * r['launches']:6.2f})  any {k['ms_any']:6.2f}  raygen {k['ms_raygen']:6.2f}  shade {k['ms_shade']:5.2f}")
 PY
 done
