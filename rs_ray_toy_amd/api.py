@@ -157,6 +157,10 @@ class Renderer:
         hits = A.Hits(A.RRT_MEM_DEVICE, self.precision, t_ptr, prim_ptr, u_ptr, v_ptr, None, None)
         _check(A.lib().rrt_trace_closest(self._h, C.byref(rays), n, C.byref(hits)))
 
+    def trace_any_device(self, ptrs7, n, occluded_ptr, skip_ptr=None):
+        rays = A.Rays(A.RRT_MEM_DEVICE, self.precision, *ptrs7, skip_ptr)
+        _check(A.lib().rrt_trace_any(self._h, C.byref(rays), n, occluded_ptr))
+
     def camera_samples(self, rect, s0, s1):
         x0, y0, x1, y1 = rect
         n = (x1 - x0) * (y1 - y0) * (s1 - s0)

@@ -801,8 +801,9 @@ RRT_DEV bool build_bsdf_tex(const SceneDev<R>& s, Surf<R>& si, const SurfExt<R>&
 
 // Light::sample_li for PointLight (point.rs:55-77) and DiffuseAreaLight (diffuse.rs:63-79) over
 // Shape::sample_ref (shape/mod.rs:33-48), Sphere::sample (sphere.rs:265-285), Triangle::sample (triangle.rs:393-418)
-template <typename R>
+template <typename R, bool AREA = true>
 RRT_DEV Rgb<R> light_sample_li(const Light<R>& L, V3<R> ref_p, R u0, R u1, V3<R>* wi, R* pdf, V3<R>* p1, V3<R>* n1) {
+  if (!AREA && L.type != 0 && L.type != 2) __builtin_unreachable();   // (instantiation for scenes whose lights are all point / distant: the host checks, rrt_impl.hpp)
   if (L.type == 0) {
     V3<R> pl(L.p_light);
     *wi = vnormalize(pl - ref_p);
@@ -892,12 +893,12 @@ RRT_DEV bool sphere_hit_for_pdf(const Light<R>& L, V3<R> ro, V3<R> rd, V3<R>* p_
 // Returns true and fills the shadow ray + contribution when a visibility test is needed.
 // The BSDF-sampling half (:483-556) can only add `li * f * weight / pdf` with li = 0 (no primitive carries an
 // area light, Q18; DiffuseAreaLight::le is the trait default 0), so it is not executed: see DESIGN.md.
-template <typename R, int NL, uint32_t KM>
+template <bool AREA = true, typename R, int NL, uint32_t KM>
 RRT_DEV bool estimate_direct_light(const Surf<R>& si, const Bsdf<R, NL, KM>& bsdf, const Light<R>& L, R ul0, R ul1, V3<R>* so, V3<R>* sd, Rgb<R>* ld) {
   const uint32_t flags = BXDF_ALL & ~BXDF_SPECULAR;
   V3<R> wi, p1, n1;
   R light_pdf = R(0);
-  Rgb<R> li = light_sample_li(L, si.p, ul0, ul1, &wi, &light_pdf, &p1, &n1);
+  Rgb<R> li = light_sample_li<R, AREA>(L, si.p, ul0, ul1, &wi, &light_pdf, &p1, &n1);
   if (!(light_pdf > R(0)) || li.is_black()) return false;
   Rgb<R> f = bsdf.f(si.wo, wi, flags) * absdot(wi, si.sn);
   R scattering_pdf = bsdf.pdf(si.wo, wi, flags);
@@ -906,7 +907,7 @@ RRT_DEV bool estimate_direct_light(const Surf<R>& si, const Bsdf<R, NL, KM>& bsd
   // and keeps t_max = 1 - SHADOW_EPSILON (Q9)
   *so = si.p;
   *sd = vnormalize(p1 - si.p);
-  if (L.type != 1) *ld = f * li / light_pdf;   // delta lights (point, distant): no MIS
+  if (!AREA || L.type != 1) *ld = f * li / light_pdf;   // delta lights (point, distant): no MIS
   else { R w = power_heuristic1(light_pdf, scattering_pdf); *ld = li * f * w / light_pdf; }
   return true;
 }
@@ -942,7 +943,8 @@ template <typename R, uint32_t KM> constexpr int shade_path_block() { return (si
 // TEX: the scene has materials that evaluate a texture per hit (SurfExt + ray differentials of the camera ray at bounce 0;
 // `ray = isect.spawn_ray(wi).into()` drops them afterwards, path.rs:163).
 // KM: the lobe kinds the scene's materials can produce (dmath.hpp "Lobe-kind sets"); kAllKinds = the general kernel.
-template <typename R, int NL, bool TEX = false, uint32_t KM = kAllKinds>
+// AREA = false: every light of the scene is a point or distant light (no area-light sampling code, no light sample dimensions drawn).
+template <typename R, int NL, bool TEX = false, uint32_t KM = kAllKinds, bool AREA = true>
 __global__ void __launch_bounds__((shade_path_block<R, KM>())) __attribute__((amdgpu_waves_per_eu(TEX ? 1 : (KM == kKindsLambert ? RRT_SHADE_WAVES_LAMBERT : RRT_SHADE_WAVES), 8))) k_shade_path(SceneDev<R> s, Pools<R> p) {
   __shared__ uint32_t push_lds[shade_path_block<R, KM>() / 64 + 1];
   const uint32_t n = p.counters[C_ACTIVE];
@@ -998,13 +1000,13 @@ __global__ void __launch_bounds__((shade_path_block<R, KM>())) __attribute__((am
           uint32_t ln = 0;
           if (s.n_lights == 1u) skip_1d(s, &dim);
           else ln = sample_light_discrete(s, to_real<R>(draw_1d(s, index, &dim)));
-          if (s.lights[ln].type != 1) skip_2d(s, &dim);
+          if (!AREA || s.lights[ln].type != 1) skip_2d(s, &dim);
           else draw_2d(s, index, &dim, &du0, &du1);
           R ul0 = to_real<R>(du0), ul1 = to_real<R>(du1);
           skip_2d(s, &dim);  // u_scattering: drawn, only used by the BSDF-sampling half
           V3<R> so, sd;
           Rgb<R> ld;
-          if (s.light_pick_pdf != R(0) && estimate_direct_light(si, bsdf, s.lights[ln], ul0, ul1, &so, &sd, &ld)) {
+          if (s.light_pick_pdf != R(0) && estimate_direct_light<AREA>(si, bsdf, s.lights[ln], ul0, ul1, &so, &sd, &ld)) {
             sh_ld = beta * (ld / s.light_pick_pdf);
             sh_o = so; sh_d = sd;
             want_shadow = true;

@@ -593,7 +593,9 @@ class Handle : public HandleBase {
             else if (has_translucent_) hipLaunchKernelGGL((k_shade_path<R, 4>), dim3(std::min((uint32_t)((nslots + 255) / 256), 16384u)), dim3(256), 0, st_, scene_, pool_);
             else if (shade_kinds_ == kKindsLambert) {
               constexpr uint32_t kB = (uint32_t)shade_path_block<R, kKindsLambert>();
-              hipLaunchKernelGGL((k_shade_path<R, 2, false, kKindsLambert>), dim3(std::min((uint32_t)((nslots + kB - 1) / kB), 16384u)), dim3(kB), 0, st_, scene_, pool_);
+              const dim3 g(std::min((uint32_t)((nslots + kB - 1) / kB), 16384u));
+              if (area_lights_ || shade_kinds_ == kAllKinds) hipLaunchKernelGGL((k_shade_path<R, 2, false, kKindsLambert, true>), g, dim3(kB), 0, st_, scene_, pool_);
+              else hipLaunchKernelGGL((k_shade_path<R, 2, false, kKindsLambert, false>), g, dim3(kB), 0, st_, scene_, pool_);
             }
             else if (shade_kinds_ == kKindsGlossy) hipLaunchKernelGGL((k_shade_path<R, 2, false, kKindsGlossy>), dim3(std::min(sgrid, 16384u)), dim3(ShadeBlock<R>::n), 0, st_, scene_, pool_);
             else hipLaunchKernelGGL((k_shade_path<R, 2>), dim3(std::min(sgrid, 16384u)), dim3(ShadeBlock<R>::n), 0, st_, scene_, pool_);
@@ -749,6 +751,7 @@ class Handle : public HandleBase {
   uint32_t trav_grid_ = 0, pt_grid_ = 0;
   int raygen_pt_ = 2;
   bool has_transmissive_ = false, has_translucent_ = false;
+  bool area_lights_ = true;   // some light is a DiffuseAreaLight (else the Lambert shading kernel drops the area-light code)
   uint32_t shade_kinds_scene_ = kAllKinds, shade_kinds_ = kAllKinds;   // lobe-kind set of the scene's materials / of the shading kernel in use (option "shade_spec")
   int trav_mode_ = 3;   // 1 = LDS-treelet grid-stride kernel, 2 = persistent-thread kernel, 3 = by queue size
   uint32_t pt_split_closest_ = 100000u, pt_split_any_ = 100000u;   // re-tuned with the shadow launches overlapped (tools/band_scaling.py)
@@ -825,6 +828,8 @@ class Handle : public HandleBase {
     // sphere.rs has no epsilon: a ray spawned on a sphere re-hits it at t ~ 0 on a last-bit coin, and every refraction through a
     // transmissive sphere tosses one. The f64 mode replays the reference's coins; fp32 has its own, and the chain through a glass
     // sphere amplifies them (no fp32 statement is made for such scenes)
+    area_lights_ = false;
+    for (size_t i = 0; i < d->n_lights; i++) area_lights_ |= d->lights[i].type == RRT_LIGHT_DIFFUSE;
     shade_kinds_scene_ = kAllKinds;
     if (std::is_same<R, float>::value && kinds != 0u) {
       if ((kinds & ~kKindsLambert) == 0u) shade_kinds_scene_ = kKindsLambert;

@@ -85,10 +85,79 @@ def bench(perm, label, reps=10):
     torch.cuda.synchronize()
     dt = (time.perf_counter() - t0) / reps
     return dt, tp.cpu().numpy()
+def bench_any(perm, reps=10):
+    """shadow rays of the same vertices towards the point lights (all at the world origin, Q17): unit direction, t_max = 1 - 1e-4 (Q9)"""
+    oo = p[perm]
+    dd = -oo / np.linalg.norm(oo, axis=1, keepdims=True)
+    sk = skip[perm]
+    t7 = [torch.from_numpy(np.ascontiguousarray(a)).to(dev) for a in (oo[:, 0], oo[:, 1], oo[:, 2], dd[:, 0], dd[:, 1], dd[:, 2], np.full(n, 1.0 - 1e-4, np.float32))]
+    tsk = torch.from_numpy(np.ascontiguousarray(sk)).to(dev)
+    occ = torch.empty(n, dtype=torch.uint8, device=dev)
+    ptrs = [t.data_ptr() for t in t7]
+    for _ in range(2):
+        r.trace_any_device(ptrs, n, occ.data_ptr(), tsk.data_ptr())
+    torch.cuda.synchronize()
+    t0 = time.perf_counter()
+    for _ in range(reps):
+        r.trace_any_device(ptrs, n, occ.data_ptr(), tsk.data_ptr())
+    torch.cuda.synchronize()
+    return (time.perf_counter() - t0) / reps, occ.cpu().numpy()
 base = None
+base_any = None
+for label, perm in orders.items():
+    if "65536" in label or "4096" in label: continue
+    dt, occ = bench_any(perm)
+    inv = np.empty(n, np.int64); inv[perm] = np.arange(n)
+    occ = occ[inv]
+    if base_any is None: base_any = occ
+    print(f"any-hit  {label:50s} {dt * 1e3:8.3f} ms  {n / dt / 1e9:6.3f} Grays/s   occluded {occ.mean():.3f}, same bits as image order: {np.array_equal(occ, base_any)}")
 for label, perm in orders.items():
     dt, prim = bench(perm, label)
     inv = np.empty(n, np.int64); inv[perm] = np.arange(n)
     prim = prim[inv]
     if base is None: base = prim
     print(f"{label:50s} {dt * 1e3:8.3f} ms  {n / dt / 1e9:6.3f} Grays/s   same winners as image order: {np.array_equal(prim, base)}")
+
+# ---- deeper bounces: origins scattered over the scene (the vertices the diffuse-bounce rays above reach), queue still in image order ----
+print("--- bounce >= 2: origins = where the diffuse-bounce rays land (scattered), in the image order of their camera samples ---")
+t7 = [torch.from_numpy(np.ascontiguousarray(a)).to(dev) for a in (p[:, 0], p[:, 1], p[:, 2], d2[:, 0], d2[:, 1], d2[:, 2], np.full(n, np.inf, np.float32))]
+tt = torch.empty(n, dtype=torch.float32, device=dev); tp = torch.empty(n, dtype=torch.int32, device=dev)
+r.trace_closest_device([t.data_ptr() for t in t7], n, tt.data_ptr(), tp.data_ptr())
+torch.cuda.synchronize()
+t_hit, prim2 = tt.cpu().numpy(), tp.cpu().numpy()
+hit2 = prim2 >= 0
+p = (p[hit2] + d2[hit2] * t_hit[hit2, None]).astype(np.float32)
+skip = prim2[hit2].astype(np.int32)
+n = len(p)
+d2 = rng.normal(size=(n, 3)).astype(np.float32); d2 /= np.linalg.norm(d2, axis=1, keepdims=True)
+d2[:, 1] = np.abs(d2[:, 1])
+print("rays:", n)
+octant = ((d2[:, 0] < 0).astype(np.uint32) | ((d2[:, 1] < 0).astype(np.uint32) << 1) | ((d2[:, 2] < 0).astype(np.uint32) << 2))
+mort = morton(p)
+def cell_sort(bits, block):
+    """origin cell (top `bits` bits of the 30-bit morton code) inside blocks of `block` rays: what a counting sort at push time could do"""
+    key = mort >> (30 - bits)
+    out = []
+    for b in range(0, n, block):
+        out.append(b + np.argsort(key[b:b + block], kind="stable"))
+    return np.concatenate(out)
+orders = {
+    "image order (as pushed)": np.arange(n),
+    "origin morton (global sort)": np.argsort(mort, kind="stable"),
+    "octant, then origin morton (global)": np.lexsort((mort, octant)),
+    "origin cell 12 bits, global": np.argsort(mort >> 18, kind="stable"),
+    "origin cell 9 bits, global": np.argsort(mort >> 21, kind="stable"),
+    "origin cell 12 bits inside 1M-ray blocks": cell_sort(12, 1 << 20),
+    "origin cell 9 bits inside 64K-ray blocks": cell_sort(9, 1 << 16),
+    "random shuffle": rng.permutation(n),
+}
+base = base_any = None
+for label, perm in orders.items():
+    dt, occ = bench_any(perm)
+    inv = np.empty(n, np.int64); inv[perm] = np.arange(n)
+    occ = occ[inv]
+    if base_any is None: base_any = occ
+    dt2, prim = bench(perm, label)
+    prim = prim[inv]
+    if base is None: base = prim
+    print(f"{label:44s} any-hit {dt * 1e3:7.3f} ms ({np.array_equal(occ, base_any)})   closest-hit {dt2 * 1e3:7.3f} ms ({np.array_equal(prim, base)})")
