@@ -939,13 +939,22 @@ RRT_DEV uint32_t sample_light_discrete(const SceneDev<R>& s, R u) {
 #ifndef RRT_SHADE_BLOCK_LAMBERT
 #define RRT_SHADE_BLOCK_LAMBERT 512
 #endif
-template <typename R, uint32_t KM> constexpr int shade_path_block() { return (sizeof(R) == 4 && KM == kKindsLambert) ? RRT_SHADE_BLOCK_LAMBERT : ShadeBlock<R>::n; }
+#ifndef RRT_SHADE_WAVES_GLOSSY
+#define RRT_SHADE_WAVES_GLOSSY RRT_SHADE_WAVES
+#endif
+#ifndef RRT_SHADE_BLOCK_GLOSSY
+#define RRT_SHADE_BLOCK_GLOSSY RRT_SHADE_BLOCK
+#endif
+template <typename R, uint32_t KM> constexpr int shade_path_block() {
+  return sizeof(R) != 4 ? ShadeBlock<R>::n : (KM == kKindsLambert ? RRT_SHADE_BLOCK_LAMBERT : (KM == kKindsGlossy ? RRT_SHADE_BLOCK_GLOSSY : ShadeBlock<R>::n));
+}
+template <uint32_t KM> constexpr int shade_path_waves() { return KM == kKindsLambert ? RRT_SHADE_WAVES_LAMBERT : (KM == kKindsGlossy ? RRT_SHADE_WAVES_GLOSSY : RRT_SHADE_WAVES); }
 // TEX: the scene has materials that evaluate a texture per hit (SurfExt + ray differentials of the camera ray at bounce 0;
 // `ray = isect.spawn_ray(wi).into()` drops them afterwards, path.rs:163).
 // KM: the lobe kinds the scene's materials can produce (dmath.hpp "Lobe-kind sets"); kAllKinds = the general kernel.
 // AREA = false: every light of the scene is a point or distant light (no area-light sampling code, no light sample dimensions drawn).
 template <typename R, int NL, bool TEX = false, uint32_t KM = kAllKinds, bool AREA = true>
-__global__ void __launch_bounds__((shade_path_block<R, KM>())) __attribute__((amdgpu_waves_per_eu(TEX ? 1 : (KM == kKindsLambert ? RRT_SHADE_WAVES_LAMBERT : RRT_SHADE_WAVES), 8))) k_shade_path(SceneDev<R> s, Pools<R> p) {
+__global__ void __launch_bounds__((shade_path_block<R, KM>())) __attribute__((amdgpu_waves_per_eu(TEX ? 1 : shade_path_waves<KM>(), 8))) k_shade_path(SceneDev<R> s, Pools<R> p) {
   __shared__ uint32_t push_lds[shade_path_block<R, KM>() / 64 + 1];
   const uint32_t n = p.counters[C_ACTIVE];
   using V4 = typename Vec4T<R>::type;

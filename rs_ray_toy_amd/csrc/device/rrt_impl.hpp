@@ -597,7 +597,10 @@ class Handle : public HandleBase {
               if (area_lights_ || shade_kinds_ == kAllKinds) hipLaunchKernelGGL((k_shade_path<R, 2, false, kKindsLambert, true>), g, dim3(kB), 0, st_, scene_, pool_);
               else hipLaunchKernelGGL((k_shade_path<R, 2, false, kKindsLambert, false>), g, dim3(kB), 0, st_, scene_, pool_);
             }
-            else if (shade_kinds_ == kKindsGlossy) hipLaunchKernelGGL((k_shade_path<R, 2, false, kKindsGlossy>), dim3(std::min(sgrid, 16384u)), dim3(ShadeBlock<R>::n), 0, st_, scene_, pool_);
+            else if (shade_kinds_ == kKindsGlossy) {
+              constexpr uint32_t kB = (uint32_t)shade_path_block<R, kKindsGlossy>();
+              hipLaunchKernelGGL((k_shade_path<R, 2, false, kKindsGlossy>), dim3(std::min((uint32_t)((nslots + kB - 1) / kB), 16384u)), dim3(kB), 0, st_, scene_, pool_);
+            }
             else hipLaunchKernelGGL((k_shade_path<R, 2>), dim3(std::min(sgrid, 16384u)), dim3(ShadeBlock<R>::n), 0, st_, scene_, pool_);
             tock(e);
             if (overlap) {
