@@ -1386,6 +1386,21 @@ class Handle : public HandleBase {
       const uint32_t split = any ? pt_split_any_ : pt_split_closest_;
       const uint32_t lo_pt = trav_mode_ == 2 ? 0u : (trav_mode_ == 1 ? 0xffffffffu : split);
       const uint32_t hi_gs = trav_mode_ == 1 ? 0xffffffffu : (trav_mode_ == 2 ? 0u : split);
+      // The grid-stride kernel goes FIRST. Both kernels are launched for every queue and the one whose regime it is not returns at once - but
+      // even a no-op workgroup needs its LDS to be scheduled, and a no-op launched BEHIND the persistent kernel found the chip held by the
+      // other stream's persistent launch (the shadow rays of the previous bounce): rocprofv3 showed the empty k_trace_pairs_f32<false> of bounce
+      // 1 waiting 3.5 ms for the any-hit launch of bounce 0 to drain, on the critical path of a frame rendered alone. In front, it is
+      // dispatched while the chip is still filling. Its grid is no larger than its regime needs.
+      if (trav_mode_ != 2) {
+        if (trav_mode_ == 3) grid = std::max(1u, std::min(grid, (split + kTravBlock - 1) / kTravBlock));
+        if (mixed_) {
+          if (any) hipLaunchKernelGGL((k_trace_pairs_f32<true, true>), dim3(grid), dim3(kTravBlock), 0, stream, trav_, pool_, queue, count, n_fixed, occluded, 0u, hi_gs);
+          else hipLaunchKernelGGL((k_trace_pairs_f32<false, true>), dim3(grid), dim3(kTravBlock), 0, stream, trav_, pool_, queue, count, n_fixed, occluded, 0u, hi_gs);
+        } else {
+          if (any) hipLaunchKernelGGL((k_trace_pairs_f32<true, false>), dim3(grid), dim3(kTravBlock), 0, stream, trav_, pool_, queue, count, n_fixed, occluded, 0u, hi_gs);
+          else hipLaunchKernelGGL((k_trace_pairs_f32<false, false>), dim3(grid), dim3(kTravBlock), 0, stream, trav_, pool_, queue, count, n_fixed, occluded, 0u, hi_gs);
+        }
+      }
       if (trav_mode_ != 1) {
         if (pt_grid_ == 0) {
           int per_cu = 0, cus = 0;
@@ -1407,15 +1422,6 @@ class Handle : public HandleBase {
         } else {
           if (any) hipLaunchKernelGGL((k_trace_pt_f32<true, false>), dim3(g2), dim3(kPtBlock), 0, stream, t2, pool_, queue, count, n_fixed, work, occluded, lo_pt, 0xffffffffu);
           else hipLaunchKernelGGL((k_trace_pt_f32<false, false>), dim3(g2), dim3(kPtBlock), 0, stream, t2, pool_, queue, count, n_fixed, work, occluded, lo_pt, 0xffffffffu);
-        }
-      }
-      if (trav_mode_ != 2) {
-        if (mixed_) {
-          if (any) hipLaunchKernelGGL((k_trace_pairs_f32<true, true>), dim3(grid), dim3(kTravBlock), 0, stream, trav_, pool_, queue, count, n_fixed, occluded, 0u, hi_gs);
-          else hipLaunchKernelGGL((k_trace_pairs_f32<false, true>), dim3(grid), dim3(kTravBlock), 0, stream, trav_, pool_, queue, count, n_fixed, occluded, 0u, hi_gs);
-        } else {
-          if (any) hipLaunchKernelGGL((k_trace_pairs_f32<true, false>), dim3(grid), dim3(kTravBlock), 0, stream, trav_, pool_, queue, count, n_fixed, occluded, 0u, hi_gs);
-          else hipLaunchKernelGGL((k_trace_pairs_f32<false, false>), dim3(grid), dim3(kTravBlock), 0, stream, trav_, pool_, queue, count, n_fixed, occluded, 0u, hi_gs);
         }
       }
       HIP_CHECK(hipGetLastError());
