@@ -494,10 +494,25 @@ struct PassDesc {
   uint32_t s_begin, ns;        // sample_num range [s_begin, s_begin + ns)
   // interleaved row bands (multi-GPU film partition): local row r -> y = ry0 + ((r / band_h) * n_ranks + rank) * band_h + r % band_h
   uint32_t band_h, n_ranks, rank;
+  // tiled = 1: the (local row, x) grid is enumerated tile by tile (kTileW x kTileH = 512 pixels: one workgroup of the dense camera kernel),
+  // row-major inside a tile and over the tiles, instead of row by row - the host sets it when the width is a multiple of kTileW and the
+  // number of local rows a multiple of kTileH. Neighbouring queue entries are then neighbours in BOTH image directions: the rays a wave
+  // holds cross a compact patch of the scene instead of a strip half an image row long.
+  uint32_t tiled;
 };
+#ifndef RRT_TILE_W
+#define RRT_TILE_W 32u
+#define RRT_TILE_H 16u
+#endif
+constexpr uint32_t kTileW = RRT_TILE_W, kTileH = RRT_TILE_H;
 RRT_DEV void pass_pixel(const PassDesc& pd, uint32_t lin, uint32_t* px, uint32_t* py) {
-  const uint32_t row = lin / (uint32_t)pd.rw;
-  *px = (uint32_t)pd.rx0 + lin % (uint32_t)pd.rw;
+  uint32_t row = lin / (uint32_t)pd.rw, col = lin % (uint32_t)pd.rw;
+  if (pd.tiled) {
+    const uint32_t tile = lin / (kTileW * kTileH), within = lin % (kTileW * kTileH), tiles_per_row = (uint32_t)pd.rw / kTileW;
+    col = (tile % tiles_per_row) * kTileW + within % kTileW;
+    row = (tile / tiles_per_row) * kTileH + within / kTileW;
+  }
+  *px = (uint32_t)pd.rx0 + col;
   *py = (uint32_t)pd.ry0 + ((row / pd.band_h) * pd.n_ranks + pd.rank) * pd.band_h + row % pd.band_h;
 }
 
@@ -1439,8 +1454,9 @@ RRT_DEV bool pass_pixel_inverse(const PassDesc& pd, int x, int y, uint32_t* pl) 
   if (x < pd.rx0 || x >= pd.rx0 + pd.rw || y < pd.ry0) return false;
   const uint32_t yy = (uint32_t)(y - pd.ry0), band = yy / pd.band_h;
   if (band % pd.n_ranks != pd.rank) return false;
-  const uint32_t row = (band / pd.n_ranks) * pd.band_h + yy % pd.band_h;
-  const uint64_t lin = (uint64_t)row * (uint32_t)pd.rw + (uint32_t)(x - pd.rx0);
+  const uint32_t row = (band / pd.n_ranks) * pd.band_h + yy % pd.band_h, col = (uint32_t)(x - pd.rx0);
+  uint64_t lin = (uint64_t)row * (uint32_t)pd.rw + col;
+  if (pd.tiled) lin = ((uint64_t)(row / kTileH) * ((uint32_t)pd.rw / kTileW) + col / kTileW) * (kTileW * kTileH) + (row % kTileH) * kTileW + col % kTileW;
   if (lin < pd.pix_begin || lin >= (uint64_t)pd.pix_begin + pd.npix) return false;
   *pl = (uint32_t)(lin - pd.pix_begin);
   return true;

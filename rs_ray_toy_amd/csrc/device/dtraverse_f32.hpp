@@ -126,8 +126,7 @@ RRT_DEV PairHit pair_slabs_f32(const float4 a, const float4 b, const float4 c, c
 // differences are of the size |O - p| * edge, so the barycentrics they imply are good to 2 % only on the 100k-triangle mesh against
 // Moller-Trumbore's 3e-5: full-size fp32 parity fell from 98.4 % to 68.6 % of the pixels within 1e-4. DESIGN.md section 4.)
 template <bool ANY>
-RRT_DEV bool tri_test_f32(const float* tp, const LaneRay& r, float* th, float* uh, float* vh) {
-  const F4 q0 = ld4(tp), q1 = ld4(tp + 4), q2 = ld4(tp + 8);
+RRT_DEV bool tri_test_vals_f32(const F4 q0, const F4 q1, const F4 q2, const LaneRay& r, float* th, float* uh, float* vh) {
   const V3<float> p0(q0.x, q0.y, q0.z), p1(q0.w, q1.x, q1.y), p2(q1.z, q1.w, q2.x);
   const V3<float> D(r.dx, r.dy, r.dz), O(r.oxy.x, r.oxy.y, r.ozz.x);
   const V3<float> E1 = p1 - p0, E2 = ANY ? (p2 - p1) : (p2 - p0);
@@ -144,6 +143,10 @@ RRT_DEV bool tri_test_f32(const float* tp, const LaneRay& r, float* th, float* u
                       ((u + v) > 1.0f) | (tt < 0.0000001f);
   *th = tt; *uh = u; *vh = v;
   return !reject;
+}
+template <bool ANY>
+RRT_DEV bool tri_test_f32(const float* tp, const LaneRay& r, float* th, float* uh, float* vh) {
+  return tri_test_vals_f32<ANY>(ld4(tp), ld4(tp + 4), ld4(tp + 8), r, th, uh, vh);
 }
 
 struct TravScene {

@@ -361,6 +361,7 @@ class Handle : public HandleBase {
     else if (key == "count_traversal") count_traversal_ = v != 0;
     else if (key == "persistent_traversal") { persistent_ = v != 0; if (v >= 1) trav_mode_ = (int)v; }
     else if (key == "raygen_pt") raygen_pt_ = v != 0 ? 2 : 0;   // 0: generic two-stage kernels (the reference's operation order), otherwise (default): dense two-stage kernels with the lean lens arithmetic
+    else if (key == "tile_order") tile_order_ = v != 0;
     else if (key == "pt_split_closest") pt_split_closest_ = (uint32_t)v;
     else if (key == "pt_split_any") pt_split_any_ = (uint32_t)v;
     else if (key == "overlap_shadow") overlap_shadow_ = v != 0;
@@ -439,7 +440,7 @@ class Handle : public HandleBase {
     ensure_pools(n);
     DevBuf<double> dd, dr, dw;
     dd.alloc(5 * n); dr.alloc(6 * n); dw.alloc(n);
-    PassDesc pd{rect[0], rect[1], rect[2] - rect[0], 0u, (uint32_t)npix, (uint32_t)s0, (uint32_t)ns, 1u << 30, 1u, 0u};
+    PassDesc pd{rect[0], rect[1], rect[2] - rect[0], 0u, (uint32_t)npix, (uint32_t)s0, (uint32_t)ns, 1u << 30, 1u, 0u, 0u};
     hipLaunchKernelGGL(k_rotate, dim3(1), dim3(1), 0, st_, counters_.p, 2);
     const uint32_t g = (uint32_t)((n + kBlock - 1) / kBlock);
     launch_raygen(pd, g, dd.p, 1);
@@ -563,7 +564,9 @@ class Handle : public HandleBase {
       const size_t npix = std::min(group, rpix - g0);
       for (uint64_t sb = 0; sb < s_total; sb += s_chunk) {
         const uint64_t ns = std::min<uint64_t>(s_chunk, s_total - sb);
-        PassDesc pd{rect[0], rect[1], (int32_t)rw, (uint32_t)g0, (uint32_t)npix, (uint32_t)(1 + sb), (uint32_t)ns, band_h, n_ranks, rank};
+        // tile order of the pixels (PassDesc::tiled) where the rect allows it: whole kTileW x kTileH tiles
+        const uint32_t tiled = (tile_order_ && rw % kTileW == 0 && rh % kTileH == 0) ? 1u : 0u;
+        PassDesc pd{rect[0], rect[1], (int32_t)rw, (uint32_t)g0, (uint32_t)npix, (uint32_t)(1 + sb), (uint32_t)ns, band_h, n_ranks, rank, tiled};
         const size_t nslots = npix * (size_t)ns;
         const uint32_t grid = (uint32_t)((nslots + kBlock - 1) / kBlock);
         const uint32_t sgrid = (uint32_t)((nslots + ShadeBlock<R>::n - 1) / ShadeBlock<R>::n);
@@ -752,6 +755,7 @@ class Handle : public HandleBase {
   bool pairs_ok_ = false;
   bool mixed_ = false;   // the tree has kSpecialLeaf leaves (spheres, kept instances): the MIXED instantiations of the pair-node kernels
   uint32_t trav_grid_ = 0, pt_grid_ = 0;
+  bool tile_order_ = true;  // option "tile_order": pixels of a pass enumerated tile by tile (PassDesc::tiled)
   int raygen_pt_ = 2;
   bool has_transmissive_ = false, has_translucent_ = false;
   bool area_lights_ = true;   // some light is a DiffuseAreaLight (else the Lambert shading kernel drops the area-light code)
