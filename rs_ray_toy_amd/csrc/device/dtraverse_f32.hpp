@@ -720,7 +720,7 @@ constexpr int kRgRepack = RRT_RG_REPACK;   // lens interfaces traced before the 
 // staging records live in the next-queue arrays, which are free until the first shading launch:
 //   nray_o[i] = {o.xyz (world), slot}, nray_d[i] = {d.xyz (world), weight}, npath[i] = {p_film.xy, p_lens.xy}, hindex[i] = Halton index
 static __global__ void __launch_bounds__(kRgDense) k_raygen_main_f32(SceneDev<float> s, Pools<float> p, PassDesc pd, int write_samp, double* dims_out,
-                                                                     const float2* safe_lim, float aux_delta, float aux_pupil, int enqueue) {
+                                                                     const float2* safe_lim, float aux_delta, float aux_pupil, int enqueue, uint32_t spb) {
   __shared__ RgLensLds lens;
   __shared__ float2 safe_s[32];
   __shared__ uint32_t push_lds[kRgDense / 64 + 1];
@@ -730,12 +730,14 @@ static __global__ void __launch_bounds__(kRgDense) k_raygen_main_f32(SceneDev<fl
   __syncthreads();
   // grid: x = sample of the pass, (y, z) = pixel block - blocks are dispatched x first, so the survivors reach the queue pixel block by pixel
   // block (all samples of 512 neighbouring pixels together): the queue is in image order, which the XCD-aware traversal relies on
-  const uint32_t pl = (blockIdx.z * gridDim.y + blockIdx.y) * blockDim.x + tid, sl = blockIdx.x;
+  // A block is kRgPix pixels x (kRgDense / kRgPix) consecutive samples (spb: samples per block, a kernel argument: 1 = one sample of kRgDense pixels)
+  const uint32_t ppb = blockDim.x / spb;   // pixels per block
+  const uint32_t pl = (blockIdx.z * gridDim.y + blockIdx.y) * ppb + tid % ppb, sl = blockIdx.x * spb + tid / ppb;
   bool alive = false;
   uint32_t slot = 0, index = 0;
   float pfx = 0, pfy = 0, lx = 0, ly = 0, w = 0;
   RgLane L; L.i = -1; L.phase = 0; L.element_z = 0;
-  if (pl < pd.npix) {
+  if (pl < pd.npix && sl < pd.ns) {
     slot = sl * pd.npix + pl;
     const uint2 po = reinterpret_cast<const uint2*>(p.pix_off)[pl];
     const uint32_t px = po.y & 0xffffu, py = po.y >> 16;

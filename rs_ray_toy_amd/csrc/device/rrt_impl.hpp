@@ -362,6 +362,7 @@ class Handle : public HandleBase {
     else if (key == "persistent_traversal") { persistent_ = v != 0; if (v >= 1) trav_mode_ = (int)v; }
     else if (key == "raygen_pt") raygen_pt_ = v != 0 ? 2 : 0;   // 0: generic two-stage kernels (the reference's operation order), otherwise (default): dense two-stage kernels with the lean lens arithmetic
     else if (key == "tile_order") tile_order_ = v != 0;
+    else if (key == "rg_spb") rg_spb_ = (int)v;
     else if (key == "pt_split_closest") pt_split_closest_ = (uint32_t)v;
     else if (key == "pt_split_any") pt_split_any_ = (uint32_t)v;
     else if (key == "overlap_shadow") overlap_shadow_ = v != 0;
@@ -755,6 +756,7 @@ class Handle : public HandleBase {
   bool pairs_ok_ = false;
   bool mixed_ = false;   // the tree has kSpecialLeaf leaves (spheres, kept instances): the MIXED instantiations of the pair-node kernels
   uint32_t trav_grid_ = 0, pt_grid_ = 0;
+  int rg_spb_ = 8;          // option "rg_spb": samples per workgroup of the dense camera kernel (the workgroup's 512 threads = 512 / spb pixels x spb samples)
   bool tile_order_ = true;  // option "tile_order": pixels of a pass enumerated tile by tile (PassDesc::tiled)
   int raygen_pt_ = 2;
   bool has_transmissive_ = false, has_translucent_ = false;
@@ -1347,8 +1349,10 @@ class Handle : public HandleBase {
         {   // dense two-stage version with the lean lens arithmetic
           const float2* safe_r2 = (aux_margin_ && tex_depth_ == 0) ? reinterpret_cast<const float2*>(lens_safe_.p) : nullptr;   // textured scenes keep the auxiliary rays themselves (ray differentials)
           // pixel blocks over grid y and z (a grid dimension holds at most 65 535 blocks; a pass has up to 2^28 / 512 of them)
-          const uint32_t n_pb = (pd.npix + kRgDense - 1) / kRgDense, gz = (n_pb + 65534u) / 65535u, gy = (n_pb + gz - 1) / gz;
-          hipLaunchKernelGGL(k_raygen_main_f32, dim3(pd.ns, gy, gz), dim3(kRgDense), 0, st_, scene_, pool_, pd, write_samp, dims_out, safe_r2, aux_delta_, aux_pupil_, enqueue);
+          // samples / pixels per workgroup: 8 samples of one 8 x 8-pixel tile (PassDesc::tiled) where the pass has that many, else one sample of 512 pixels
+          const uint32_t spb = (pd.tiled && pd.ns >= (uint32_t)rg_spb_) ? (uint32_t)std::max(1, std::min(rg_spb_, kRgDense / 64)) : 1u, ppb = kRgDense / spb;
+          const uint32_t n_pb = (pd.npix + ppb - 1) / ppb, gz = (n_pb + 65534u) / 65535u, gy = (n_pb + gz - 1) / gz;
+          hipLaunchKernelGGL(k_raygen_main_f32, dim3((pd.ns + spb - 1) / spb, gy, gz), dim3(kRgDense), 0, st_, scene_, pool_, pd, write_samp, dims_out, safe_r2, aux_delta_, aux_pupil_, enqueue, spb);
           hipLaunchKernelGGL(k_raygen_aux2_f32, dim3((total + kRgDense - 1) / kRgDense), dim3(kRgDense), 0, st_, scene_, pool_, enqueue);
           hipLaunchKernelGGL(k_rotate, dim3(1), dim3(1), 0, st_, counters_.p, 4);   // q_next was only a staging queue
         }

@@ -618,9 +618,9 @@ def test_shading_kernel_specialisation(which, workdir):
 
 @pytest.mark.parametrize("which", ["box_cfg4", "gaussian_cfg3", "bands_cfg2"])
 def test_tile_order_of_the_pixels_changes_nothing(which, workdir):
-    """The pixels of a pass are enumerated tile by tile (32 x 16 = one workgroup of the camera kernel) where the rect is made of whole tiles,
-    row by row otherwise (PassDesc::tiled): queue entries that are neighbours are then neighbours in both image directions, which the traversal
-    and shading kernels' caches like (frame 36.8 -> 35.7 ms on config 4). Only the ORDER of the work changes - a sample's slot, Halton index and
+    """The pixels of a pass are enumerated tile by tile (8 x 8; a workgroup of the camera kernel takes one tile x 8 samples) where the rect is made
+    of whole tiles, row by row otherwise (PassDesc::tiled): queue entries that are neighbours are then neighbours in both image directions, which
+    the traversal and shading kernels' caches like (frame 36.8 -> 35.0 ms on config 4). Only the ORDER of the work changes - a sample's slot, Halton index and
     film pixel do not: frames, weights and counters with and without it are identical bit for bit, also under a filter that gathers across
     pixels (the film kernel inverts the enumeration) and for a rank's bands."""
     if which == "box_cfg4": cfg, root = scenes.cfg4(workdir, xres=128, yres=96, nsamp=9, max_depth=5, n=64)
@@ -638,7 +638,7 @@ def test_tile_order_of_the_pixels_changes_nothing(which, workdir):
                 out[tile] = (sum(r.render_bands(k, 3) for k in range(3)), None)
             else:
                 out[tile] = r.render(stats=True)
-                r.set_option("max_paths", 32 * 16 * 3)          # several pixel groups and passes: tiles split over groups
+                r.set_option("max_paths", 8 * 8 * 5 * 3)        # several pixel groups and passes: groups of whole tiles, 3 samples per pass
                 out[tile + 2] = r.render(stats=True)
                 r.set_option("max_paths", 1 << 28)
         r.close()
