@@ -984,7 +984,7 @@ __global__ void __launch_bounds__((shade_path_block<R, KM>())) __attribute__((am
   V3<R> sh_o, sh_d, nx_o, nx_d, o_lo;   // shadow ray / next ray + path state, stored at their queue positions at the end
   Rgb<R> sh_ld, nx_beta;
   R nx_eta_scale = R(1);
-  uint32_t index = 0, nx_db = 0;
+  uint32_t index = 0, nx_db = 0, sh_tab = 0;
   if (i < n) {
     const QEnt qe = p.q_active[i];
     slot = qe.slot;
@@ -1034,6 +1034,7 @@ __global__ void __launch_bounds__((shade_path_block<R, KM>())) __attribute__((am
           if (s.light_pick_pdf != R(0) && estimate_direct_light<AREA>(si, bsdf, s.lights[ln], ul0, ul1, &so, &sd, &ld)) {
             sh_ld = beta * (ld / s.light_pick_pdf);
             sh_o = so; sh_d = sd;
+            sh_tab = s.use_shadow_tabs ? s.lights[ln].shadow_tab : 0u;
             want_shadow = true;
           }
         }
@@ -1079,7 +1080,7 @@ __global__ void __launch_bounds__((shade_path_block<R, KM>())) __attribute__((am
   }
   const uint32_t qs = block_push(p.shadow_count, want_shadow, push_lds);
   if (want_shadow) {
-    store_ray<R>(p.sray_o, p.sray_d, qs, sh_o, o_lo, sh_d, R(1) - R(0.0001), self_prim<R>(prim));
+    store_ray<R>(p.sray_o, p.sray_d, qs, sh_o, o_lo, sh_d, R(1) - R(0.0001), self_prim<R>(prim) | (int)(sh_tab << 24));   // (sh_tab != 0 only in fp32, where prim >= 0 and < 2^19)
     p.sld[qs] = mk4u<R>(sh_ld.r, sh_ld.g, sh_ld.b, slot);
   }
   const uint32_t qn = block_push(&p.counters[C_NEXT], want_next, push_lds);

@@ -568,6 +568,103 @@ __global__ void __launch_bounds__(kPtBlock) k_trace_pt_f32(TravScene ts, Pools<f
 #endif
 }
 
+// ------------------------------------------------------------------------------------------------------------
+// Shadow rays towards delta lights by candidate lists (no tree walk).
+// An occlusion query is order independent, and a leaf's box test implies its ancestors' (their boxes contain it and every step of the slab
+// arithmetic is monotone under rounding), so BVHAccel::intersect_p's verdict is: "some triangle of some leaf whose OWN box the ray passes is
+// hit" - the tree only finds those leaves. A pool shadow ray starts on a known triangle T, is kShadowTmax long (Q9) and points at a light
+// whose position (point lights: all at the world origin, Q17) or direction (distant lights) is fixed: the leaves such a ray can reach at all
+// are few and can be listed per (light, T) at scene load - the host sweeps T towards the light over the ray's length, fattens that prism by
+// the spread of directions over T and by the fp32 slack, and collects every leaf whose box meets it (rrt_impl.hpp build_shadow_lists()).
+// Here a ray runs down its list: the reference's own slab test on each leaf's box (same function, same box), the reference's triangle tests on
+// the leaves that pass. Same boxes tested as the walk would test at the leaves, less the ones that cannot pass; same verdict, bit for bit
+// (tests/test_gpu_parity.py::test_shadow_candidate_lists_change_nothing). 17.8 pair-node steps per shadow ray become ~8 leaf-box tests.
+// A triangle without a list (light closer than a few triangle sizes, more than kShadowListMax candidates) walks the tree right here.
+// ------------------------------------------------------------------------------------------------------------
+constexpr uint32_t kShadowListMax = 48u;        // candidates per (light table, triangle); 0xff in the header = no list: walk the tree
+constexpr uint32_t kShadowTabShift = 24u;       // a pool shadow ray's start word: triangle (24 bits) | light table + 1 (bits 24-27)
+struct LeafRec { float bmin[3]; uint32_t word; float bmax[3]; uint32_t pad; };   // a BVH leaf: its (fp32, outward) box and its leaf word
+struct ShadowLists {
+  const uint32_t* headers;   // [table][triangle]: first entry << 8 | count (0xff: none)
+  const uint32_t* entries;   // leaf ids
+  const LeafRec* leaves;
+  uint32_t n_tris, n_tables;
+};
+
+// the pair-node walk of k_trace_pairs_f32<true> with a private stack (rare path of k_shadow_lists_f32)
+RRT_DEV bool walk_any_private_f32(const TravScene& ts, LaneRay& r) {
+  float tmin;
+  if (!(ts.n_nodes != 0 && box_slabs_f32(ts.root_box[0], ts.root_box[1], ts.root_box[2], ts.root_box[3], ts.root_box[4], ts.root_box[5], r, &tmin) && tmin < r.tmax)) return false;
+  uint32_t stack[64];
+  uint32_t sp = 0, cur = ts.root_id;
+  int hit; float hu, hv;
+  for (;;) {
+    if (is_node(cur)) {
+      const char* np = reinterpret_cast<const char*>(ts.pairs) + cur;
+      const float4 a = *reinterpret_cast<const float4*>(np), b = *reinterpret_cast<const float4*>(np + 16), c = *reinterpret_cast<const float4*>(np + 32);
+      const uint4 d = *reinterpret_cast<const uint4*>(np + 48);
+      float t0, t1;
+      const bool h0 = box_slabs_f32(a.x, a.y, c.x, a.z, a.w, c.y, r, &t0) && t0 < r.tmax;
+      const bool h1 = box_slabs_f32(b.x, b.y, c.z, b.z, b.w, c.w, r, &t1) && t1 < r.tmax;
+      if (h0 && h1) { stack[sp++] = d.y; cur = d.x; }
+      else if (h0) cur = d.x;
+      else if (h1) cur = d.y;
+      else { if (sp == 0) return false; cur = stack[--sp]; }
+    } else {
+      if (leaf_step_f32<true, false>(ts, cur, r, &hit, &hu, &hv)) return true;
+      if (sp == 0) return false;
+      cur = stack[--sp];
+    }
+  }
+}
+
+static __global__ void __launch_bounds__(256) k_shadow_lists_f32(TravScene ts, ShadowLists sl, Pools<float> p, const uint32_t* count) {
+  const uint32_t n = *count;
+  for (uint32_t i = blockIdx.x * blockDim.x + threadIdx.x; i < n; i += gridDim.x * blockDim.x) {
+    const float4 ro = p.sray_o[i], rd = p.sray_d[i];
+    LaneRay r;
+    V3<float> lo;
+    ray_tail(ro, kShadowTmax, &r.tmax, &lo);
+    const uint32_t sw = __float_as_uint(rd.w);
+    const bool has_start = (int32_t)sw >= 0;
+    const uint32_t sk = sw & ((1u << kShadowTabShift) - 1u), tab = has_start ? (sw >> kShadowTabShift) & 15u : 0u;
+    r.oxy = v2f{ro.x, ro.y}; r.ozz = v2f{ro.z, ro.z}; r.dx = rd.x; r.dy = rd.y; r.dz = rd.z;
+    r.lx = lo.x; r.ly = lo.y; r.lz = lo.z;
+    r.skip_plane = has_start ? __float_as_uint(ts.tris[(size_t)sk * 12 + 11]) : 0xffffffffu;
+    r.ixy = v2f{1.0f / r.dx, 1.0f / r.dy}; r.izz.x = 1.0f / r.dz; r.izz.y = r.izz.x;
+    r.neg = (r.ixy.x < 0.0f ? 1u : 0u) | (r.ixy.y < 0.0f ? 2u : 0u) | (r.izz.x < 0.0f ? 4u : 0u);
+    uint32_t hdr = 0xffu;
+    if (tab != 0u && tab <= sl.n_tables && sk < sl.n_tris) hdr = sl.headers[(size_t)(tab - 1u) * sl.n_tris + sk];
+    bool found = false;
+    if ((hdr & 0xffu) == 0xffu) found = walk_any_private_f32(ts, r);   // no list: the tree walk, here
+    else {
+      // four candidates per round: their ids are one aligned 16-byte load (the host pads a list to a multiple of four with id 0xffffffff), their
+      // eight box words are in flight together, and only then the slab tests - a lane's rounds are a chain of dependent loads otherwise
+      const uint32_t cnt = hdr & 0xffu;
+      const uint4* e4 = reinterpret_cast<const uint4*>(sl.entries + (hdr >> 8));
+      for (uint32_t k = 0; k < cnt && !found; k += 4u) {
+        const uint4 ids = e4[k >> 2];
+        const uint32_t id[4] = {ids.x, ids.y, ids.z, ids.w};
+        float4 a[4], b[4];
+#pragma unroll
+        for (int j = 0; j < 4; j++) {
+          const float4* lp = reinterpret_cast<const float4*>(sl.leaves + (id[j] != 0xffffffffu ? id[j] : 0u));
+          a[j] = lp[0]; b[j] = lp[1];   // {bmin.xyz, word}, {bmax.xyz, -}
+        }
+#pragma unroll
+        for (int j = 0; j < 4; j++) {
+          float tmin;
+          if (!found && id[j] != 0xffffffffu && box_slabs_f32(a[j].x, a[j].y, a[j].z, b[j].x, b[j].y, b[j].z, r, &tmin) && tmin < r.tmax) {
+            int hit; float hu, hv;
+            found = leaf_step_f32<true, false>(ts, __float_as_uint(a[j].w), r, &hit, &hu, &hv);
+          }
+        }
+      }
+    }
+    if (!found) add_pending(p, i);
+  }
+}
+
 }  // namespace rrtd
 
 // ------------------------------------------------------------------------------------------------------------

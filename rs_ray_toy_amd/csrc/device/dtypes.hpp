@@ -120,6 +120,7 @@ struct Light {
   R tn[3][3];                      // triangle vertex normals (if tri_has_n)
   uint32_t tri_has_n;
   R w_light[3], world_radius;      // DistantLight (lights/distant.rs)
+  uint32_t shadow_tab;             // fp32: shadow candidate table of this light + 1 (dtraverse_f32.hpp), 0 = none
 };
 
 template <typename R>
@@ -151,6 +152,7 @@ struct SceneDev {
   R light_pick_pdf;            // 1 / (func_int * n)
   uint32_t stack_depth;        // >= bvh depth + 1
   uint32_t flags;
+  uint32_t use_shadow_tabs;    // the shading kernel stores Light::shadow_tab with a shadow ray's start triangle (the launch that follows is k_shadow_lists_f32)
   // camera
   const LensElem<R>* lens;
   int32_t n_lens, simple_weighting;

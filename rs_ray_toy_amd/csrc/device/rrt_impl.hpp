@@ -2,12 +2,14 @@
 // SoA in HBM), pool allocation, the per-pass / per-bounce launch sequence and the public trace entry points.
 // One HIP stream per handle; no host synchronisation inside a frame (queue sizes are read on the device).
 #pragma once
+#include <algorithm>
 #include <cmath>
 #include <cstdio>
 #include <cstring>
 #include <memory>
 #include <stdexcept>
 #include <string>
+#include <thread>
 #include <unordered_map>
 #include <vector>
 
@@ -232,6 +234,156 @@ inline AuxMargins calibrate_aux_margins(const rrt_scene_desc* d) {
   return out;
 }
 
+// ---- shadow candidate lists of the fp32 any-hit path (dtraverse_f32.hpp "Shadow rays towards delta lights by candidate lists") ----------
+// One table per distinct delta-light source (point lights by position - the reference puts every one at the world origin, Q17 -, distant lights
+// by direction). Per triangle T: the leaves whose box can meet a shadow ray that starts on T and points at the source. Such a ray is
+// q + t u(q), q in T, t in [0, kShadowTmax |d|] with |d| = 1 +- 1e-6; u(q) lies within an angle theta of the centroid's direction u_c
+// (point light: tan(theta) <= r_T / sqrt(dist^2 - r_T^2); distant light: theta = 0), so the ray stays within delta = L tan(theta) of the prism
+// "T swept along u_c by L". A leaf is a candidate when its box, fattened by delta + slack, meets that prism - decided by a separating-axis
+// test over the box axes, the prism's face normals and the edge cross products, which can only err towards "meets". The slack covers what
+// separates the fp32 evaluation from this geometry: the ray's origin word is the fp32 rounding of a point of T (<= 1 ulp of the coordinates),
+// the boxes are rounded outward, the slab test widens the far planes by 1 + 2 gamma(3): 16 ulp of the largest coordinate + 1e-4 in all.
+// Triangles closer to a point light than 8 triangle radii, or with more than kShadowListMax candidates, get no list (the kernel walks the tree).
+struct ShadowListsHost {
+  std::vector<uint32_t> headers, entries;
+  std::vector<LeafRec> leaves;
+  uint32_t n_tables = 0;
+  std::vector<uint32_t> table_of_light;   // per light: table + 1, 0 = none
+};
+inline ShadowListsHost build_shadow_lists(const std::vector<Node<float>>& nodes, const std::vector<Tri<float>>& tris, const rrt_scene_desc* d) {
+  ShadowListsHost out;
+  out.table_of_light.assign(d->n_lights, 0u);
+  if (nodes.empty() || tris.empty()) return out;
+  struct Src { int type; double v[3]; };
+  std::vector<Src> srcs;
+  for (size_t i = 0; i < d->n_lights; i++) {
+    const rrt_light& l = d->lights[i];
+    Src s{l.type, {0, 0, 0}};
+    if (l.type == RRT_LIGHT_POINT) for (int k = 0; k < 3; k++) s.v[k] = (double)(float)l.p_light[k];
+    else if (l.type == RRT_LIGHT_DISTANT) for (int k = 0; k < 3; k++) s.v[k] = (double)(float)l.w_light[k];
+    else return ShadowListsHost{{}, {}, {}, 0u, std::vector<uint32_t>(d->n_lights, 0u)};   // an area light: the scene keeps the tree walk for every shadow ray
+    size_t t = 0;
+    for (; t < srcs.size(); t++) if (srcs[t].type == s.type && srcs[t].v[0] == s.v[0] && srcs[t].v[1] == s.v[1] && srcs[t].v[2] == s.v[2]) break;
+    if (t == srcs.size()) srcs.push_back(s);
+    if (t >= 15) return ShadowListsHost{{}, {}, {}, 0u, std::vector<uint32_t>(d->n_lights, 0u)};
+    out.table_of_light[i] = (uint32_t)t + 1u;
+  }
+  if (srcs.empty()) return out;
+  // leaves of the tree
+  std::vector<uint32_t> leaf_of(nodes.size(), 0xffffffffu);
+  for (size_t i = 0; i < nodes.size(); i++) {
+    const uint32_t np = nodes[i].meta >> 2;
+    if (np == 0) continue;
+    leaf_of[i] = (uint32_t)out.leaves.size();
+    LeafRec lr{};
+    for (int k = 0; k < 3; k++) { lr.bmin[k] = nodes[i].bmin[k]; lr.bmax[k] = nodes[i].bmax[k]; }
+    lr.word = kLeafBit | (np << 19) | nodes[i].offset;
+    out.leaves.push_back(lr);
+  }
+  double coord_max = 0.0;
+  for (int k = 0; k < 3; k++) coord_max = std::max(coord_max, std::max(std::fabs((double)nodes[0].bmin[k]), std::fabs((double)nodes[0].bmax[k])));
+  const double L = (double)kShadowTmax * (1.0 + 1e-5), slack = 16.0 * coord_max * 1.1920929e-7 + 1e-4;
+  const size_t nt = tris.size();
+  out.n_tables = (uint32_t)srcs.size();
+  out.headers.assign(nt * srcs.size(), 0xffu);
+  std::vector<std::vector<uint32_t>> lists(nt * srcs.size());
+  auto work = [&](size_t t0, size_t t1) {
+    std::vector<uint32_t> stack;
+    for (size_t ti = t0; ti < t1; ti++) {
+      const Tri<float>& T = tris[ti];
+      if (T.plane == kSphereMark || (T.material & kInstFlag) != 0u) continue;   // (not a world-space triangle: no list)
+      const double P[3][3] = {{T.p0[0], T.p0[1], T.p0[2]}, {T.p1[0], T.p1[1], T.p1[2]}, {T.p2[0], T.p2[1], T.p2[2]}};
+      double c[3], rT = 0.0;
+      for (int k = 0; k < 3; k++) c[k] = (P[0][k] + P[1][k] + P[2][k]) / 3.0;
+      for (int v = 0; v < 3; v++) rT = std::max(rT, std::sqrt((P[v][0] - c[0]) * (P[v][0] - c[0]) + (P[v][1] - c[1]) * (P[v][1] - c[1]) + (P[v][2] - c[2]) * (P[v][2] - c[2])));
+      for (size_t si = 0; si < srcs.size(); si++) {
+        double u[3], delta = 0.0;
+        if (srcs[si].type == RRT_LIGHT_POINT) {
+          double w[3] = {srcs[si].v[0] - c[0], srcs[si].v[1] - c[1], srcs[si].v[2] - c[2]};
+          const double dist = std::sqrt(w[0] * w[0] + w[1] * w[1] + w[2] * w[2]);
+          if (!(dist > 8.0 * rT) || !(dist > 0.0)) continue;   // light too close: the directions over T spread too far
+          for (int k = 0; k < 3; k++) u[k] = w[k] / dist;
+          delta = L * rT / std::sqrt(dist * dist - rT * rT) * 1.01;
+        } else {
+          const double len = std::sqrt(srcs[si].v[0] * srcs[si].v[0] + srcs[si].v[1] * srcs[si].v[1] + srcs[si].v[2] * srcs[si].v[2]);
+          if (!(len > 0.0)) continue;
+          for (int k = 0; k < 3; k++) u[k] = srcs[si].v[k] / len;
+        }
+        const double m = delta + slack;
+        // prism vertices and the axes of the separating-axis test
+        double V[6][3];
+        for (int v = 0; v < 3; v++) for (int k = 0; k < 3; k++) { V[v][k] = P[v][k]; V[3 + v][k] = P[v][k] + L * u[k]; }
+        double E[4][3];   // edge directions: the triangle's three edges and the sweep
+        for (int k = 0; k < 3; k++) { E[0][k] = P[1][k] - P[0][k]; E[1][k] = P[2][k] - P[1][k]; E[2][k] = P[0][k] - P[2][k]; E[3][k] = u[k]; }
+        auto cross = [](const double* a, const double* b, double* o) { o[0] = a[1] * b[2] - a[2] * b[1]; o[1] = a[2] * b[0] - a[0] * b[2]; o[2] = a[0] * b[1] - a[1] * b[0]; };
+        double A[16][3];
+        int na = 0;
+        cross(E[0], E[1], A[na++]);                                   // the triangle's plane
+        for (int e = 0; e < 3; e++) cross(E[e], E[3], A[na++]);      // the three side faces
+        for (int e = 0; e < 4; e++) for (int ax = 0; ax < 3; ax++) { const double b[3] = {ax == 0 ? 1.0 : 0.0, ax == 1 ? 1.0 : 0.0, ax == 2 ? 1.0 : 0.0}; cross(E[e], b, A[na++]); }
+        double lo[3], hi[3];
+        for (int k = 0; k < 3; k++) { lo[k] = hi[k] = V[0][k]; for (int v = 1; v < 6; v++) { lo[k] = std::min(lo[k], V[v][k]); hi[k] = std::max(hi[k], V[v][k]); } }
+        auto meets = [&](const Node<float>& nd) {
+          double bc[3], bh[3];
+          for (int k = 0; k < 3; k++) {
+            const double b0 = (double)nd.bmin[k] - m, b1 = (double)nd.bmax[k] + m;
+            if (b0 > hi[k] || b1 < lo[k]) return false;   // the box axes
+            bc[k] = 0.5 * (b0 + b1); bh[k] = 0.5 * (b1 - b0);
+          }
+          for (int a = 0; a < na; a++) {
+            const double* ax = A[a];
+            const double l2 = ax[0] * ax[0] + ax[1] * ax[1] + ax[2] * ax[2];
+            if (!(l2 > 1e-30)) continue;   // degenerate axis: decides nothing
+            double pmin = 1e300, pmax = -1e300;
+            for (int v = 0; v < 6; v++) { const double q = V[v][0] * ax[0] + V[v][1] * ax[1] + V[v][2] * ax[2]; pmin = std::min(pmin, q); pmax = std::max(pmax, q); }
+            const double cc = bc[0] * ax[0] + bc[1] * ax[1] + bc[2] * ax[2], rr = bh[0] * std::fabs(ax[0]) + bh[1] * std::fabs(ax[1]) + bh[2] * std::fabs(ax[2]);
+            if (cc - rr > pmax || cc + rr < pmin) return false;
+          }
+          return true;
+        };
+        std::vector<uint32_t>& list = lists[si * nt + ti];
+        bool too_many = false;
+        stack.clear(); stack.push_back(0u);
+        while (!stack.empty() && !too_many) {
+          const uint32_t ni = stack.back(); stack.pop_back();
+          const Node<float>& nd = nodes[ni];
+          if (!meets(nd)) continue;
+          if ((nd.meta >> 2) != 0u) { if (list.size() >= kShadowListMax) too_many = true; else list.push_back(leaf_of[ni]); }
+          else { stack.push_back(nd.offset); stack.push_back(ni + 1u); }
+        }
+        if (too_many) list.clear();
+        else {
+          // nearest leaves first: an occluded ray (a fifth of them on config 4) then stops early; the verdict does not depend on the order
+          auto dist2 = [&](uint32_t leaf) {
+            const LeafRec& lr = out.leaves[leaf];
+            double d2 = 0.0;
+            for (int k = 0; k < 3; k++) { const double g = std::max(0.0, std::max((double)lr.bmin[k] - c[k], c[k] - (double)lr.bmax[k])); d2 += g * g; }
+            return d2;
+          };
+          std::stable_sort(list.begin(), list.end(), [&](uint32_t a, uint32_t b) { return dist2(a) < dist2(b); });
+          out.headers[si * nt + ti] = (uint32_t)list.size();   // (offset filled in below)
+        }
+      }
+    }
+  };
+  {
+    const unsigned hw = std::max(1u, std::min(16u, std::thread::hardware_concurrency()));
+    std::vector<std::thread> pool;
+    const size_t chunk = (nt + hw - 1) / hw;
+    for (unsigned t = 0; t < hw; t++) { const size_t a = std::min(nt, t * chunk), b = std::min(nt, a + chunk); if (a < b) pool.emplace_back(work, a, b); }
+    for (auto& th : pool) th.join();
+  }
+  for (size_t i = 0; i < lists.size(); i++) {
+    if (out.headers[i] == 0xffu) continue;
+    if (out.entries.size() + 64u >= (1u << 24)) { out.headers[i] = 0xffu; continue; }
+    out.headers[i] = ((uint32_t)out.entries.size() << 8) | (uint32_t)lists[i].size();   // (the offset is a multiple of 4: the kernel reads four ids at a time)
+    out.entries.insert(out.entries.end(), lists[i].begin(), lists[i].end());
+    while (out.entries.size() % 4u != 0u) out.entries.push_back(0xffffffffu);
+  }
+  if (out.entries.empty()) out.entries.assign(4, 0xffffffffu);
+  return out;
+}
+
 // A desc normally comes from rrt_scene_load, but the ABI lets a caller fill one: every index the kernels follow is checked here once
 // (a kernel reading past an array can take the GPU down for everybody on the host)
 inline void validate_desc(const rrt_scene_desc* d) {
@@ -362,6 +514,7 @@ class Handle : public HandleBase {
     else if (key == "persistent_traversal") { persistent_ = v != 0; if (v >= 1) trav_mode_ = (int)v; }
     else if (key == "raygen_pt") raygen_pt_ = v != 0 ? 2 : 0;   // 0: generic two-stage kernels (the reference's operation order), otherwise (default): dense two-stage kernels with the lean lens arithmetic
     else if (key == "tile_order") tile_order_ = v != 0;
+    else if (key == "shadow_lists") shadow_lists_on_ = v != 0;
     else if (key == "rg_spb") rg_spb_ = (int)v;
     else if (key == "pt_split_closest") pt_split_closest_ = (uint32_t)v;
     else if (key == "pt_split_any") pt_split_any_ = (uint32_t)v;
@@ -592,6 +745,7 @@ class Handle : public HandleBase {
               use_shadow_queue(b & 1);
               if (b > 1) HIP_CHECK(hipStreamWaitEvent(st_, ev_shadow_[b & 1], 0));   // shading refills the queue the shadow launch of bounce b - 2 read
             }
+            scene_.use_shadow_tabs = use_shadow_lists() ? 1u : 0u;
             e = tick(3);
             if (tex_depth_ > 0) hipLaunchKernelGGL((k_shade_path<R, 4, true>), dim3(std::min((uint32_t)((nslots + 255) / 256), 16384u)), dim3(256), 0, st_, scene_, pool_);
             else if (has_translucent_) hipLaunchKernelGGL((k_shade_path<R, 4>), dim3(std::min((uint32_t)((nslots + 255) / 256), 16384u)), dim3(256), 0, st_, scene_, pool_);
@@ -766,6 +920,10 @@ class Handle : public HandleBase {
   uint32_t pt_split_closest_ = 100000u, pt_split_any_ = 100000u;   // re-tuned with the shadow launches overlapped (tools/band_scaling.py)
   DevBuf<uint32_t> pt_overflow_, pt_overflow_any_;
   DevBuf<uint32_t> any_list_;              // TravScene::any_list, 8 words per triangle
+  DevBuf<uint32_t> sl_headers_, sl_entries_;   // shadow candidate lists (build_shadow_lists())
+  DevBuf<LeafRec> sl_leaves_;
+  ShadowLists sl_dev_{};
+  bool shadow_lists_ok_ = false, shadow_lists_on_ = true;   // built for this scene / option "shadow_lists"
   bool any_entry_on_ = true;
   std::vector<uint32_t> newidx_keep_;      // build_pairs(): BFS renumbering of the pair nodes
   DevBuf<uint32_t> pix_off_;
@@ -1127,6 +1285,23 @@ class Handle : public HandleBase {
     nodes_.upload(nodes, st_); tris_.upload(tris, st_); spheres_.upload(spheres, st_); insts_.upload(insts, st_); build_pairs(nodes, tris); shades_.upload(shades, st_);
     materials_.upload(mats, st_); textures_.upload(texs, st_); images_.upload(imgs, st_); image_texels_.upload(texels, st_);
     { const AuxMargins am = calibrate_aux_margins(d); lens_safe_.upload(am.lim, st_); aux_delta_ = am.delta; aux_pupil_ = am.pupil; }
+    if constexpr (std::is_same<R, float>::value) {
+      // shadow candidate lists (dtraverse_f32.hpp): scenes whose lights are all point / distant lights, triangles in world space only
+      shadow_lists_ok_ = false;
+      if (pairs_ok_ && !mixed_ && d->n_lights > 0 && d->bvh_depth + 1 <= 64) {
+        ShadowListsHost sl = build_shadow_lists(nodes, tris, d);
+        if (sl.n_tables > 0) {
+          sl_headers_.upload(sl.headers, st_); sl_entries_.upload(sl.entries, st_); sl_leaves_.upload(sl.leaves, st_);
+          HIP_CHECK(hipStreamSynchronize(st_));
+          sl_dev_ = ShadowLists{sl_headers_.p, sl_entries_.p, sl_leaves_.p, (uint32_t)tris.size(), sl.n_tables};
+          for (size_t i = 0; i < d->n_lights; i++) lights[i].shadow_tab = sl.table_of_light[i];
+          shadow_lists_ok_ = true;
+          size_t n_with = 0, n_entries = 0;
+          for (uint32_t h : sl.headers) if ((h & 0xffu) != 0xffu) { n_with++; n_entries += h & 0xffu; }
+          if (getenv("RRT_DEBUG")) fprintf(stderr, "[rrt] shadow lists: %u table(s), %zu of %zu (table, triangle) pairs listed, %.2f candidate leaves on average\n", sl.n_tables, n_with, sl.headers.size(), n_with ? (double)n_entries / (double)n_with : 0.0);
+        }
+      }
+    }
     lights_.upload(lights, st_); light_cdf_.upload(cdf_r, st_); lens_.upload(lens, st_); hdims_.upload(hd, st_); perms_.upload(perms, st_);
     HIP_CHECK(hipStreamSynchronize(st_));  // host vectors go out of scope below
 
@@ -1591,8 +1766,18 @@ class Handle : public HandleBase {
       pairs_ok_ = true;
     }
   }
+  // (the path integrator's shading kernel is the one that stores the light table with its shadow rays)
+  bool use_shadow_lists() const { return std::is_same<R, float>::value && shadow_lists_ok_ && shadow_lists_on_ && !count_traversal_ && use_persistent() && desc_.integrator.type == RRT_INT_PATH; }
   void launch_shadow(uint32_t grid, hipStream_t stream = nullptr) {
     if (!stream) stream = st_;
+    if constexpr (std::is_same<R, float>::value) {
+      if (use_shadow_lists()) {   // (the shading kernel stored the light table with the ray's start triangle: scene_.use_shadow_tabs)
+        const uint32_t g = std::max(1u, std::min((uint32_t)(((size_t)grid * kBlock + 255) / 256), 256u * 32u));
+        hipLaunchKernelGGL(k_shadow_lists_f32, dim3(g), dim3(256), 0, stream, trav_, sl_dev_, pool_, pool_.shadow_count);
+        HIP_CHECK(hipGetLastError());
+        return;
+      }
+    }
     if (!count_traversal_ && use_persistent()) { launch_persistent(true, nullptr, pool_.shadow_count, 0, grid, nullptr, stream); return; }
     uint32_t* ds = deep_ ? deep_stack_.p : nullptr;
     const uint32_t stride = deep_ ? (uint32_t)cap_ : 0u;

@@ -649,6 +649,39 @@ def test_tile_order_of_the_pixels_changes_nothing(which, workdir):
             assert np.array_equal(out[3][0], out[2][0])
 
 
+@pytest.mark.parametrize("which", ["cfg4", "cfg4_distant", "cfg4_far", "cfg2", "cfg3", "cfg5_area"])
+def test_shadow_candidate_lists_change_nothing(which, workdir):
+    """Shadow rays towards point / distant lights run down a per-(light, triangle) list of candidate leaves instead of walking the tree
+    (dtraverse_f32.hpp k_shadow_lists_f32, rrt_impl.hpp build_shadow_lists()): a leaf's box test implies its ancestors', an occlusion query does
+    not depend on the order, and the host lists every leaf whose box can meet a ray that starts on the triangle and points at the light. The
+    same slab test on the same leaf boxes, the same triangle tests: frames and query counts with and without the lists are identical bit for
+    bit - mesh at the origin and 1e5 units away, axis-aligned instanced cubes, an enclosure whose light sits inside it. A scene with an area
+    light keeps the tree walk for every shadow ray (cfg5_area: the option changes nothing because nothing was built)."""
+    if which == "cfg4": cfg, root = scenes.cfg4(workdir, xres=128, yres=128, nsamp=9, max_depth=6, n=96)
+    elif which == "cfg4_distant": cfg, root = _cfg4_distant(workdir)
+    elif which == "cfg4_far":
+        cfg, root = scenes.cfg4(workdir, xres=128, yres=128, nsamp=9, max_depth=6, n=96)
+        far = np.array([1.0e5, -7.0e4, 3.0e4])
+        cfg["Aggregate"]["primitives"][0]["instances"] = [{"world_pos": list(far)}]
+        cfg["Camera"]["world_pos"] = list(np.array(cfg["Camera"]["world_pos"], float) + far)
+        cfg["Camera"]["look"] = list(np.array(cfg["Camera"]["look"], float) + far)
+        cfg["lights"] = [{"light_type": "distant", "l": {"values": [3.0, 2.5, 2.0]}, "from": [20.0, 30.0, 10.0], "to": [35.0, 0.0, 0.0]}]
+    elif which == "cfg2": cfg, root = scenes.cfg2(workdir, xres=128, yres=128, nsamp=9, max_depth=4)
+    elif which == "cfg3": cfg, root = scenes.cfg3(workdir, xres=128, yres=128, nsamp=9)
+    else: cfg, root = scenes.cfg5(workdir, xres=96, yres=96, nsamp=9, max_depth=6, n=64)
+    sc = Scene.loads(cfg, root, flags=RRT_FIXED_BVH)
+    r = Renderer(sc, 0, RRT_F32)
+    a, st_a = r.render(stats=True)
+    r.set_option("shadow_lists", 0)
+    b, st_b = r.render(stats=True)
+    r.set_option("any_entry", 0)               # ... and against the plain walk from the root
+    c, st_c = r.render(stats=True)
+    r.close()
+    assert st_a.any_queries == st_b.any_queries == st_c.any_queries and st_a.any_queries > 1000
+    assert np.array_equal(a, b) and np.array_equal(a, c)
+    assert a[..., :3].max() > 0
+
+
 def test_camera_halton_block_tables_change_nothing(workdir):
     """The fp32 camera kernel replaces the digit loops of Halton dimensions 1-3 (bases 3, 5, 7; halton.rs:107-128, lowdiscrepancy.rs:188-227)
     by two table look-ups each - the index split into a block of low digits and the rest, SceneDev::cam_lo / cam_hi. Same integers, same f64
