@@ -1103,7 +1103,7 @@ __global__ void __launch_bounds__(ShadeBlock<R>::n) k_shade_nee(SceneDev<R> s, P
   const uint32_t n = p.counters[C_ACTIVE];
   if (blockIdx.x * blockDim.x >= n) return;   // whole block past the queue end (the grid is sized for the worst case)
   bool want_shadow = false;
-  uint32_t slot = 0;
+  uint32_t slot = 0, sh_tab = 0;
   int prim = -1;
   V3<R> sh_o, sh_d, o_lo;
   Rgb<R> sh_ld;
@@ -1149,6 +1149,7 @@ __global__ void __launch_bounds__(ShadeBlock<R>::n) k_shade_nee(SceneDev<R> s, P
         if (estimate_direct_light(si, bsdf, s.lights[ln], ul0, ul1, &so, &sd, &ld)) {
           sh_ld = beta * (ld / pick_pdf);
           sh_o = so; sh_d = sd; o_lo = si.p_lo;
+          sh_tab = s.use_shadow_tabs ? s.lights[ln].shadow_tab : 0u;
           want_shadow = true;
         }
         p.q_active[i].db = (dim & 0xffffu) | (db & 0xffff0000u);
@@ -1157,7 +1158,7 @@ __global__ void __launch_bounds__(ShadeBlock<R>::n) k_shade_nee(SceneDev<R> s, P
   }
   const uint32_t qs = block_push(p.shadow_count, want_shadow, push_lds);
   if (want_shadow) {
-    store_ray<R>(p.sray_o, p.sray_d, qs, sh_o, o_lo, sh_d, R(1) - R(0.0001), self_prim<R>(prim));
+    store_ray<R>(p.sray_o, p.sray_d, qs, sh_o, o_lo, sh_d, R(1) - R(0.0001), self_prim<R>(prim) | (int)(sh_tab << 24));
     p.sld[qs] = mk4u<R>(sh_ld.r, sh_ld.g, sh_ld.b, slot);
   }
 }

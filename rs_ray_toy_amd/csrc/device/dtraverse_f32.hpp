@@ -618,7 +618,14 @@ RRT_DEV bool walk_any_private_f32(const TravScene& ts, LaneRay& r) {
   }
 }
 
-static __global__ void __launch_bounds__(256) k_shadow_lists_f32(TravScene ts, ShadowLists sl, Pools<float> p, const uint32_t* count) {
+#ifndef RRT_SL_UNROLL
+#define RRT_SL_UNROLL 4
+#endif
+#ifndef RRT_SL_BLOCK
+#define RRT_SL_BLOCK 256
+#endif
+constexpr int kSlBlock = RRT_SL_BLOCK;
+static __global__ void __launch_bounds__(kSlBlock) k_shadow_lists_f32(TravScene ts, ShadowLists sl, Pools<float> p, const uint32_t* count) {
   const uint32_t n = *count;
   for (uint32_t i = blockIdx.x * blockDim.x + threadIdx.x; i < n; i += gridDim.x * blockDim.x) {
     const float4 ro = p.sray_o[i], rd = p.sray_d[i];
@@ -642,17 +649,22 @@ static __global__ void __launch_bounds__(256) k_shadow_lists_f32(TravScene ts, S
       // eight box words are in flight together, and only then the slab tests - a lane's rounds are a chain of dependent loads otherwise
       const uint32_t cnt = hdr & 0xffu;
       const uint4* e4 = reinterpret_cast<const uint4*>(sl.entries + (hdr >> 8));
-      for (uint32_t k = 0; k < cnt && !found; k += 4u) {
-        const uint4 ids = e4[k >> 2];
-        const uint32_t id[4] = {ids.x, ids.y, ids.z, ids.w};
-        float4 a[4], b[4];
+      constexpr int U = RRT_SL_UNROLL;   // candidates per round (a multiple of 4)
+      for (uint32_t k = 0; k < cnt && !found; k += (uint32_t)U) {
+        uint32_t id[U];
 #pragma unroll
-        for (int j = 0; j < 4; j++) {
+        for (int q = 0; q < U / 4; q++) {
+          const uint4 ids = (k + 4u * (uint32_t)q < cnt) ? e4[(k >> 2) + (uint32_t)q] : make_uint4(0xffffffffu, 0xffffffffu, 0xffffffffu, 0xffffffffu);
+          id[4 * q] = ids.x; id[4 * q + 1] = ids.y; id[4 * q + 2] = ids.z; id[4 * q + 3] = ids.w;
+        }
+        float4 a[U], b[U];
+#pragma unroll
+        for (int j = 0; j < U; j++) {
           const float4* lp = reinterpret_cast<const float4*>(sl.leaves + (id[j] != 0xffffffffu ? id[j] : 0u));
           a[j] = lp[0]; b[j] = lp[1];   // {bmin.xyz, word}, {bmax.xyz, -}
         }
 #pragma unroll
-        for (int j = 0; j < 4; j++) {
+        for (int j = 0; j < U; j++) {
           float tmin;
           if (!found && id[j] != 0xffffffffu && box_slabs_f32(a[j].x, a[j].y, a[j].z, b[j].x, b[j].y, b[j].z, r, &tmin) && tmin < r.tmax) {
             int hit; float hu, hv;

@@ -3,6 +3,7 @@
 // One HIP stream per handle; no host synchronisation inside a frame (queue sizes are read on the device).
 #pragma once
 #include <algorithm>
+#include <chrono>
 #include <cmath>
 #include <cstdio>
 #include <cstring>
@@ -515,6 +516,7 @@ class Handle : public HandleBase {
     else if (key == "raygen_pt") raygen_pt_ = v != 0 ? 2 : 0;   // 0: generic two-stage kernels (the reference's operation order), otherwise (default): dense two-stage kernels with the lean lens arithmetic
     else if (key == "tile_order") tile_order_ = v != 0;
     else if (key == "shadow_lists") shadow_lists_on_ = v != 0;
+    else if (key == "sl_grid") sl_grid_cap_ = std::max(1, (int)v);
     else if (key == "rg_spb") rg_spb_ = (int)v;
     else if (key == "pt_split_closest") pt_split_closest_ = (uint32_t)v;
     else if (key == "pt_split_any") pt_split_any_ = (uint32_t)v;
@@ -810,6 +812,7 @@ class Handle : public HandleBase {
               const int nl = all ? (int)desc_.n_lights : 1;
               for (int j = 0; j < nl; j++) {
                 hipLaunchKernelGGL(k_rotate, dim3(1), dim3(1), 0, st_, counters_.p, 1);
+                scene_.use_shadow_tabs = use_shadow_lists() ? 1u : 0u;
                 e = tick(3);
                 hipLaunchKernelGGL((k_shade_nee<R>), dim3(sgrid), dim3(ShadeBlock<R>::n), 0, st_, scene_, pool_, all ? j : -1, j == 0 ? 1 : 0);
                 tock(e);
@@ -923,6 +926,7 @@ class Handle : public HandleBase {
   DevBuf<uint32_t> sl_headers_, sl_entries_;   // shadow candidate lists (build_shadow_lists())
   DevBuf<LeafRec> sl_leaves_;
   ShadowLists sl_dev_{};
+  int sl_grid_cap_ = 32768;  // option "sl_grid" (measured: 2 048 / 8 192 / 32 768 workgroups: any-hit alone 4.27 / 3.46 / 3.38 ms)
   bool shadow_lists_ok_ = false, shadow_lists_on_ = true;   // built for this scene / option "shadow_lists"
   bool any_entry_on_ = true;
   std::vector<uint32_t> newidx_keep_;      // build_pairs(): BFS renumbering of the pair nodes
@@ -1289,7 +1293,9 @@ class Handle : public HandleBase {
       // shadow candidate lists (dtraverse_f32.hpp): scenes whose lights are all point / distant lights, triangles in world space only
       shadow_lists_ok_ = false;
       if (pairs_ok_ && !mixed_ && d->n_lights > 0 && d->bvh_depth + 1 <= 64) {
+        const auto t_sl0 = std::chrono::steady_clock::now();
         ShadowListsHost sl = build_shadow_lists(nodes, tris, d);
+        const double t_sl = std::chrono::duration<double>(std::chrono::steady_clock::now() - t_sl0).count();
         if (sl.n_tables > 0) {
           sl_headers_.upload(sl.headers, st_); sl_entries_.upload(sl.entries, st_); sl_leaves_.upload(sl.leaves, st_);
           HIP_CHECK(hipStreamSynchronize(st_));
@@ -1298,7 +1304,7 @@ class Handle : public HandleBase {
           shadow_lists_ok_ = true;
           size_t n_with = 0, n_entries = 0;
           for (uint32_t h : sl.headers) if ((h & 0xffu) != 0xffu) { n_with++; n_entries += h & 0xffu; }
-          if (getenv("RRT_DEBUG")) fprintf(stderr, "[rrt] shadow lists: %u table(s), %zu of %zu (table, triangle) pairs listed, %.2f candidate leaves on average\n", sl.n_tables, n_with, sl.headers.size(), n_with ? (double)n_entries / (double)n_with : 0.0);
+          if (getenv("RRT_DEBUG")) fprintf(stderr, "[rrt] shadow lists: %u table(s), %zu of %zu (table, triangle) pairs listed, %.2f candidate leaves on average, built in %.3f s\n", sl.n_tables, n_with, sl.headers.size(), n_with ? (double)n_entries / (double)n_with : 0.0, t_sl);
         }
       }
     }
@@ -1766,14 +1772,14 @@ class Handle : public HandleBase {
       pairs_ok_ = true;
     }
   }
-  // (the path integrator's shading kernel is the one that stores the light table with its shadow rays)
-  bool use_shadow_lists() const { return std::is_same<R, float>::value && shadow_lists_ok_ && shadow_lists_on_ && !count_traversal_ && use_persistent() && desc_.integrator.type == RRT_INT_PATH; }
+  // (the shading kernels that feed the shadow queue - k_shade_path, k_shade_nee - store the light table with the ray's start triangle)
+  bool use_shadow_lists() const { return std::is_same<R, float>::value && shadow_lists_ok_ && shadow_lists_on_ && !count_traversal_ && use_persistent(); }
   void launch_shadow(uint32_t grid, hipStream_t stream = nullptr) {
     if (!stream) stream = st_;
     if constexpr (std::is_same<R, float>::value) {
       if (use_shadow_lists()) {   // (the shading kernel stored the light table with the ray's start triangle: scene_.use_shadow_tabs)
-        const uint32_t g = std::max(1u, std::min((uint32_t)(((size_t)grid * kBlock + 255) / 256), 256u * 32u));
-        hipLaunchKernelGGL(k_shadow_lists_f32, dim3(g), dim3(256), 0, stream, trav_, sl_dev_, pool_, pool_.shadow_count);
+        const uint32_t g = std::max(1u, std::min((uint32_t)(((size_t)grid * kBlock + kSlBlock - 1) / kSlBlock), (uint32_t)sl_grid_cap_));
+        hipLaunchKernelGGL(k_shadow_lists_f32, dim3(g), dim3(kSlBlock), 0, stream, trav_, sl_dev_, pool_, pool_.shadow_count);
         HIP_CHECK(hipGetLastError());
         return;
       }

@@ -649,7 +649,7 @@ def test_tile_order_of_the_pixels_changes_nothing(which, workdir):
             assert np.array_equal(out[3][0], out[2][0])
 
 
-@pytest.mark.parametrize("which", ["cfg4", "cfg4_distant", "cfg4_far", "cfg2", "cfg3", "cfg5_area"])
+@pytest.mark.parametrize("which", ["cfg4", "cfg4_distant", "cfg4_far", "cfg2", "cfg3", "cfg3_direct", "cfg5_area"])
 def test_shadow_candidate_lists_change_nothing(which, workdir):
     """Shadow rays towards point / distant lights run down a per-(light, triangle) list of candidate leaves instead of walking the tree
     (dtraverse_f32.hpp k_shadow_lists_f32, rrt_impl.hpp build_shadow_lists()): a leaf's box test implies its ancestors', an occlusion query does
@@ -668,6 +668,9 @@ def test_shadow_candidate_lists_change_nothing(which, workdir):
         cfg["lights"] = [{"light_type": "distant", "l": {"values": [3.0, 2.5, 2.0]}, "from": [20.0, 30.0, 10.0], "to": [35.0, 0.0, 0.0]}]
     elif which == "cfg2": cfg, root = scenes.cfg2(workdir, xres=128, yres=128, nsamp=9, max_depth=4)
     elif which == "cfg3": cfg, root = scenes.cfg3(workdir, xres=128, yres=128, nsamp=9)
+    elif which == "cfg3_direct":
+        cfg, root = scenes.cfg3(workdir, xres=128, yres=128, nsamp=9)
+        cfg["Integrator"] = {"integrator_type": "DirectLighting", "light_strategy": "all", "max_depth": 3}
     else: cfg, root = scenes.cfg5(workdir, xres=96, yres=96, nsamp=9, max_depth=6, n=64)
     sc = Scene.loads(cfg, root, flags=RRT_FIXED_BVH)
     r = Renderer(sc, 0, RRT_F32)
