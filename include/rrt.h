@@ -32,7 +32,7 @@
 extern "C" {
 #endif
 
-#define RRT_ABI_VERSION 8
+#define RRT_ABI_VERSION 9
 
 /* ---- error codes ------------------------------------------------------- */
 enum {
@@ -296,6 +296,7 @@ typedef struct rrt_render_stats {
   uint64_t closest_launches, any_launches;
   uint64_t closest_nodes, closest_prims;  /* split of nodes_visited / prims_tested per kernel: the roofline's */
   uint64_t any_nodes, any_prims;          /* algorithmic-byte model needs the closest-hit kernel's own counts */
+  uint64_t tile_launches;       /* closest-hit launches over camera rays issued with the per-patch sub-trees ("tile_trees" option) */
 } rrt_render_stats;
 
 /* ---- host side: scene build (stays on the host in the north_star) -------- */

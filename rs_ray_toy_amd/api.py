@@ -198,12 +198,13 @@ class Renderer:
         _check(A.lib().rrt_render_end_stats(self._h, C.byref(st)))
         return st
 
-    def render_bands(self, rank, world, film=None):
+    def render_bands(self, rank, world, film=None, stats=False):
         W, H = self.scene.resolution
         if film is None:
             film = np.zeros((H, W, 4), self.dtype)
-        _check(A.lib().rrt_render_bands(self._h, rank, world, film.ctypes.data, A.RRT_MEM_HOST, None))
-        return film
+        st = A.RenderStats()
+        _check(A.lib().rrt_render_bands(self._h, rank, world, film.ctypes.data, A.RRT_MEM_HOST, C.byref(st) if stats else None))
+        return (film, st) if stats else film
 
     def render_device(self, rect, film_ptr, stats=True):
         st = A.RenderStats()

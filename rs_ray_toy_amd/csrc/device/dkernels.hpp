@@ -11,7 +11,9 @@ constexpr int kBlock = 256;
 // device counters, one 128-byte line each (atomics on different queues must not share an L2 line)
 enum { C_ACTIVE = 0, C_NEXT = 32, C_SHADOW = 64, C_CAMERA_RAYS = 96, C_ERROR = 128, C_WORK_CLOSEST = 160, C_WORK_SHADOW = 192, C_WORK_AUX = 224, C_SHADOW2 = 256,
        // per-XCD work cursors of the persistent traversal kernels: 8 lines each (one cursor per eighth of the queue)
-       C_WORK8_CLOSEST = 288, C_WORK8_SHADOW = 544, C_COUNT = 800 };
+       C_WORK8_CLOSEST = 288, C_WORK8_SHADOW = 544,
+       // queue entries [0, C_TT_DONE) came from the camera workgroups in whole chunks (k_raygen_main_f32's chunk records), the rest from stage B
+       C_TT_DONE = 800, C_COUNT = 832 };
 // shading kernels push to their queues once per block (measured: 256 <= 512 <= 1024 threads by 5 %: smaller blocks retire
 // and refill a CU sooner, and one atomic per 256 paths no longer serialises)
 template <typename R> struct ShadeBlock { static constexpr int n = 256; };

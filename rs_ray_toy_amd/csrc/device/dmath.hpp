@@ -142,6 +142,25 @@ RRT_DEV uint32_t block_push(uint32_t* counter, bool pred, uint32_t* lds) {
   return base + (uint32_t)__popcll(mask & ((1ull << lane) - 1ull));
 }
 
+// block_push() that also reports where the block's entries went: [*first, *first + *total) (`lds` = waves per block + 2 words)
+RRT_DEV uint32_t block_push_range(uint32_t* counter, bool pred, uint32_t* lds, uint32_t* first, uint32_t* total) {
+  const uint64_t mask = __ballot(pred);
+  const uint32_t lane = __lane_id(), w = threadIdx.x >> 6, nw = (blockDim.x + 63u) >> 6;
+  if (lane == 0) lds[w] = (uint32_t)__popcll(mask);
+  __syncthreads();
+  if (threadIdx.x == 0) {
+    uint32_t tot = 0;
+    for (uint32_t k = 0; k < nw; k++) { const uint32_t c = lds[k]; lds[k] = tot; tot += c; }
+    lds[nw] = tot ? atomicAdd(counter, tot) : 0u;
+    lds[nw + 1] = tot;
+  }
+  __syncthreads();
+  *first = lds[nw]; *total = lds[nw + 1];
+  const uint32_t base = lds[nw] + lds[w];
+  __syncthreads();   // lds is reused by the next push
+  return base + (uint32_t)__popcll(mask & ((1ull << lane) - 1ull));
+}
+
 // Rank of this thread among the block's threads with `pred` (block order) and their number: block_push() without the queue.
 // `lds` = (waves per block + 1) words. Must be reached by every thread of the block.
 RRT_DEV uint32_t block_rank(bool pred, uint32_t* lds, uint32_t* total) {

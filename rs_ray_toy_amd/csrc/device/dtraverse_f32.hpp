@@ -569,6 +569,210 @@ __global__ void __launch_bounds__(kPtBlock) k_trace_pt_f32(TravScene ts, Pools<f
 }
 
 // ------------------------------------------------------------------------------------------------------------
+// Camera rays through per-tile sub-trees in LDS ("tile trees").
+// The camera rays of a 32 x 32-pixel patch of the image - some 80 000 of them at 256 spp - visit 260-290 DISTINCT interior nodes of config 4's
+// 49 000 (tools/tile_subtree_stats.py: an 8 x 8 tile 64-150, 16 x 16 170-205), 33-55 each: their node fetches are the same few hundred lines
+// over and over, through the unit the persistent kernel keeps busiest (the vector L1: 39 cycles per 64-lane gather instruction against 8 for
+// a ds_read_b128). Per patch the host lists the kTtNodes pair nodes its rays visit most (rrt_impl.hpp build_tile_trees(): a census with a few
+// camera rays per pixel; counts only decide WHICH nodes are copied) and stores a local copy of them whose child words say "slot k of this
+// copy" (byte offsets below kTtNodes * 64) or "node n of the whole tree" (offsets from there on: TravScene::pairs of this launch is a copy of
+// the whole tree behind kTtNodes unused slots, its interior child words shifted alike). Boxes, leaf words and split axes are the tree's own,
+// so a ray makes the decisions it makes in k_trace_pt_f32, in the same order, whatever the census chose:
+// tests/test_gpu_parity.py::test_tile_trees_change_nothing holds frames bit-identical with and without.
+// The queue is NOT reordered. The camera kernel's workgroup is one 8 x 8 tile x 8 samples and pushes its survivors as one contiguous run
+// (block_push_range): the runs are recorded ("chunks", indexed by workgroup) and an ITEM of work here is the chunks of four neighbouring
+// tiles - 32 x 8 pixels, all samples, ~20 000 rays - walked by one 1 024-thread workgroup with that patch's copy in LDS, lanes refilled from
+// the item's chunks as in k_trace_pt_f32. Survivors of stage B (k_raygen_aux2_f32: the few whose auxiliary rays needed tracing) sit behind
+// the chunked entries in no tile order; they are walked in ranges of kTtRange with the copy of the top of the tree.
+// ------------------------------------------------------------------------------------------------------------
+#ifndef RRT_TT_BLOCK
+#define RRT_TT_BLOCK 1024
+#endif
+#ifndef RRT_TT_STACK
+#define RRT_TT_STACK 8
+#endif
+#ifndef RRT_TT_NODES
+#define RRT_TT_NODES 240
+#endif
+#ifndef RRT_TT_WG_PER_CU
+#define RRT_TT_WG_PER_CU 2
+#endif
+#ifndef RRT_TT_REFILL
+#define RRT_TT_REFILL 16u
+#endif
+#ifndef RRT_TT_NODE_STEPS
+#define RRT_TT_NODE_STEPS 2
+#endif
+#ifndef RRT_TT_VOTE_A
+#define RRT_TT_VOTE_A 1u
+#define RRT_TT_VOTE_B 2u
+#endif
+constexpr int kTtBlock = RRT_TT_BLOCK, kTtStack = RRT_TT_STACK;
+constexpr uint32_t kTtNodes = RRT_TT_NODES;      // pair nodes per local copy (15 KB + 64 KB of stacks: two workgroups per CU, 8 waves per SIMD)
+constexpr uint32_t kTtMacro = 32u;               // edge of the image patch that shares a copy, in pixels
+#ifndef RRT_TT_ITEM_TILES
+#define RRT_TT_ITEM_TILES 2
+#endif
+constexpr uint32_t kTtItemTiles = RRT_TT_ITEM_TILES;            // 8 x 8 tiles per item (one tile row of a patch)
+constexpr uint32_t kTtRange = 16384u, kTtRangeChunk = 256u;
+struct TileTrees {
+  const float4* trees;     // [n_trees + 1][kTtNodes][4]: the local copies, patch by patch (row-major over the image); the last one = top of the tree
+  const uint2* chunks;     // per camera workgroup of the pass (pixel block x sample group): {first queue entry, entries}
+  uint32_t tiles_x, tiles_y;   // 8 x 8 tiles of the pass's pixel grid
+  uint32_t groups;         // camera workgroups (sample groups) per tile
+  uint32_t mt_x, n_trees;  // patches per image row, number of patches
+  PassDesc pd;
+};
+
+// between the camera kernel's two stages: the entries so far are the chunked ones
+static __global__ void k_tt_snapshot(uint32_t* c) { c[C_TT_DONE] = c[C_ACTIVE]; }
+
+template <bool MIXED = false>
+__global__ void __launch_bounds__(kTtBlock) __attribute__((amdgpu_waves_per_eu(RRT_TT_WG_PER_CU * RRT_TT_BLOCK / 256))) k_trace_tiles_f32(TravScene ts, Pools<float> p, const uint32_t* count, uint32_t* work, TileTrees tt,
+                                                                                  uint32_t n_lo, uint32_t n_hi) {
+  const uint32_t n = *count;
+  if (n < n_lo || n >= n_hi) return;
+  __shared__ uint2 stk[kTtStack * kTtBlock];
+  __shared__ float4 tree[kTtNodes * 4];   // bank-swizzled like k_trace_pt_f32's treelet
+  __shared__ uint32_t s_item, s_next;
+  constexpr uint32_t tl_bytes = kTtNodes * 64u;
+  constexpr uint32_t kNone = 0xffffffffu;
+  const uint32_t tid = threadIdx.x, lane = tid & 63u;
+  const uint32_t gtid = blockIdx.x * blockDim.x + tid;   // overflow-stack column of this lane
+  const uint32_t n_done = min(p.counters[C_TT_DONE], n);
+  const uint32_t groups_x = (tt.tiles_x + kTtItemTiles - 1u) / kTtItemTiles;
+  const uint32_t n_tile_items = groups_x * tt.tiles_y;
+  const uint32_t n_items = n_tile_items + (n - n_done + kTtRange - 1u) / kTtRange;
+  const uint32_t home = blockIdx.x & (kXcdParts - 1u);
+  uint32_t parts_done = 0;      // thread 0 only
+  LaneRay r;
+  r.oxy = r.ixy = r.ozz = r.izz = v2f{0.0f, 0.0f};
+  r.dx = r.dy = r.dz = r.tmax = r.lx = r.ly = r.lz = 0.0f; r.neg = 0; r.skip_plane = 0xffffffffu;
+  uint32_t cur = kIdle, qidx = 0, sp = 0;
+  int hit = -1;
+  float hu = 0.0f, hv = 0.0f;
+
+  auto finish = [&]() {
+    p.hit[qidx] = make_float4(r.tmax, __uint_as_float((uint32_t)hit), hu, hv);
+    cur = kIdle;
+  };
+  auto pop = [&]() {   // as in k_trace_pt_f32
+    while (sp > 0) {
+      sp--;
+      uint2 e = stk[(sp < (uint32_t)kTtStack ? sp : 0u) * kTtBlock + tid];
+      asm volatile("" : "+v"(e.x), "+v"(e.y));
+      if (__builtin_expect(sp >= (uint32_t)kTtStack, 0)) e = *reinterpret_cast<const uint2*>(ts.overflow + ((size_t)(sp - kTtStack) * ts.overflow_stride + gtid) * 2);
+      if (__uint_as_float(e.y) < r.tmax) { cur = e.x; return; }
+    }
+    finish();
+  };
+
+  for (;;) {
+    // ---- next item: the items are cut into 8 contiguous parts with their own cursors, the workgroups of an XCD take "their" part first
+    // (as the rays of k_trace_pt_f32: neighbouring items walk neighbouring parts of the tree, which then stay in that XCD's L2)
+    if (tid == 0) {
+      uint32_t item = kNone;
+      while (parts_done < kXcdParts) {
+        const uint32_t part = (home + parts_done) & (kXcdParts - 1u);
+        const uint32_t p_lo = (uint32_t)(((uint64_t)n_items * part) / kXcdParts), p_hi = (uint32_t)(((uint64_t)n_items * (part + 1u)) / kXcdParts);
+        const uint32_t k = atomicAdd(work + 32u * part, 1u);
+        if (k < p_hi - p_lo) { item = p_lo + k; break; }
+        parts_done++;
+      }
+      s_item = item; s_next = 0u;
+    }
+    __syncthreads();
+    const uint32_t item = s_item;
+    if (item == kNone) break;
+    uint32_t tree_id = tt.n_trees, n_chunks, chunk0 = 0, r_lo = 0, r_hi = 0;
+    const bool tiles = item < n_tile_items;
+    if (tiles) {
+      const uint32_t ty = item / groups_x, tx0 = (item % groups_x) * kTtItemTiles;
+      const uint32_t nt = min(kTtItemTiles, tt.tiles_x - tx0), tile0 = ty * tt.tiles_x + tx0;
+      uint32_t px, py;
+      pass_pixel(tt.pd, tile0 * (kTileW * kTileH), &px, &py);
+      tree_id = (py / kTtMacro) * tt.mt_x + px / kTtMacro;
+      n_chunks = nt * tt.groups; chunk0 = tile0 * tt.groups;   // tiles of one tile row are consecutive pixel blocks of the camera kernel's grid
+    } else {
+      r_lo = n_done + (item - n_tile_items) * kTtRange; r_hi = min(n, r_lo + kTtRange);
+      n_chunks = (r_hi - r_lo + kTtRangeChunk - 1u) / kTtRangeChunk;
+    }
+    {
+      const float4* src = tt.trees + (size_t)tree_id * (kTtNodes * 4u);
+      for (uint32_t i = tid; i < kTtNodes * 4u; i += kTtBlock) tree[(i & ~3u) | ((i ^ (i >> 4)) & 3u)] = src[i];
+    }
+    __syncthreads();
+
+    uint32_t lo = 0, hi = 0;      // wave-private run of reserved rays
+    bool exhausted = false;       // wave-uniform: the item has no chunk left
+    while (true) {
+      // ---- refill idle lanes from the item's chunks
+      const uint64_t idle = __ballot(cur == kIdle);
+      const uint32_t n_idle = (uint32_t)__popcll(idle);
+      if (!exhausted && (n_idle >= RRT_TT_REFILL)) {
+        while (lo == hi && !exhausted) {
+          uint32_t k = 0;
+          if (lane == 0) k = atomicAdd(&s_next, 1u);
+          k = (uint32_t)__builtin_amdgcn_readfirstlane((int)k);
+          if (k >= n_chunks) { exhausted = true; break; }
+          if (tiles) { const uint2 c = tt.chunks[chunk0 + k]; lo = c.x; hi = c.x + c.y; }
+          else { lo = r_lo + k * kTtRangeChunk; hi = min(r_hi, lo + kTtRangeChunk); }
+        }
+        if (!exhausted) {
+          const uint32_t take = (hi - lo) < n_idle ? (hi - lo) : n_idle;
+          const uint32_t rank = (uint32_t)__popcll(idle & ((1ull << lane) - 1ull));
+          if (cur == kIdle && rank < take) {
+            qidx = lo + rank;
+            sp = 0; hit = -1; hu = 0.0f; hv = 0.0f;
+            int start_tri;
+            cur = lane_ray_begin<false>(ts, p, false, qidx, r, &start_tri);
+            if (cur == kIdle) finish();
+          }
+          lo += take;
+        }
+      }
+      const uint64_t m_node = __ballot(is_node(cur)), m_leaf = __ballot(is_leaf(cur));
+      if ((m_node | m_leaf) == 0ull) { if (exhausted) break; else continue; }
+      const bool do_node = (uint32_t)__popcll(m_node) * RRT_TT_VOTE_A >= (uint32_t)__popcll(m_leaf) * RRT_TT_VOTE_B;
+      if (do_node) {
+        for (int rep_k = 0; rep_k < RRT_TT_NODE_STEPS; rep_k++) {
+          if (is_node(cur)) {
+            const uint32_t off = cur;
+            float4 a, b, c; uint4 d;
+            if (off < tl_bytes) {
+              const uint32_t x = off ^ ((off >> 4) & 0x30u);   // byte address of word 0's slot
+              const char* lp = reinterpret_cast<const char*>(tree);
+              a = *reinterpret_cast<const float4*>(lp + x); b = *reinterpret_cast<const float4*>(lp + (x ^ 16u)); c = *reinterpret_cast<const float4*>(lp + (x ^ 32u));
+              const float4 dd = *reinterpret_cast<const float4*>(lp + (x ^ 48u));
+              d = make_uint4(__float_as_uint(dd.x), __float_as_uint(dd.y), __float_as_uint(dd.z), 0u);
+            } else {
+              const char* np = reinterpret_cast<const char*>(ts.pairs) + off;
+              a = *reinterpret_cast<const float4*>(np); b = *reinterpret_cast<const float4*>(np + 16); c = *reinterpret_cast<const float4*>(np + 32);
+              d = *reinterpret_cast<const uint4*>(np + 48);
+            }
+            const PairStep st = pair_step_f32<false>(a, b, c, d, r, cur);
+            if (st.push_far) {
+              const uint2 e = make_uint2(st.id_far, __float_as_uint(st.t_far));
+              if (sp < (uint32_t)kTtStack) stk[sp * kTtBlock + tid] = e;
+              else *reinterpret_cast<uint2*>(ts.overflow + ((size_t)(sp - kTtStack) * ts.overflow_stride + gtid) * 2) = e;
+              sp++;
+            }
+            if (st.go_near) cur = st.id_near;
+            else pop();
+          }
+        }
+      } else {
+        if (is_leaf(cur)) {
+          if (leaf_step_f32<false, MIXED>(ts, cur, r, &hit, &hu, &hv)) finish();
+          else pop();
+        }
+      }
+    }
+    __syncthreads();   // every wave is done with this item's copy before the next one is loaded
+  }
+}
+
+// ------------------------------------------------------------------------------------------------------------
 // Shadow rays towards delta lights by candidate lists (no tree walk).
 // An occlusion query is order independent, and a leaf's box test implies its ancestors' (their boxes contain it and every step of the slab
 // arithmetic is monotone under rounding), so BVHAccel::intersect_p's verdict is: "some triangle of some leaf whose OWN box the ray passes is
@@ -829,10 +1033,10 @@ constexpr int kRgRepack = RRT_RG_REPACK;   // lens interfaces traced before the 
 // staging records live in the next-queue arrays, which are free until the first shading launch:
 //   nray_o[i] = {o.xyz (world), slot}, nray_d[i] = {d.xyz (world), weight}, npath[i] = {p_film.xy, p_lens.xy}, hindex[i] = Halton index
 static __global__ void __launch_bounds__(kRgDense) k_raygen_main_f32(SceneDev<float> s, Pools<float> p, PassDesc pd, int write_samp, double* dims_out,
-                                                                     const float2* safe_lim, float aux_delta, float aux_pupil, int enqueue, uint32_t spb) {
+                                                                     const float2* safe_lim, float aux_delta, float aux_pupil, int enqueue, uint32_t spb, uint2* chunks) {
   __shared__ RgLensLds lens;
   __shared__ float2 safe_s[32];
-  __shared__ uint32_t push_lds[kRgDense / 64 + 1];
+  __shared__ uint32_t push_lds[kRgDense / 64 + 2];
   const uint32_t tid = threadIdx.x;
   rg_lens_to_lds(s, &lens, tid);
   if (tid < (uint32_t)s.n_lens) safe_s[tid] = safe_lim ? safe_lim[tid] : make_float2(0.0f, 0.0f);   // 16 c_i = 0: never safe
@@ -901,7 +1105,10 @@ static __global__ void __launch_bounds__(kRgDense) k_raygen_main_f32(SceneDev<fl
   }
   // survivors whose auxiliary rays cannot be blocked are done: straight to q_active; the others wait in the staging queue for stage B
   const bool done = alive & safe, staged = alive & !safe;
-  const uint32_t qa = block_push(&p.counters[C_ACTIVE], done && enqueue, push_lds);
+  uint32_t qa_first, qa_total;
+  const uint32_t qa = block_push_range(&p.counters[C_ACTIVE], done && enqueue, push_lds, &qa_first, &qa_total);
+  // chunk record of this workgroup (k_trace_tiles_f32): its entries of the first queue are one contiguous run, all from one tile of the image
+  if (chunks && tid == 0) chunks[(size_t)(blockIdx.z * gridDim.y + blockIdx.y) * gridDim.x + blockIdx.x] = make_uint2(qa_first, qa_total);
   const uint32_t qs = block_push(&p.counters[C_NEXT], staged, push_lds);
   (void)block_push(&p.counters[C_CAMERA_RAYS], done, push_lds);
   if (alive) {

@@ -3,11 +3,13 @@
 // One HIP stream per handle; no host synchronisation inside a frame (queue sizes are read on the device).
 #pragma once
 #include <algorithm>
+#include <atomic>
 #include <chrono>
 #include <cmath>
 #include <cstdio>
 #include <cstring>
 #include <memory>
+#include <queue>
 #include <stdexcept>
 #include <string>
 #include <thread>
@@ -459,7 +461,7 @@ struct FrameRec {
   std::vector<hipEvent_t> all;
   std::vector<std::pair<int, std::pair<hipEvent_t, hipEvent_t>>> evs;   // category, begin, end
   hipEvent_t ev_begin = nullptr, ev_end = nullptr;
-  uint64_t n_closest_launch = 0, n_any_launch = 0, camera_samples = 0;
+  uint64_t n_closest_launch = 0, n_any_launch = 0, n_tile_launch = 0, camera_samples = 0;
   bool timing = false;
   hipEvent_t make() { hipEvent_t e = nullptr; HIP_CHECK(hipEventCreate(&e)); all.push_back(e); return e; }
   ~FrameRec() { for (hipEvent_t e : all) (void)hipEventDestroy(e); }   // on every way out (a panic / HIP error thrown mid-frame included)
@@ -515,6 +517,8 @@ class Handle : public HandleBase {
     else if (key == "persistent_traversal") { persistent_ = v != 0; if (v >= 1) trav_mode_ = (int)v; }
     else if (key == "raygen_pt") raygen_pt_ = v != 0 ? 2 : 0;   // 0: generic two-stage kernels (the reference's operation order), otherwise (default): dense two-stage kernels with the lean lens arithmetic
     else if (key == "tile_order") tile_order_ = v != 0;
+    else if (key == "tile_trees") tile_trees_on_ = v != 0;
+    else if (key == "tt_census") { tt_census_spp_ = std::max(1, (int)v); tt_state_ = 0; }
     else if (key == "shadow_lists") shadow_lists_on_ = v != 0;
     else if (key == "sl_grid") sl_grid_cap_ = std::max(1, (int)v);
     else if (key == "rg_spb") rg_spb_ = (int)v;
@@ -696,6 +700,12 @@ class Handle : public HandleBase {
       P = std::max<size_t>(64, std::min(P, (free_b / 4) / per_slot));
     }
     ensure_pools(P);
+    if constexpr (std::is_same<R, float>::value) {
+      if (tt_state_ == 0 && tile_trees_on_) {
+        build_tile_trees();
+        HIP_CHECK(hipMemsetAsync(counters_.p, 0, C_COUNT * sizeof(uint32_t), st_));   // the census ran the camera kernels
+      }
+    }
     const size_t group = std::min(rpix, cap_);                           // pixels per group
     const uint64_t s_chunk = std::max<uint64_t>(1, cap_ / group);         // samples per pass
     const bool timing = stats != nullptr || (defer_ && frame_stats_);
@@ -741,8 +751,9 @@ class Handle : public HandleBase {
           for (int b = 0; b < max_depth; b++) {
             hipLaunchKernelGGL(k_accumulate_counts, dim3(1), dim3(1), 0, st_, counters_.p, totals_.p);
             e = tick(1);
-            launch_closest(nullptr, &counters_.p[C_ACTIVE], 0, count_traversal_, nullptr, nullptr, count_traversal_ ? totals_.p : nullptr, grid);
+            launch_closest(nullptr, &counters_.p[C_ACTIVE], 0, count_traversal_, nullptr, nullptr, count_traversal_ ? totals_.p : nullptr, grid, b == 0);
             tock(e); n_closest_launch++;
+            if (b == 0 && tt_pass_ok_ && !count_traversal_ && use_persistent()) fr->n_tile_launch++;
             if (overlap) {
               use_shadow_queue(b & 1);
               if (b > 1) HIP_CHECK(hipStreamWaitEvent(st_, ev_shadow_[b & 1], 0));   // shading refills the queue the shadow launch of bounce b - 2 read
@@ -806,8 +817,9 @@ class Handle : public HandleBase {
           for (int level = 0; level < std::max(1, max_depth - 1); level++) {
             hipLaunchKernelGGL(k_accumulate_counts, dim3(1), dim3(1), 0, st_, counters_.p, totals_.p);
             e = tick(1);
-            launch_closest(nullptr, &counters_.p[C_ACTIVE], 0, count_traversal_, nullptr, nullptr, count_traversal_ ? totals_.p : nullptr, grid);
+            launch_closest(nullptr, &counters_.p[C_ACTIVE], 0, count_traversal_, nullptr, nullptr, count_traversal_ ? totals_.p : nullptr, grid, level == 0);
             tock(e); n_closest_launch++;
+            if (level == 0 && tt_pass_ok_ && !count_traversal_ && use_persistent()) fr->n_tile_launch++;
             if (desc_.n_lights > 0) {
               const int nl = all ? (int)desc_.n_lights : 1;
               for (int j = 0; j < nl; j++) {
@@ -880,6 +892,7 @@ class Handle : public HandleBase {
     stats->closest_nodes = ht[0]; stats->closest_prims = ht[1]; stats->any_nodes = ht[5]; stats->any_prims = ht[6];
     stats->closest_launches = fr.n_closest_launch;
     stats->any_launches = fr.n_any_launch;
+    stats->tile_launches = fr.n_tile_launch;
     if (!fr.timing) return;
     float ms = 0;
     HIP_CHECK(hipEventElapsedTime(&ms, fr.ev_begin, fr.ev_end));
@@ -930,6 +943,19 @@ class Handle : public HandleBase {
   bool shadow_lists_ok_ = false, shadow_lists_on_ = true;   // built for this scene / option "shadow_lists"
   bool any_entry_on_ = true;
   std::vector<uint32_t> newidx_keep_;      // build_pairs(): BFS renumbering of the pair nodes
+  // tile trees (dtraverse_f32.hpp k_trace_tiles_f32): per 32 x 32-pixel patch of the image, a local copy of the pair nodes its camera rays visit most
+  bool tile_trees_on_ = true;              // option "tile_trees"
+  int tt_census_spp_ = 2;                  // option "tt_census": camera samples per pixel of the census
+  int tt_state_ = 0;                       // 0 = not built yet, 1 = built, -1 = not for this scene
+  std::vector<PairNode> pairs_host_;       // build_pairs(): the kernels' tree, kept for the census walk
+  std::vector<Tri<float>> tris_host_;
+  DevBuf<PairNode> tt_pairs_;              // kTtNodes unused slots, then the whole tree with its interior child words shifted by kTtNodes * 64
+  DevBuf<PairNode> tt_trees_;              // [patches + 1][kTtNodes]
+  DevBuf<uint2> tt_chunks_;
+  DevBuf<uint32_t> tt_overflow_;
+  uint32_t tt_grid_ = 0, tt_mt_x_ = 0, tt_n_trees_ = 0;
+  TileTrees tt_pass_{};                    // this pass
+  bool tt_pass_ok_ = false;
   DevBuf<uint32_t> pix_off_;
   TravScene trav_{};
   DevBuf<PairNode> pairs_;
@@ -1497,10 +1523,11 @@ class Handle : public HandleBase {
   // active <- next for the queue and for the rays stored at its positions
   void swap_queues() { std::swap(pool_.q_active, pool_.q_next); std::swap(pool_.ray_o, pool_.nray_o); std::swap(pool_.ray_d, pool_.nray_d); std::swap(pool_.path, pool_.npath); }
 
+  // camera_rays: the queue is the one the camera kernels of this pass filled (tile trees, where the pass has them)
   void launch_closest(const uint32_t* queue, const uint32_t* count, uint32_t n_fixed, bool counting, uint32_t* cn, uint32_t* cp,
-                      unsigned long long* totals, uint32_t grid_override = 0) {
+                      unsigned long long* totals, uint32_t grid_override = 0, bool camera_rays = false) {
     const uint32_t grid = grid_override ? grid_override : (uint32_t)((n_fixed + kBlock - 1) / kBlock);
-    if (!counting && use_persistent()) { launch_persistent(false, queue, count, n_fixed, grid, nullptr); return; }
+    if (!counting && use_persistent()) { launch_persistent(false, queue, count, n_fixed, grid, nullptr, nullptr, camera_rays && tt_pass_ok_ && count != nullptr); return; }
     uint32_t* ds = deep_ ? deep_stack_.p : nullptr;
     const uint32_t stride = deep_ ? (uint32_t)cap_ : 0u;
     if (deep_) {
@@ -1515,6 +1542,7 @@ class Handle : public HandleBase {
   // camera ray generation: the dense lean-arithmetic kernels in fp32 (dtraverse_f32.hpp), the generic two-stage kernels (main trace, auxiliary traces; the
   // reference's operation order) in f64 and for what the dense ones do not cover
   void launch_raygen(const PassDesc& pd, uint32_t grid, double* dims_out, int enqueue) {
+    tt_pass_ok_ = false;
     if constexpr (std::is_same<R, float>::value) {
       // the dense fp32 kernels cover Halton scenes with lenses of up to 32 interfaces on films below 65 536 px per side; everything else
       // (StratifiedSampler, longer lens tables) takes the generic kernels below, which have no such limits
@@ -1533,7 +1561,17 @@ class Handle : public HandleBase {
           // samples / pixels per workgroup: 8 samples of one 8 x 8-pixel tile (PassDesc::tiled) where the pass has that many, else one sample of 512 pixels
           const uint32_t spb = (pd.tiled && pd.ns >= (uint32_t)rg_spb_) ? (uint32_t)std::max(1, std::min(rg_spb_, kRgDense / 64)) : 1u, ppb = kRgDense / spb;
           const uint32_t n_pb = (pd.npix + ppb - 1) / ppb, gz = (n_pb + 65534u) / 65535u, gy = (n_pb + gz - 1) / gz;
-          hipLaunchKernelGGL(k_raygen_main_f32, dim3((pd.ns + spb - 1) / spb, gy, gz), dim3(kRgDense), 0, st_, scene_, pool_, pd, write_samp, dims_out, safe_r2, aux_delta_, aux_pupil_, enqueue, spb);
+          // tile trees: the pass qualifies when it covers the whole pixel grid of its rect in tile order with one 8 x 8 tile x 8 samples per camera workgroup
+          if (tt_state_ == 1 && tile_trees_on_ && enqueue && pd.tiled && spb == 8 && ppb == kTileW * kTileH && pd.pix_begin == 0 && pd.npix % ((uint32_t)pd.rw * kTileH) == 0 &&
+              pd.ns % spb == 0 && use_persistent() && trav_mode_ == 3 && !count_traversal_) {
+            const size_t n_chunks = (size_t)gy * gz * ((pd.ns + spb - 1) / spb);
+            if (tt_chunks_.n < n_chunks) { HIP_CHECK(hipStreamSynchronize(st_)); tt_chunks_.alloc(n_chunks); }
+            tt_pass_ = TileTrees{reinterpret_cast<const float4*>(tt_trees_.p), tt_chunks_.p, (uint32_t)pd.rw / kTileW, pd.npix / (uint32_t)pd.rw / kTileH, pd.ns / spb, tt_mt_x_, tt_n_trees_, pd};
+            tt_pass_ok_ = true;
+          }
+          hipLaunchKernelGGL(k_raygen_main_f32, dim3((pd.ns + spb - 1) / spb, gy, gz), dim3(kRgDense), 0, st_, scene_, pool_, pd, write_samp, dims_out, safe_r2, aux_delta_, aux_pupil_, enqueue, spb,
+                             tt_pass_ok_ ? tt_chunks_.p : nullptr);
+          if (tt_pass_ok_) hipLaunchKernelGGL(k_tt_snapshot, dim3(1), dim3(1), 0, st_, counters_.p);
           hipLaunchKernelGGL(k_raygen_aux2_f32, dim3((total + kRgDense - 1) / kRgDense), dim3(kRgDense), 0, st_, scene_, pool_, enqueue);
           hipLaunchKernelGGL(k_rotate, dim3(1), dim3(1), 0, st_, counters_.p, 4);   // q_next was only a staging queue
         }
@@ -1548,7 +1586,7 @@ class Handle : public HandleBase {
   }
   // fp32 production traversal (dtraverse_f32.hpp): 64 B pair nodes, LDS stack with global overflow
   bool use_persistent() const { return std::is_same<R, float>::value && persistent_ && pairs_ok_; }
-  void launch_persistent(bool any, const uint32_t* queue, const uint32_t* count, uint32_t n_fixed, uint32_t grid, uint8_t* occluded, hipStream_t stream = nullptr) {
+  void launch_persistent(bool any, const uint32_t* queue, const uint32_t* count, uint32_t n_fixed, uint32_t grid, uint8_t* occluded, hipStream_t stream = nullptr, bool tiles = false) {
     if constexpr (std::is_same<R, float>::value) {
       if (!stream) stream = st_;
       const uint32_t grid_in = grid;
@@ -1590,7 +1628,22 @@ class Handle : public HandleBase {
           else hipLaunchKernelGGL((k_trace_pairs_f32<false, false>), dim3(grid), dim3(kTravBlock), 0, stream, trav_, pool_, queue, count, n_fixed, occluded, 0u, hi_gs);
         }
       }
-      if (trav_mode_ != 1) {
+      if (trav_mode_ != 1 && tiles) {   // camera rays of a pass with chunk records: k_trace_tiles_f32 in the persistent kernel's place
+        if (tt_grid_ == 0) {
+          int per_cu = 0, cus = 0;
+          HIP_CHECK(hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, dev_));
+          HIP_CHECK(hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu, (k_trace_tiles_f32<false>), kTtBlock, 0));
+          tt_grid_ = (uint32_t)(std::max(1, per_cu) * std::max(1, cus));
+          if (scene_.stack_depth > (uint32_t)kTtStack) tt_overflow_.alloc((size_t)(scene_.stack_depth - kTtStack) * (size_t)tt_grid_ * kTtBlock * 2);
+          if (getenv("RRT_DEBUG")) fprintf(stderr, "[rrt] tile trees: %d workgroup(s) of %d threads per CU, grid %u\n", per_cu, kTtBlock, tt_grid_);
+        }
+        TravScene t2 = trav_;
+        t2.pairs = tt_pairs_.p; t2.root_id = 0u;   // slot 0 of every local copy is the root
+        t2.overflow = tt_overflow_.p;
+        t2.overflow_stride = tt_grid_ * kTtBlock;
+        uint32_t* work = &counters_.p[C_WORK8_CLOSEST];
+        hipLaunchKernelGGL((k_trace_tiles_f32<false>), dim3(tt_grid_), dim3(kTtBlock), 0, stream, t2, pool_, count, work, tt_pass_, lo_pt, 0xffffffffu);
+      } else if (trav_mode_ != 1) {
         if (pt_grid_ == 0) {
           int per_cu = 0, cus = 0;
           HIP_CHECK(hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, dev_));
@@ -1614,6 +1667,182 @@ class Handle : public HandleBase {
         }
       }
       HIP_CHECK(hipGetLastError());
+    }
+  }
+  // Tile trees (dtraverse_f32.hpp, k_trace_tiles_f32): per 32 x 32-pixel patch of the image, a local copy of the kTtNodes pair nodes its camera rays visit
+  // most. The census: a few camera samples per pixel through the product's own camera kernels, their rays walked here on the host (plain fp32 slab and
+  // Moeller-Trumbore tests, hits accepted like Q10) with a visit counter per pair node and patch. The counts only decide which nodes are copied; what a
+  // copy says about a node is the tree's own data, so no result depends on them. A set of most-visited nodes is closed under "parent" (a parent is
+  // visited at least as often as its child and has the smaller index, which breaks ties), so every copied node can be reached through copies.
+  void build_tile_trees() {
+    tt_state_ = -1;
+    if constexpr (std::is_same<R, float>::value) {
+      const size_t n_int = pairs_host_.size();
+      const bool pt_ok = scene_.n_lens <= 32 && scene_.sampler_type == RRT_SAMPLER_HALTON && scene_.xres < 65536 && scene_.yres < 65536;
+      if (!use_persistent() || mixed_ || !pt_ok || raygen_pt_ < 1 || n_int <= kTtNodes || trav_.root_id != 0u || (uint64_t)(n_int + kTtNodes) * 64u >= kIdle) return;
+      const uint64_t s_total = desc_.sampler.samples_per_pixel > 1 ? desc_.sampler.samples_per_pixel - 1 : 0;
+      if (s_total == 0 || cap_ == 0) return;
+      const auto t_begin = std::chrono::steady_clock::now();
+      const size_t W = (size_t)desc_.film.xres, H = (size_t)desc_.film.yres;
+      const uint32_t mt_x = (uint32_t)((W + kTtMacro - 1) / kTtMacro), mt_y = (uint32_t)((H + kTtMacro - 1) / kTtMacro), n_trees = mt_x * mt_y;
+      const uint32_t S = (uint32_t)std::min<uint64_t>((uint64_t)tt_census_spp_, s_total);
+      // ---- camera rays of the census, bucketed by patch
+      struct CRay { float o[3], d[3]; };
+      std::vector<CRay> rays;
+      std::vector<uint32_t> tree_of;
+      {
+        const size_t group = std::max<size_t>(1, std::min(W * H, cap_ / S));
+        std::vector<QEnt> q; std::vector<float4> ro, rd;
+        const bool save_ok = tt_pass_ok_;
+        for (size_t g0 = 0; g0 < W * H; g0 += group) {
+          const size_t npix = std::min(group, W * H - g0);
+          PassDesc pd{0, 0, (int32_t)W, (uint32_t)g0, (uint32_t)npix, 1u, S, 1u << 30, 1u, 0u, 0u};
+          HIP_CHECK(hipMemsetAsync(counters_.p, 0, C_COUNT * sizeof(uint32_t), st_));
+          launch_raygen(pd, (uint32_t)((npix * S + kBlock - 1) / kBlock), nullptr, 1);
+          uint32_t n = 0;
+          HIP_CHECK(hipMemcpyAsync(&n, counters_.p + C_ACTIVE, sizeof(n), hipMemcpyDeviceToHost, st_));
+          HIP_CHECK(hipStreamSynchronize(st_));
+          q.resize(n); ro.resize(n); rd.resize(n);
+          if (n) {
+            HIP_CHECK(hipMemcpy(q.data(), pool_.q_active, (size_t)n * sizeof(QEnt), hipMemcpyDeviceToHost));
+            HIP_CHECK(hipMemcpy(ro.data(), pool_.ray_o, (size_t)n * sizeof(float4), hipMemcpyDeviceToHost));
+            HIP_CHECK(hipMemcpy(rd.data(), pool_.ray_d, (size_t)n * sizeof(float4), hipMemcpyDeviceToHost));
+          }
+          for (uint32_t i = 0; i < n; i++) {
+            const size_t lin = g0 + q[i].slot % npix, x = lin % W, y = lin / W;
+            rays.push_back(CRay{{ro[i].x, ro[i].y, ro[i].z}, {rd[i].x, rd[i].y, rd[i].z}});
+            tree_of.push_back((uint32_t)((y / kTtMacro) * mt_x + x / kTtMacro));
+          }
+        }
+        tt_pass_ok_ = save_ok;
+      }
+      std::vector<uint32_t> first(n_trees + 1, 0), order(rays.size());
+      for (uint32_t t : tree_of) first[t + 1]++;
+      for (uint32_t t = 0; t < n_trees; t++) first[t + 1] += first[t];
+      { std::vector<uint32_t> at(first.begin(), first.end() - 1); for (uint32_t i = 0; i < (uint32_t)rays.size(); i++) order[at[tree_of[i]]++] = i; }
+
+      // ---- per patch: walk, count, choose, copy
+      std::vector<PairNode> trees((size_t)(n_trees + 1) * kTtNodes);
+      memset(trees.data(), 0, trees.size() * sizeof(PairNode));
+      const uint32_t shift = kTtNodes * 64u;
+      auto slab = [](const float bmin[3], const float bmax[3], const float o[3], const float inv[3], float* t) {
+        float tn = -INFINITY, tf = INFINITY;
+        for (int k = 0; k < 3; k++) { const float a = (bmin[k] - o[k]) * inv[k], b = (bmax[k] - o[k]) * inv[k]; tn = std::max(tn, std::min(a, b)); tf = std::min(tf, std::max(a, b)); }
+        *t = tn;
+        return tn <= tf * 1.0000004f && tf > 0.0f;
+      };
+      auto copy_into = [&](PairNode* dst, const std::vector<uint32_t>& sel, std::vector<uint32_t>& slot_of) {   // sel ascending; slot_of: all-ones scratch, restored
+        for (uint32_t k = 0; k < (uint32_t)sel.size(); k++) slot_of[sel[k]] = k;
+        for (uint32_t k = 0; k < (uint32_t)sel.size(); k++) {
+          PairNode nd = pairs_host_[sel[k]];
+          for (uint32_t* id : {&nd.id0, &nd.id1}) if (!(*id & kLeafBit)) { const uint32_t c = slot_of[*id / 64u]; *id = c != 0xffffffffu ? c * 64u : *id + shift; }
+          dst[k] = nd;
+        }
+        for (uint32_t k : sel) slot_of[k] = 0xffffffffu;
+      };
+      std::vector<uint32_t> top(kTtNodes);
+      for (uint32_t k = 0; k < kTtNodes; k++) top[k] = k;
+      { std::vector<uint32_t> slot_of(n_int, 0xffffffffu); copy_into(&trees[(size_t)n_trees * kTtNodes], top, slot_of); }
+      std::atomic<uint32_t> next_tree{0};
+      std::atomic<uint64_t> sum_nodes{0}, n_with{0};
+      auto worker = [&]() {
+        std::vector<uint32_t> counts(n_int, 0), touched, slot_of(n_int, 0xffffffffu), sel;
+        struct E { uint32_t w; float t; };
+        std::vector<E> stack;
+        for (;;) {
+          const uint32_t t = next_tree.fetch_add(1);
+          if (t >= n_trees) break;
+          touched.clear();
+          for (uint32_t ri = first[t]; ri < first[t + 1]; ri++) {
+            const CRay& ray = rays[order[ri]];
+            float inv[3]; bool neg[3];
+            for (int k = 0; k < 3; k++) { inv[k] = 1.0f / ray.d[k]; neg[k] = inv[k] < 0.0f; }
+            float tmax = INFINITY, tb;
+            if (!slab(trav_.root_box, trav_.root_box + 3, ray.o, inv, &tb)) continue;
+            stack.clear();
+            uint32_t cur = 0u;
+            for (;;) {
+              if (!(cur & kLeafBit)) {
+                const uint32_t k = cur / 64u;
+                if (counts[k]++ == 0) touched.push_back(k);
+                const PairNode& nd = pairs_host_[k];
+                const float b0min[3] = {nd.xy0[0], nd.xy0[1], nd.zz[0]}, b0max[3] = {nd.xy0[2], nd.xy0[3], nd.zz[1]};
+                const float b1min[3] = {nd.xy1[0], nd.xy1[1], nd.zz[2]}, b1max[3] = {nd.xy1[2], nd.xy1[3], nd.zz[3]};
+                float t0, t1;
+                const bool h0 = slab(b0min, b0max, ray.o, inv, &t0), h1 = slab(b1min, b1max, ray.o, inv, &t1);
+                const bool sf = neg[nd.axis & 3u];
+                const uint32_t id_near = sf ? nd.id1 : nd.id0, id_far = sf ? nd.id0 : nd.id1;
+                const bool h_near = sf ? h1 : h0, h_far = sf ? h0 : h1;
+                const float t_near = sf ? t1 : t0, t_far = sf ? t0 : t1;
+                if (h_far) stack.push_back(E{id_far, t_far});
+                if (h_near && t_near < tmax) { cur = id_near; continue; }
+              } else if (!(cur & kSpecialLeaf)) {
+                uint32_t lf = cur & 0x7ffffu, ln = (cur >> 19) & kLeafCountMask;
+                for (; ln; lf++, ln--) {
+                  const Tri<float>& tr = tris_host_[lf];
+                  const float e1[3] = {tr.p1[0] - tr.p0[0], tr.p1[1] - tr.p0[1], tr.p1[2] - tr.p0[2]}, e2[3] = {tr.p2[0] - tr.p0[0], tr.p2[1] - tr.p0[1], tr.p2[2] - tr.p0[2]};
+                  const float* d = ray.d;
+                  const float pv[3] = {d[1] * e2[2] - d[2] * e2[1], d[2] * e2[0] - d[0] * e2[2], d[0] * e2[1] - d[1] * e2[0]};
+                  const float det = e1[0] * pv[0] + e1[1] * pv[1] + e1[2] * pv[2];
+                  if (det > -1e-7f && det < 1e-7f) continue;
+                  const float f = 1.0f / det, tv[3] = {ray.o[0] - tr.p0[0], ray.o[1] - tr.p0[1], ray.o[2] - tr.p0[2]};
+                  const float u = f * (tv[0] * pv[0] + tv[1] * pv[1] + tv[2] * pv[2]);
+                  if (u < 0.0f || u > 1.0f) continue;
+                  const float qv[3] = {tv[1] * e1[2] - tv[2] * e1[1], tv[2] * e1[0] - tv[0] * e1[2], tv[0] * e1[1] - tv[1] * e1[0]};
+                  const float v = f * (d[0] * qv[0] + d[1] * qv[1] + d[2] * qv[2]);
+                  if (v < 0.0f || u + v > 1.0f) continue;
+                  const float tt = f * (e2[0] * qv[0] + e2[1] * qv[1] + e2[2] * qv[2]);
+                  if (tt >= 1e-7f) tmax = tt;
+                }
+              }
+              bool got = false;
+              while (!stack.empty()) { const E e = stack.back(); stack.pop_back(); if (e.t < tmax) { cur = e.w; got = true; break; } }
+              if (!got) break;
+            }
+          }
+          PairNode* dst = &trees[(size_t)t * kTtNodes];
+          if (touched.empty()) { memcpy(dst, &trees[(size_t)n_trees * kTtNodes], kTtNodes * sizeof(PairNode)); continue; }
+          std::sort(touched.begin(), touched.end(), [&](uint32_t a, uint32_t b) { return counts[a] != counts[b] ? counts[a] > counts[b] : a < b; });
+          sel.assign(touched.begin(), touched.begin() + std::min<size_t>(touched.size(), kTtNodes));
+          if (sel.size() < kTtNodes) {   // room left: children of the chosen nodes, the most visited parents' first
+            std::priority_queue<std::pair<float, uint32_t>> cand;
+            for (uint32_t k : sel) slot_of[k] = 0u;
+            auto offer = [&](uint32_t k, float pr) { const PairNode& nd = pairs_host_[k]; for (uint32_t id : {nd.id0, nd.id1}) if (!(id & kLeafBit) && slot_of[id / 64u] == 0xffffffffu) cand.push({pr, id / 64u}); };
+            for (uint32_t k : sel) offer(k, 0.5f * (float)counts[k]);
+            while (sel.size() < kTtNodes && !cand.empty()) {
+              const auto c = cand.top(); cand.pop();
+              if (slot_of[c.second] != 0xffffffffu) continue;
+              sel.push_back(c.second); slot_of[c.second] = 0u;
+              offer(c.second, 0.5f * c.first);
+            }
+            for (uint32_t k : sel) slot_of[k] = 0xffffffffu;
+          }
+          std::sort(sel.begin(), sel.end());
+          copy_into(dst, sel, slot_of);
+          sum_nodes += touched.size(); n_with++;
+          for (uint32_t k : touched) counts[k] = 0;
+        }
+      };
+      {
+        const unsigned nt = std::max(1u, std::min(16u, std::thread::hardware_concurrency()));
+        std::vector<std::thread> pool;
+        for (unsigned k = 0; k < nt; k++) pool.emplace_back(worker);
+        for (auto& th : pool) th.join();
+      }
+      std::vector<PairNode> shifted(kTtNodes + n_int);
+      memset(shifted.data(), 0, kTtNodes * sizeof(PairNode));
+      for (size_t i = 0; i < n_int; i++) {
+        PairNode nd = pairs_host_[i];
+        for (uint32_t* id : {&nd.id0, &nd.id1}) if (!(*id & kLeafBit)) *id += shift;
+        shifted[kTtNodes + i] = nd;
+      }
+      tt_pairs_.upload(shifted, st_); tt_trees_.upload(trees, st_);
+      HIP_CHECK(hipStreamSynchronize(st_));
+      tt_mt_x_ = mt_x; tt_n_trees_ = n_trees;
+      tt_state_ = 1;
+      if (getenv("RRT_DEBUG")) fprintf(stderr, "[rrt] tile trees: %u patches of %u x %u pixels, %zu census rays (%u spp), %.1f distinct pair nodes visited per patch with rays (%llu patches), %.1f MB, built in %.3f s\n",
+                                       n_trees, kTtMacro, kTtMacro, rays.size(), S, n_with ? (double)sum_nodes / (double)n_with : 0.0, (unsigned long long)n_with.load(),
+                                       (double)(trees.size() * sizeof(PairNode)) / 1e6, std::chrono::duration<double>(std::chrono::steady_clock::now() - t_begin).count());
     }
   }
   // re-pack the linear BVH into pair nodes (see dtraverse_f32.hpp)
@@ -1762,6 +1991,7 @@ class Handle : public HandleBase {
       }
       pairs_.upload(packed, st_);
       HIP_CHECK(hipStreamSynchronize(st_));
+      if constexpr (std::is_same<R, float>::value) { pairs_host_ = packed; tris_host_.assign(tris.begin(), tris.end()); }
       trav_.any_list = (any_entry_on_ && any_list_.n) ? reinterpret_cast<const uint4*>(any_list_.p) : nullptr;
       trav_.pairs = pairs_.p;
       trav_.tris = reinterpret_cast<const float*>(tris_.p);

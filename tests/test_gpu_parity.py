@@ -649,6 +649,43 @@ def test_tile_order_of_the_pixels_changes_nothing(which, workdir):
             assert np.array_equal(out[3][0], out[2][0])
 
 
+@pytest.mark.parametrize("which", ["cfg4", "cfg4_odd_width", "cfg4_two_groups", "cfg4_bands", "cfg4_direct", "cfg4_passes", "cfg2_small_tree"])
+def test_tile_trees_change_nothing(which, workdir):
+    """Camera rays walk the tree through per-patch local copies of its most visited pair nodes in LDS (dtraverse_f32.hpp k_trace_tiles_f32,
+    rrt_impl.hpp build_tile_trees()): the copies hold the tree's own boxes, leaf words and split axes - only the child words of a copy say
+    "slot k of this copy" or "node n of the tree" - and the queue is not reordered, so every ray makes the same decisions in the same order
+    whatever the census chose to copy. Frames, weights and query counts with and without are identical bit for bit: whole 32-pixel patches and
+    a width of 13 tiles, one and two sample groups per tile, a rank's bands, DirectLighting's first level, and two census densities. Passes
+    that do not cover the pixel grid in whole tile rows x 8 samples (small max_paths) and trees that fit a copy anyway keep the ordinary kernel
+    (tile_launches = 0)."""
+    kw = dict(xres=128, yres=96, nsamp=9, max_depth=5, n=64)
+    if which == "cfg4_odd_width": kw.update(xres=104, yres=72)
+    if which == "cfg4_two_groups": kw.update(nsamp=17)
+    if which == "cfg2_small_tree": cfg, root = scenes.cfg2(workdir, xres=64, yres=96, nsamp=9, max_depth=3)
+    else: cfg, root = scenes.cfg4(workdir, **kw)
+    if which == "cfg4_direct": cfg["Integrator"] = {"integrator_type": "DirectLighting", "max_depth": 3, "light_strategy": "UniformSampleAll"}
+    sc = Scene.loads(cfg, root, flags=RRT_FIXED_BVH)
+    r = Renderer(sc, 0, RRT_F32)
+    r.set_option("pt_split_closest", 0)    # the persistent kernels at every queue size (the product switches at 100 000 rays)
+    if which == "cfg4_passes": r.set_option("max_paths", 128 * 96 * 3)
+    out = {}
+    for tt in (1, 0, 2):
+        r.set_option("tile_trees", 1 if tt else 0)
+        if tt == 2: r.set_option("tt_census", 1)      # a sparser census: other copies, same frames
+        if which == "cfg4_bands":
+            out[tt] = [r.render_bands(k, 3, stats=True) for k in range(3)]
+            out[tt] = (sum(f for f, _ in out[tt]), out[tt][0][1])
+        else:
+            out[tt] = r.render(stats=True)
+    r.close()
+    expect = 0 if which in ("cfg4_passes", "cfg2_small_tree") else 1
+    assert out[1][1].tile_launches == expect and out[2][1].tile_launches == expect and out[0][1].tile_launches == 0, (out[1][1].tile_launches, out[0][1].tile_launches)
+    assert out[1][0][..., :3].max() > 0
+    for tt in (1, 2):
+        assert np.array_equal(out[tt][0], out[0][0])
+        assert (out[tt][1].camera_rays, out[tt][1].closest_queries, out[tt][1].any_queries) == (out[0][1].camera_rays, out[0][1].closest_queries, out[0][1].any_queries)
+
+
 @pytest.mark.parametrize("which", ["cfg4", "cfg4_distant", "cfg4_far", "cfg2", "cfg3", "cfg3_direct", "cfg5_area"])
 def test_shadow_candidate_lists_change_nothing(which, workdir):
     """Shadow rays towards point / distant lights run down a per-(light, triangle) list of candidate leaves instead of walking the tree

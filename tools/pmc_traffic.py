@@ -20,7 +20,7 @@ def kernel_source_hash():   # = bench.py kernel_source_hash(): ties the file to 
             h.update(open(f, "rb").read())
     return h.hexdigest()[:16]
 fam = collections.OrderedDict([
-    ("closest", r"k_trace_(pt|pairs)_f32<false[,>]"), ("any", r"k_trace_(pt|pairs)_f32<true[,>]|k_shadow_lists_f32"),
+    ("closest", r"k_trace_(pt|pairs)_f32<false[,>]|k_trace_tiles_f32"), ("any", r"k_trace_(pt|pairs)_f32<true[,>]|k_shadow_lists_f32"),
     ("raygen", r"k_raygen|k_pixel_offsets"), ("shade", r"k_shade"), ("film", r"k_film|k_accumulate")])
 tot = {k: collections.defaultdict(float) for k in fam}
 disp = {k: collections.defaultdict(int) for k in fam}
