@@ -339,12 +339,13 @@ def main():
         fetch_factor = fetch_src = None
         if traffic is not None:
             fetch_factor, fetch_src = pmc_fetch_factor
-        roofline = {"kernel": "k_trace_pt_f32<false> + k_trace_pairs_f32<false> (closest-hit BVH traversal, one pair per bounce)",
+        roofline = {"kernel": "closest-hit BVH traversal, one launch pair per bounce: k_trace_tiles_f32 (camera rays, per-patch sub-trees in LDS) / k_trace_pt_f32<false> (bounces 1..) + k_trace_pairs_f32<false> (small queues)",
                     "bound": "l2_gather",
                     "achieved": round(gather, 1), "peak": GATHER_L2_GBS, "unit": "GB/s", "frac": round(gather / GATHER_L2_GBS, 4),
                     "traffic": traffic,
                     "what": "gathered bytes per launch (64-B pair-node lines: nodes visited / 2; 48-B triangles tested; 48 B ray + hit record per query; exact device "
-                            "counters of a counting frame of this workload) / average launch duration, against the L2-resident row-gather rate of the guide",
+                            "counters of a counting frame of this workload) / average launch duration, against the L2-resident row-gather rate of the guide; the share of the node lines "
+                            "that the LDS copies serve (treelet, per-patch sub-trees of the camera-ray launch) is counted as gathered: the figure is algorithmic, l1_gather has what reached the vector L1",
                     "gathered_bytes_per_launch": round(gather_bytes / n_launch, 1),
                     "avg_launch_ms": round(launch_s * 1e3, 4), "launches": int(n_launch),
                     "measured": "HIP events on the handle's stream around every closest-hit launch, frames ONE AT A TIME after the timed region (shadow launches beside "

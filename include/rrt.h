@@ -408,7 +408,9 @@ int rrt_film_gather_all(rrt_handle* const* handles, void* const* films_device, i
  * operation order, otherwise = default: dense kernels with the lean lens arithmetic), "shade_spec" (fp32: 1 = default: the path shading kernel instantiated for the lobe kinds the
  * scene's materials can produce - Lambertian only / + Oren-Nayar + microfacet reflection / all -, 0 = always the general kernel; the same arithmetic per lobe), "tile_order" (1 = default: the pixels of a pass are enumerated in 8 x 8 tiles where the rect is made of whole tiles - only the
  * order of the work changes, frames are identical bit for bit), "shadow_lists" (fp32, 1 = default: shadow rays of scenes whose lights are all point / distant lights run down their start
- * triangle's list of candidate leaves instead of walking the tree - the same box and triangle tests, frames identical bit for bit), and three
+ * triangle's list of candidate leaves instead of walking the tree - the same box and triangle tests, frames identical bit for bit), "tile_trees" (fp32, 1 = default:
+ * camera rays walk the tree through per-patch copies of its most visited nodes in LDS where the pass allows it, rrt_render_stats::tile_launches counts those launches -
+ * the same decisions in the same order, frames identical bit for bit; "tt_census" = camera samples per pixel of the census that chooses the nodes, default 2), and three
  * result-invariant shortcuts of the fp32 mode that tests switch off to show that they are (1 = default): "any_entry" (shadow rays start from
  * their triangle's list of deciding nodes instead of the root), "cam_tables" / "halton_tables" (block tables instead of the digit loops of
  * the camera's / the integrators' Halton dimensions) */
