@@ -389,13 +389,14 @@ def test_full_size_frame_properties(workdir):
     """BASELINE config 4 at its full size (100 352 triangles, 1024^2, 256 spp, depth 8), fp32 product path:
     idempotence (bitwise identical frames although queue order depends on atomics), the closed-form filter weight
     sum 3 * (nsamp - 1) in every pixel (Q1, Q2, Q3), the result-invariant shortcuts switched off (auxiliary lens traces, any-hit start
-    lists, Halton block tables: identical frames), a 2-rank band partition that reassembles the frame exactly, and a 32-row slice
+    lists, Halton block tables, tile trees: identical frames), a 2-rank band partition that reassembles the frame exactly, and a 32-row slice
     checked against the f64 oracle at full spp."""
     cfg, root = scenes.cfg4(workdir, xres=1024, yres=1024, nsamp=257, max_depth=8, n=224)
     sc = Scene.loads(cfg, root, flags=RRT_FIXED_BVH)
     r = Renderer(sc, 0, RRT_F32)
     film, st = r.render(stats=True)
     assert st.camera_samples == 1024 * 1024 * 256
+    assert st.tile_launches == 1          # the camera rays went through the per-patch sub-trees (test_tile_trees_change_nothing)
     assert 0.25 < st.camera_rays / st.camera_samples < 0.36
     assert np.all(film[..., 3] == 3.0 * 256.0)
     assert np.isfinite(film).all() and film[..., :3].max() > 0
@@ -406,10 +407,12 @@ def test_full_size_frame_properties(workdir):
     r.set_option("aux_margin", 1)
     assert st_aux.camera_rays == st.camera_rays and np.array_equal(full_aux, film)
     # the shortcuts of the second half of round 2, all at once, at full size: shadow rays from the root instead of their start lists,
-    # Halton digit loops instead of block tables (camera and integrator dimensions) - the same 268 M samples, bit for bit
-    for key in ("any_entry", "cam_tables", "halton_tables"): r.set_option(key, 0)
+    # Halton digit loops instead of block tables (camera and integrator dimensions), camera rays through the ordinary persistent kernel - the same
+    # 268 M samples, bit for bit
+    for key in ("any_entry", "cam_tables", "halton_tables", "tile_trees"): r.set_option(key, 0)
     plain, st_plain = r.render(stats=True)
-    for key in ("any_entry", "cam_tables", "halton_tables"): r.set_option(key, 1)
+    for key in ("any_entry", "cam_tables", "halton_tables", "tile_trees"): r.set_option(key, 1)
+    assert st_plain.tile_launches == 0
     assert (st_plain.camera_rays, st_plain.closest_queries, st_plain.any_queries) == (st.camera_rays, st.closest_queries, st.any_queries)
     assert np.array_equal(plain, film)
     bands = r.render_bands(0, 2)
