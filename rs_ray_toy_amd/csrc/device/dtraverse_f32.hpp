@@ -580,8 +580,8 @@ __global__ void __launch_bounds__(kPtBlock) k_trace_pt_f32(TravScene ts, Pools<f
 // so a ray makes the decisions it makes in k_trace_pt_f32, in the same order, whatever the census chose:
 // tests/test_gpu_parity.py::test_tile_trees_change_nothing holds frames bit-identical with and without.
 // The queue is NOT reordered. The camera kernel's workgroup is one 8 x 8 tile x 8 samples and pushes its survivors as one contiguous run
-// (block_push_range): the runs are recorded ("chunks", indexed by workgroup) and an ITEM of work here is the chunks of four neighbouring
-// tiles - 32 x 8 pixels, all samples, ~20 000 rays - walked by one 1 024-thread workgroup with that patch's copy in LDS, lanes refilled from
+// (block_push_range): the runs are recorded ("chunks", indexed by workgroup) and an ITEM of work here is the chunks of two neighbouring
+// tiles - 16 x 8 pixels, all samples, ~10 000 rays - walked by one 1 024-thread workgroup with that patch's copy in LDS, lanes refilled from
 // the item's chunks as in k_trace_pt_f32. Survivors of stage B (k_raygen_aux2_f32: the few whose auxiliary rays needed tracing) sit behind
 // the chunked entries in no tile order; they are walked in ranges of kTtRange with the copy of the top of the tree.
 // ------------------------------------------------------------------------------------------------------------
@@ -592,7 +592,7 @@ __global__ void __launch_bounds__(kPtBlock) k_trace_pt_f32(TravScene ts, Pools<f
 #define RRT_TT_STACK 8
 #endif
 #ifndef RRT_TT_NODES
-#define RRT_TT_NODES 240
+#define RRT_TT_NODES 232
 #endif
 #ifndef RRT_TT_WG_PER_CU
 #define RRT_TT_WG_PER_CU 2
@@ -601,7 +601,7 @@ __global__ void __launch_bounds__(kPtBlock) k_trace_pt_f32(TravScene ts, Pools<f
 #define RRT_TT_REFILL 16u
 #endif
 #ifndef RRT_TT_NODE_STEPS
-#define RRT_TT_NODE_STEPS 2
+#define RRT_TT_NODE_STEPS 3
 #endif
 #ifndef RRT_TT_VOTE_A
 #define RRT_TT_VOTE_A 1u
@@ -609,6 +609,12 @@ __global__ void __launch_bounds__(kPtBlock) k_trace_pt_f32(TravScene ts, Pools<f
 #endif
 constexpr int kTtBlock = RRT_TT_BLOCK, kTtStack = RRT_TT_STACK;
 constexpr uint32_t kTtNodes = RRT_TT_NODES;      // pair nodes per local copy (15 KB + 64 KB of stacks: two workgroups per CU, 8 waves per SIMD)
+// LDS byte address of slot k of a copy = the child word that names it (see the kernel): 16 bytes of padding after every four slots, so that slots
+// never overlap and the lanes of one read spread over every bank group. kTtLocalBytes: the first byte offset that means "node of the whole tree".
+constexpr uint32_t tt_local_addr(uint32_t k) { return 64u * k + 16u * (k >> 2); }
+constexpr uint32_t kTtLocalBytes = (tt_local_addr(kTtNodes - 1u) + 64u + 63u) & ~63u;
+constexpr bool tt_local_layout_ok() { for (uint32_t k = 0; k + 1u < kTtNodes; k++) if (tt_local_addr(k + 1u) < tt_local_addr(k) + 64u) return false; return true; }
+static_assert(tt_local_layout_ok() && kTtLocalBytes + (uint32_t)kTtStack * kTtBlock * 8u + 8u <= (160u * 1024u) / RRT_TT_WG_PER_CU - 512u, "tile trees: LDS layout / budget");
 constexpr uint32_t kTtMacro = 32u;               // edge of the image patch that shares a copy, in pixels
 #ifndef RRT_TT_ITEM_TILES
 #define RRT_TT_ITEM_TILES 2
@@ -632,10 +638,14 @@ __global__ void __launch_bounds__(kTtBlock) __attribute__((amdgpu_waves_per_eu(R
                                                                                   uint32_t n_lo, uint32_t n_hi) {
   const uint32_t n = *count;
   if (n < n_lo || n >= n_hi) return;
+  // The copy comes first in LDS: its byte addresses are the local child words themselves and fit the 16-bit offset field of ds_read_b128.
+  // Slot k of the copy lives at tt_local_addr(k) = 64 k + 16 (k >> 2): the four 16-byte words of a node are consecutive (one address register,
+  // immediate offsets 0 / 16 / 32 / 48 - no address arithmetic in the node step), and the 16 bytes of padding after every four slots spread the
+  // 64 lanes of one read over all 16 bank groups like the XOR swizzle of k_trace_pt_f32's treelet does.
+  __shared__ __attribute__((aligned(1024))) float4 tree[kTtLocalBytes / 16];   // (the most aligned LDS object is placed first: offset 0)
   __shared__ uint2 stk[kTtStack * kTtBlock];
-  __shared__ float4 tree[kTtNodes * 4];   // bank-swizzled like k_trace_pt_f32's treelet
   __shared__ uint32_t s_item, s_next;
-  constexpr uint32_t tl_bytes = kTtNodes * 64u;
+  constexpr uint32_t tl_bytes = kTtLocalBytes;
   constexpr uint32_t kNone = 0xffffffffu;
   const uint32_t tid = threadIdx.x, lane = tid & 63u;
   const uint32_t gtid = blockIdx.x * blockDim.x + tid;   // overflow-stack column of this lane
@@ -699,7 +709,7 @@ __global__ void __launch_bounds__(kTtBlock) __attribute__((amdgpu_waves_per_eu(R
     }
     {
       const float4* src = tt.trees + (size_t)tree_id * (kTtNodes * 4u);
-      for (uint32_t i = tid; i < kTtNodes * 4u; i += kTtBlock) tree[(i & ~3u) | ((i ^ (i >> 4)) & 3u)] = src[i];
+      for (uint32_t i = tid; i < kTtNodes * 4u; i += kTtBlock) tree[i + (i >> 4)] = src[i];   // word i & 3 of slot i >> 2 at tt_local_addr(i >> 2) / 16 + (i & 3)
     }
     __syncthreads();
 
@@ -740,10 +750,9 @@ __global__ void __launch_bounds__(kTtBlock) __attribute__((amdgpu_waves_per_eu(R
             const uint32_t off = cur;
             float4 a, b, c; uint4 d;
             if (off < tl_bytes) {
-              const uint32_t x = off ^ ((off >> 4) & 0x30u);   // byte address of word 0's slot
-              const char* lp = reinterpret_cast<const char*>(tree);
-              a = *reinterpret_cast<const float4*>(lp + x); b = *reinterpret_cast<const float4*>(lp + (x ^ 16u)); c = *reinterpret_cast<const float4*>(lp + (x ^ 32u));
-              const float4 dd = *reinterpret_cast<const float4*>(lp + (x ^ 48u));
+              const char* lp = reinterpret_cast<const char*>(tree) + off;   // a local child word IS the node's LDS address
+              a = *reinterpret_cast<const float4*>(lp); b = *reinterpret_cast<const float4*>(lp + 16); c = *reinterpret_cast<const float4*>(lp + 32);
+              const float4 dd = *reinterpret_cast<const float4*>(lp + 48);
               d = make_uint4(__float_as_uint(dd.x), __float_as_uint(dd.y), __float_as_uint(dd.z), 0u);
             } else {
               const char* np = reinterpret_cast<const char*>(ts.pairs) + off;

@@ -949,7 +949,7 @@ class Handle : public HandleBase {
   int tt_state_ = 0;                       // 0 = not built yet, 1 = built, -1 = not for this scene
   std::vector<PairNode> pairs_host_;       // build_pairs(): the kernels' tree, kept for the census walk
   std::vector<Tri<float>> tris_host_;
-  DevBuf<PairNode> tt_pairs_;              // kTtNodes unused slots, then the whole tree with its interior child words shifted by kTtNodes * 64
+  DevBuf<PairNode> tt_pairs_;              // kTtLocalBytes unused bytes, then the whole tree with its interior child words shifted by kTtLocalBytes
   DevBuf<PairNode> tt_trees_;              // [patches + 1][kTtNodes]
   DevBuf<uint2> tt_chunks_;
   DevBuf<uint32_t> tt_overflow_;
@@ -1679,13 +1679,16 @@ class Handle : public HandleBase {
     if constexpr (std::is_same<R, float>::value) {
       const size_t n_int = pairs_host_.size();
       const bool pt_ok = scene_.n_lens <= 32 && scene_.sampler_type == RRT_SAMPLER_HALTON && scene_.xres < 65536 && scene_.yres < 65536;
-      if (!use_persistent() || mixed_ || !pt_ok || raygen_pt_ < 1 || n_int <= kTtNodes || trav_.root_id != 0u || (uint64_t)(n_int + kTtNodes) * 64u >= kIdle) return;
+      if (!use_persistent() || mixed_ || !pt_ok || raygen_pt_ < 1 || n_int <= kTtNodes || trav_.root_id != 0u || (uint64_t)n_int * 64u + kTtLocalBytes >= kIdle) return;
       const uint64_t s_total = desc_.sampler.samples_per_pixel > 1 ? desc_.sampler.samples_per_pixel - 1 : 0;
       if (s_total == 0 || cap_ == 0) return;
       const auto t_begin = std::chrono::steady_clock::now();
       const size_t W = (size_t)desc_.film.xres, H = (size_t)desc_.film.yres;
       const uint32_t mt_x = (uint32_t)((W + kTtMacro - 1) / kTtMacro), mt_y = (uint32_t)((H + kTtMacro - 1) / kTtMacro), n_trees = mt_x * mt_y;
       const uint32_t S = (uint32_t)std::min<uint64_t>((uint64_t)tt_census_spp_, s_total);
+      // the census renders the image in pixel groups of what the pools hold: with very small pools (option "max_paths") that would be thousands of launches
+      // for passes that do not qualify anyway - try again when the pools have grown
+      if (cap_ / S < std::min<size_t>(W * H, 65536)) { tt_state_ = 0; return; }
       // ---- camera rays of the census, bucketed by patch
       struct CRay { float o[3], d[3]; };
       std::vector<CRay> rays;
@@ -1724,7 +1727,7 @@ class Handle : public HandleBase {
       // ---- per patch: walk, count, choose, copy
       std::vector<PairNode> trees((size_t)(n_trees + 1) * kTtNodes);
       memset(trees.data(), 0, trees.size() * sizeof(PairNode));
-      const uint32_t shift = kTtNodes * 64u;
+      const uint32_t shift = kTtLocalBytes;   // interior child words of the whole tree start here; below: LDS addresses of a copy's slots
       auto slab = [](const float bmin[3], const float bmax[3], const float o[3], const float inv[3], float* t) {
         float tn = -INFINITY, tf = INFINITY;
         for (int k = 0; k < 3; k++) { const float a = (bmin[k] - o[k]) * inv[k], b = (bmax[k] - o[k]) * inv[k]; tn = std::max(tn, std::min(a, b)); tf = std::min(tf, std::max(a, b)); }
@@ -1735,7 +1738,7 @@ class Handle : public HandleBase {
         for (uint32_t k = 0; k < (uint32_t)sel.size(); k++) slot_of[sel[k]] = k;
         for (uint32_t k = 0; k < (uint32_t)sel.size(); k++) {
           PairNode nd = pairs_host_[sel[k]];
-          for (uint32_t* id : {&nd.id0, &nd.id1}) if (!(*id & kLeafBit)) { const uint32_t c = slot_of[*id / 64u]; *id = c != 0xffffffffu ? c * 64u : *id + shift; }
+          for (uint32_t* id : {&nd.id0, &nd.id1}) if (!(*id & kLeafBit)) { const uint32_t c = slot_of[*id / 64u]; *id = c != 0xffffffffu ? tt_local_addr(c) : *id + shift; }
           dst[k] = nd;
         }
         for (uint32_t k : sel) slot_of[k] = 0xffffffffu;
@@ -1829,12 +1832,13 @@ class Handle : public HandleBase {
         for (unsigned k = 0; k < nt; k++) pool.emplace_back(worker);
         for (auto& th : pool) th.join();
       }
-      std::vector<PairNode> shifted(kTtNodes + n_int);
-      memset(shifted.data(), 0, kTtNodes * sizeof(PairNode));
+      constexpr size_t kFront = kTtLocalBytes / sizeof(PairNode);
+      std::vector<PairNode> shifted(kFront + n_int);
+      memset(shifted.data(), 0, kFront * sizeof(PairNode));
       for (size_t i = 0; i < n_int; i++) {
         PairNode nd = pairs_host_[i];
         for (uint32_t* id : {&nd.id0, &nd.id1}) if (!(*id & kLeafBit)) *id += shift;
-        shifted[kTtNodes + i] = nd;
+        shifted[kFront + i] = nd;
       }
       tt_pairs_.upload(shifted, st_); tt_trees_.upload(trees, st_);
       HIP_CHECK(hipStreamSynchronize(st_));
