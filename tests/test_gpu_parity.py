@@ -652,18 +652,20 @@ def test_tile_order_of_the_pixels_changes_nothing(which, workdir):
             assert np.array_equal(out[3][0], out[2][0])
 
 
-@pytest.mark.parametrize("which", ["cfg4", "cfg4_odd_width", "cfg4_two_groups", "cfg4_bands", "cfg4_direct", "cfg4_passes", "cfg2_small_tree"])
+@pytest.mark.parametrize("which", ["cfg4", "cfg4_odd_width", "cfg4_two_groups", "cfg4_bands", "cfg4_direct", "cfg4_passes", "cfg2_small_tree", "cfg4_2048"])
 def test_tile_trees_change_nothing(which, workdir):
     """Camera rays walk the tree through per-patch local copies of its most visited pair nodes in LDS (dtraverse_f32.hpp k_trace_tiles_f32,
     rrt_impl.hpp build_tile_trees()): the copies hold the tree's own boxes, leaf words and split axes - only the child words of a copy say
     "slot k of this copy" or "node n of the tree" - and the queue is not reordered, so every ray makes the same decisions in the same order
     whatever the census chose to copy. Frames, weights and query counts with and without are identical bit for bit: whole 32-pixel patches and
-    a width of 13 tiles, one and two sample groups per tile, a rank's bands, DirectLighting's first level, and two census densities. Passes
+    a width of 13 tiles, one and two sample groups per tile, a rank's bands, DirectLighting's first level, a 2048^2 film (more 8 x 8 tiles than one grid
+    dimension holds), and two census densities. Passes
     that do not cover the pixel grid in whole tile rows x 8 samples (small max_paths) and trees that fit a copy anyway keep the ordinary kernel
     (tile_launches = 0)."""
     kw = dict(xres=128, yres=96, nsamp=9, max_depth=5, n=64)
     if which == "cfg4_odd_width": kw.update(xres=104, yres=72)
     if which == "cfg4_two_groups": kw.update(nsamp=17)
+    if which == "cfg4_2048": kw.update(xres=2048, yres=2048, max_depth=2)      # 65 536 tiles: the camera kernel's pixel blocks spill into grid z
     if which == "cfg2_small_tree": cfg, root = scenes.cfg2(workdir, xres=64, yres=96, nsamp=9, max_depth=3)
     else: cfg, root = scenes.cfg4(workdir, **kw)
     if which == "cfg4_direct": cfg["Integrator"] = {"integrator_type": "DirectLighting", "max_depth": 3, "light_strategy": "UniformSampleAll"}
