@@ -275,8 +275,9 @@ def main():
 
     stat_dev = "cpu" if args.dist_backend == "gloo" else f"cuda:{local_rank}"
     tt = torch.tensor([elapsed], dtype=torch.float64, device=stat_dev)
-    keys = ["camera_samples", "camera_rays", "closest_queries", "any_queries", "closest_nodes", "closest_prims", "any_nodes", "any_prims", "closest_launches"]
+    keys = ["camera_samples", "camera_rays", "closest_queries", "any_queries", "closest_nodes", "closest_prims", "any_nodes", "any_prims", "closest_launches", "root_culled"]
     counted["closest_launches"] = timed["closest_launches"]
+    counted["root_culled"] = timed["root_culled"]   # (the counting frame keeps every query in the queue)
     cnt = torch.tensor([float(counted[k]) for k in keys] + [timed["ms_closest"], timed["ms_any"], timed["ms_shade"], timed["ms_raygen"], timed["ms_film"], timed["ms_total"], isolated["ms_closest"],
                                                             single["ms_closest"], single["ms_any"], single["ms_shade"], single["ms_raygen"], single["ms_film"], single["ms_total"]],
                        dtype=torch.float64, device=stat_dev)
@@ -303,7 +304,9 @@ def main():
         # one-frame-at-a-time pass above (shadow launches beside them on the second stream, as in the product): what rocprofv3's kernel trace
         # of `bench.py --frames-in-flight 1` shows per dispatch (profiles/). `as_ran` = the same events inside the timed region.
         n_launch = max(1.0, tot["closest_launches"])
-        bytes_closest = tot["closest_queries"] * 44.0 + 32.0 * tot["closest_nodes"] + 48.0 * tot["closest_prims"]
+        # camera rays that miss the root box are answered by the camera kernel (option "root_cull"): queries, but no records through the traversal launches
+        in_queue = tot["closest_queries"] - tot["root_culled"]
+        bytes_closest = in_queue * 44.0 + 32.0 * tot["closest_nodes"] + 48.0 * tot["closest_prims"]
         ms_closest = mx_tot["ms1_closest"]   # per frame; ranks run concurrently: the slowest rank's sum
         launch_s = ms_closest * 1e-3 / (n_launch / world) if ms_closest > 0 else float("inf")
         achieved = (bytes_closest / n_launch) / launch_s / 1e9
@@ -321,7 +324,7 @@ def main():
                     j = json.load(f)
                 if j.get("source_hash") == src:
                     # gathers at the calibrated x1; the coalesced ray-record reads (32 B per query) are tallied at half: + 16 B per query
-                    traffic = round((j["closest"]["hbm_bytes"] + 16.0 * tot["closest_queries"]) / n_launch, 1)
+                    traffic = round((j["closest"]["hbm_bytes"] + 16.0 * in_queue) / n_launch, 1)
                     pmc_fetch_factor = ((j.get("fetch_size_factor") or {}).get("closest"), j.get("fetch_size_factor_source"))
                     lane_util = j.get("closest", {}).get("valu_lane_util")
                     tcp_acc = j.get("closest", {}).get("tcp_accesses")
@@ -332,7 +335,7 @@ def main():
         # HBM position is an order of magnitude lower (`hbm`). What the kernel does per lane is GATHER: one 64-B pair-node line per two nodes
         # visited, one 48-B triangle per test, 48 B of ray + hit records per query. The ceiling that applies is the guide's row-gather rate out
         # of the XCD's L2 (MI355X_MICROARCH.md "Indexed rows: gather": 16.8-18.8 TB/s chip-wide; Infinity-Cache-resident rows: 8.6 TB/s).
-        gather_bytes = 64.0 * tot["closest_nodes"] / 2.0 + 48.0 * tot["closest_prims"] + 48.0 * tot["closest_queries"]
+        gather_bytes = 64.0 * tot["closest_nodes"] / 2.0 + 48.0 * tot["closest_prims"] + 48.0 * in_queue
         gather = (gather_bytes / n_launch) / launch_s / 1e9
         as_ran_s = mx_tot["ms_closest"] * 1e-3 * world / n_launch
         alone_s = mx_tot["ms_closest_isolated"] * 1e-3 * world / n_launch
@@ -386,7 +389,7 @@ def main():
             "roofline": roofline, "cpu_baseline": cpu,
             "camera_mrays_per_s": round(tot["camera_rays"] / (ms_per_step * 1e-3) / 1e6, 3),
             "camera_samples": int(tot["camera_samples"]), "camera_rays": int(tot["camera_rays"]),
-            "closest_queries": int(tot["closest_queries"]), "any_queries": int(tot["any_queries"]),
+            "closest_queries": int(tot["closest_queries"]), "root_culled": int(tot["root_culled"]), "any_queries": int(tot["any_queries"]),
             "any_nodes_per_query": round(tot["any_nodes"] / max(1.0, tot["any_queries"]), 2), "any_tris_per_query": round(tot["any_prims"] / max(1.0, tot["any_queries"]), 2),
             "kernel_ms_per_frame": {k: round(mx_tot[k], 3) for k in ("ms_raygen", "ms_closest", "ms_any", "ms_shade", "ms_film", "ms_total")},
             "kernel_ms_per_frame_one_at_a_time": {k.replace("ms1_", "ms_"): round(mx_tot[k], 3) for k in ("ms1_raygen", "ms1_closest", "ms1_any", "ms1_shade", "ms1_film", "ms1_total")},

@@ -32,7 +32,7 @@
 extern "C" {
 #endif
 
-#define RRT_ABI_VERSION 9
+#define RRT_ABI_VERSION 10
 
 /* ---- error codes ------------------------------------------------------- */
 enum {
@@ -297,6 +297,7 @@ typedef struct rrt_render_stats {
   uint64_t closest_nodes, closest_prims;  /* split of nodes_visited / prims_tested per kernel: the roofline's */
   uint64_t any_nodes, any_prims;          /* algorithmic-byte model needs the closest-hit kernel's own counts */
   uint64_t tile_launches;       /* closest-hit launches over camera rays issued with the per-patch sub-trees ("tile_trees" option) */
+  uint64_t root_culled;         /* closest_queries answered by the camera kernels: camera rays that miss the root box ("root_cull" option) */
 } rrt_render_stats;
 
 /* ---- host side: scene build (stays on the host in the north_star) -------- */
@@ -410,7 +411,9 @@ int rrt_film_gather_all(rrt_handle* const* handles, void* const* films_device, i
  * order of the work changes, frames are identical bit for bit), "shadow_lists" (fp32, 1 = default: shadow rays of scenes whose lights are all point / distant lights run down their start
  * triangle's list of candidate leaves instead of walking the tree - the same box and triangle tests, frames identical bit for bit), "tile_trees" (fp32, 1 = default:
  * camera rays walk the tree through per-patch copies of its most visited nodes in LDS where the pass allows it, rrt_render_stats::tile_launches counts those launches -
- * the same decisions in the same order, frames identical bit for bit; "tt_census" = camera samples per pixel of the census that chooses the nodes, default 2), and three
+ * the same decisions in the same order, frames identical bit for bit; "tt_census" = camera samples per pixel of the census that chooses the nodes, default 2), "root_cull"
+ * (fp32 path integrator, 1 = default: a camera ray that misses the BVH's root box - the traversal kernels' own first test - is answered by the camera kernel and never
+ * enters a queue; counted in closest_queries and in rrt_render_stats::root_culled; frames identical bit for bit), and three
  * result-invariant shortcuts of the fp32 mode that tests switch off to show that they are (1 = default): "any_entry" (shadow rays start from
  * their triangle's list of deciding nodes instead of the root), "cam_tables" / "halton_tables" (block tables instead of the digit loops of
  * the camera's / the integrators' Halton dimensions) */

@@ -13,7 +13,9 @@ enum { C_ACTIVE = 0, C_NEXT = 32, C_SHADOW = 64, C_CAMERA_RAYS = 96, C_ERROR = 1
        // per-XCD work cursors of the persistent traversal kernels: 8 lines each (one cursor per eighth of the queue)
        C_WORK8_CLOSEST = 288, C_WORK8_SHADOW = 544,
        // queue entries [0, C_TT_DONE) came from the camera workgroups in whole chunks (k_raygen_main_f32's chunk records), the rest from stage B
-       C_TT_DONE = 800, C_COUNT = 832 };
+       C_TT_DONE = 800,
+       // camera rays answered by the camera kernels (SceneDev::root_cull): closest-hit queries that never entered a queue
+       C_CULLED = 832, C_COUNT = 864 };
 // shading kernels push to their queues once per block (measured: 256 <= 512 <= 1024 threads by 5 %: smaller blocks retire
 // and refill a CU sooner, and one atomic per 256 paths no longer serialises)
 template <typename R> struct ShadeBlock { static constexpr int n = 256; };
@@ -1397,7 +1399,10 @@ static __global__ void k_accumulate_counts(uint32_t* c, unsigned long long* tota
   totals[2] += c[C_ACTIVE];
 }
 static __global__ void k_accumulate_shadow(const uint32_t* shadow_count, unsigned long long* totals) { totals[3] += *shadow_count; }
-static __global__ void k_accumulate_camera(uint32_t* c, unsigned long long* totals) { totals[4] += c[C_CAMERA_RAYS]; c[C_CAMERA_RAYS] = 0; }
+static __global__ void k_accumulate_camera(uint32_t* c, unsigned long long* totals) {
+  totals[4] += c[C_CAMERA_RAYS]; c[C_CAMERA_RAYS] = 0;
+  totals[2] += c[C_CULLED]; totals[7] += c[C_CULLED]; c[C_CULLED] = 0;   // queries all the same: answered by the root-box test in the camera kernel
+}
 
 // ------------------------------------------------------------------------------------------------------------
 // Film: FilmTile::add_sample (film.rs:77-130) + merge_film_tile (:248-263, Q3) for the box filter of radius

@@ -1039,6 +1039,16 @@ constexpr int kRgDense = RRT_RG_DENSE;
 #endif
 constexpr int kRgRepack = RRT_RG_REPACK;   // lens interfaces traced before the block packs its survivors (0 = never)
 
+// lane_ray_begin()'s root test on a camera ray as the queue would hold it (plain fp32 origin, t_max = inf): the same function on the same values, so the
+// camera kernel's verdict is the traversal kernels' verdict. A ray that fails it is a miss (kIdle at once, hit record {inf, -1}).
+RRT_DEV bool camera_ray_meets_root(const SceneDev<float>& s, const V3<float>& wo, const V3<float>& wd) {
+  LaneRay r;
+  r.oxy = v2f{wo.x, wo.y}; r.ozz = v2f{wo.z, wo.z};
+  r.ixy = v2f{1.0f / wd.x, 1.0f / wd.y}; r.izz.x = 1.0f / wd.z; r.izz.y = r.izz.x;
+  float tmin;
+  return box_slabs_f32(s.root_box[0], s.root_box[1], s.root_box[2], s.root_box[3], s.root_box[4], s.root_box[5], r, &tmin) && tmin < Const<float>::inf;
+}
+
 // staging records live in the next-queue arrays, which are free until the first shading launch:
 //   nray_o[i] = {o.xyz (world), slot}, nray_d[i] = {d.xyz (world), weight}, npath[i] = {p_film.xy, p_lens.xy}, hindex[i] = Halton index
 static __global__ void __launch_bounds__(kRgDense) k_raygen_main_f32(SceneDev<float> s, Pools<float> p, PassDesc pd, int write_samp, double* dims_out,
@@ -1114,24 +1124,30 @@ static __global__ void __launch_bounds__(kRgDense) k_raygen_main_f32(SceneDev<fl
   }
   // survivors whose auxiliary rays cannot be blocked are done: straight to q_active; the others wait in the staging queue for stage B
   const bool done = alive & safe, staged = alive & !safe;
+  // ray out of the lens = flip_z, camera_to_world, normalise (camera.rs:558-565)
+  V3<float> wo, wd;
+  bool meets = true;
+  if (alive) {
+    wo = aff_pt(s.cam_m, V3<float>(L.o.x, L.o.y, -L.o.z));
+    const V3<float> wdu = aff_vec(s.cam_m, V3<float>(L.d.x, L.d.y, -L.d.z));
+    wd = wdu * __builtin_amdgcn_rsqf(len2(wdu));
+    if (s.root_cull && done) meets = camera_ray_meets_root(s, wo, wd);
+  }
   uint32_t qa_first, qa_total;
-  const uint32_t qa = block_push_range(&p.counters[C_ACTIVE], done && enqueue, push_lds, &qa_first, &qa_total);
+  const uint32_t qa = block_push_range(&p.counters[C_ACTIVE], done && enqueue && meets, push_lds, &qa_first, &qa_total);
+  if (s.root_cull) (void)block_push(&p.counters[C_CULLED], done && enqueue && !meets, push_lds);   // block-uniform condition
   // chunk record of this workgroup (k_trace_tiles_f32): its entries of the first queue are one contiguous run, all from one tile of the image
   if (chunks && tid == 0) chunks[(size_t)(blockIdx.z * gridDim.y + blockIdx.y) * gridDim.x + blockIdx.x] = make_uint2(qa_first, qa_total);
   const uint32_t qs = block_push(&p.counters[C_NEXT], staged, push_lds);
   (void)block_push(&p.counters[C_CAMERA_RAYS], done, push_lds);
   if (alive) {
-    // ray out of the lens = flip_z, camera_to_world, normalise (camera.rs:558-565)
-    const V3<float> wo = aff_pt(s.cam_m, V3<float>(L.o.x, L.o.y, -L.o.z));
-    const V3<float> wdu = aff_vec(s.cam_m, V3<float>(L.d.x, L.d.y, -L.d.z));
-    const V3<float> wd = wdu * __builtin_amdgcn_rsqf(len2(wdu));
     if (staged) {
       p.nray_o[qs] = make_float4(wo.x, wo.y, wo.z, __uint_as_float(slot));
       p.nray_d[qs] = make_float4(wd.x, wd.y, wd.z, w);
       p.npath[qs] = make_float4(pfx, pfy, lx, ly);
       p.hindex[qs] = index;
     } else {
-      if (enqueue) {
+      if (enqueue && meets) {
         p.q_active[qa] = QEnt{slot, 5u, index, 0u};          // five camera dimensions consumed, bounce 0
         p.path[qa] = make_float4(1.0f, 1.0f, 1.0f, 1.0f);    // beta, eta_scale
         p.ray_o[qa] = make_float4(wo.x, wo.y, wo.z, Const<float>::inf);
@@ -1203,8 +1219,10 @@ static __global__ void __launch_bounds__(kRgDense) k_raygen_aux2_f32(SceneDev<fl
       p.rdy_o[slot] = make_float4(ryo.x, ryo.y, ryo.z, 0.0f); p.rdy_d[slot] = make_float4(ryd.x, ryd.y, ryd.z, 0.0f);
     }
   }
-  const bool enq = alive && enqueue;
+  const bool meets = !(s.root_cull && alive) || camera_ray_meets_root(s, V3<float>(ro.x, ro.y, ro.z), V3<float>(rd.x, rd.y, rd.z));
+  const bool enq = alive && enqueue && meets;
   const uint32_t q = block_push(&p.counters[C_ACTIVE], enq, push_lds);
+  if (s.root_cull) (void)block_push(&p.counters[C_CULLED], alive && enqueue && !meets, push_lds);
   (void)block_push(&p.counters[C_CAMERA_RAYS], alive, push_lds);
   if (enq) {
     p.q_active[q] = QEnt{slot, 5u, p.hindex[i], 0u};   // five camera dimensions consumed, bounce 0

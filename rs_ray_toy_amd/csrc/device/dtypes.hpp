@@ -153,6 +153,10 @@ struct SceneDev {
   uint32_t stack_depth;        // >= bvh depth + 1
   uint32_t flags;
   uint32_t use_shadow_tabs;    // the shading kernel stores Light::shadow_tab with a shadow ray's start triangle (the launch that follows is k_shadow_lists_f32)
+  // fp32 path integrator: the camera kernels answer a camera ray that misses the root box themselves (the test lane_ray_begin() makes, on the ray as stored:
+  // such a ray is a miss, which the path integrator shades with nothing) instead of sending it through the queue - see camera_ray_meets_root()
+  uint32_t root_cull;
+  float root_box[6];
   // camera
   const LensElem<R>* lens;
   int32_t n_lens, simple_weighting;

@@ -518,6 +518,7 @@ class Handle : public HandleBase {
     else if (key == "raygen_pt") raygen_pt_ = v != 0 ? 2 : 0;   // 0: generic two-stage kernels (the reference's operation order), otherwise (default): dense two-stage kernels with the lean lens arithmetic
     else if (key == "tile_order") tile_order_ = v != 0;
     else if (key == "tile_trees") tile_trees_on_ = v != 0;
+    else if (key == "root_cull") root_cull_on_ = v != 0;
     else if (key == "tt_census") { tt_census_spp_ = std::max(1, (int)v); tt_state_ = 0; }
     else if (key == "shadow_lists") shadow_lists_on_ = v != 0;
     else if (key == "sl_grid") sl_grid_cap_ = std::max(1, (int)v);
@@ -738,7 +739,7 @@ class Handle : public HandleBase {
         const uint32_t sgrid = (uint32_t)((nslots + ShadeBlock<R>::n - 1) / ShadeBlock<R>::n);
         hipLaunchKernelGGL(k_rotate, dim3(1), dim3(1), 0, st_, counters_.p, 2);
         size_t e = tick(0);
-        launch_raygen(pd, grid, nullptr, integ != RRT_INT_AO ? 1 : 0);
+        launch_raygen(pd, grid, nullptr, integ != RRT_INT_AO ? 1 : 0, true);
         tock(e);
         hipLaunchKernelGGL(k_accumulate_camera, dim3(1), dim3(1), 0, st_, counters_.p, totals_.p);
         if (integ == RRT_INT_PATH) {
@@ -893,6 +894,7 @@ class Handle : public HandleBase {
     stats->closest_launches = fr.n_closest_launch;
     stats->any_launches = fr.n_any_launch;
     stats->tile_launches = fr.n_tile_launch;
+    stats->root_culled = ht[7];
     if (!fr.timing) return;
     float ms = 0;
     HIP_CHECK(hipEventElapsedTime(&ms, fr.ev_begin, fr.ev_end));
@@ -945,6 +947,7 @@ class Handle : public HandleBase {
   std::vector<uint32_t> newidx_keep_;      // build_pairs(): BFS renumbering of the pair nodes
   // tile trees (dtraverse_f32.hpp k_trace_tiles_f32): per 32 x 32-pixel patch of the image, a local copy of the pair nodes its camera rays visit most
   bool tile_trees_on_ = true;              // option "tile_trees"
+  bool root_cull_on_ = true;               // option "root_cull": the camera kernels answer camera rays that miss the root box (SceneDev::root_cull)
   int tt_census_spp_ = 2;                  // option "tt_census": camera samples per pixel of the census
   int tt_state_ = 0;                       // 0 = not built yet, 1 = built, -1 = not for this scene
   std::vector<PairNode> pairs_host_;       // build_pairs(): the kernels' tree, kept for the census walk
@@ -1541,8 +1544,18 @@ class Handle : public HandleBase {
   }
   // camera ray generation: the dense lean-arithmetic kernels in fp32 (dtraverse_f32.hpp), the generic two-stage kernels (main trace, auxiliary traces; the
   // reference's operation order) in f64 and for what the dense ones do not cover
-  void launch_raygen(const PassDesc& pd, uint32_t grid, double* dims_out, int enqueue) {
+  // for_render: the queue feeds the integrator (camera rays that miss the root box may be answered here); otherwise every survivor's ray is wanted (rrt_camera_samples)
+  void launch_raygen(const PassDesc& pd, uint32_t grid, double* dims_out, int enqueue, bool for_render = false) {
     tt_pass_ok_ = false;
+    scene_.root_cull = 0u;
+    if constexpr (std::is_same<R, float>::value) {
+      // a miss is shaded with nothing by the path integrator only (DirectLighting / Debug panic on a miss without lights, Q20), and the root test that
+      // is replayed is the pair-node kernels' (lane_ray_begin); counting frames keep every query in the queue
+      if (for_render && root_cull_on_ && enqueue && desc_.integrator.type == RRT_INT_PATH && use_persistent() && !count_traversal_ && trav_.n_nodes != 0u) {
+        scene_.root_cull = 1u;
+        for (int k = 0; k < 6; k++) scene_.root_box[k] = trav_.root_box[k];
+      }
+    }
     if constexpr (std::is_same<R, float>::value) {
       // the dense fp32 kernels cover Halton scenes with lenses of up to 32 interfaces on films below 65 536 px per side; everything else
       // (StratifiedSampler, longer lens tables) takes the generic kernels below, which have no such limits

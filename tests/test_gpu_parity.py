@@ -409,10 +409,10 @@ def test_full_size_frame_properties(workdir):
     # the shortcuts of the second half of round 2, all at once, at full size: shadow rays from the root instead of their start lists,
     # Halton digit loops instead of block tables (camera and integrator dimensions), camera rays through the ordinary persistent kernel - the same
     # 268 M samples, bit for bit
-    for key in ("any_entry", "cam_tables", "halton_tables", "tile_trees"): r.set_option(key, 0)
+    for key in ("any_entry", "cam_tables", "halton_tables", "tile_trees", "root_cull"): r.set_option(key, 0)
     plain, st_plain = r.render(stats=True)
-    for key in ("any_entry", "cam_tables", "halton_tables", "tile_trees"): r.set_option(key, 1)
-    assert st_plain.tile_launches == 0
+    for key in ("any_entry", "cam_tables", "halton_tables", "tile_trees", "root_cull"): r.set_option(key, 1)
+    assert st_plain.tile_launches == 0 and st_plain.root_culled == 0 and 0 < st.root_culled < st.camera_rays
     assert (st_plain.camera_rays, st_plain.closest_queries, st_plain.any_queries) == (st.camera_rays, st.closest_queries, st.any_queries)
     assert np.array_equal(plain, film)
     bands = r.render_bands(0, 2)
@@ -689,6 +689,37 @@ def test_tile_trees_change_nothing(which, workdir):
     for tt in (1, 2):
         assert np.array_equal(out[tt][0], out[0][0])
         assert (out[tt][1].camera_rays, out[tt][1].closest_queries, out[tt][1].any_queries) == (out[0][1].camera_rays, out[0][1].closest_queries, out[0][1].any_queries)
+
+
+@pytest.mark.parametrize("which", ["cfg4", "cfg4_stage_b", "cfg4_bands", "cfg2", "cfg4_direct"])
+def test_root_cull_changes_nothing(which, workdir):
+    """The fp32 path integrator's camera kernels answer a camera ray that misses the BVH's root box themselves - with the traversal kernels' own
+    first test (lane_ray_begin: box_slabs_f32 on the root box) on the ray as the queue would hold it - instead of sending it through the queue:
+    the miss it would have come back as is shaded with nothing. Frames, weights and the query counts (the culled rays stay closest-hit queries)
+    are identical bit for bit with and without; stage B's survivors are culled the same way (aux_margin = 0 sends every survivor through stage
+    B); DirectLighting keeps every ray in the queue (a miss without lights panics there, Q20)."""
+    kw = dict(xres=128, yres=96, nsamp=9, max_depth=5, n=64)
+    if which == "cfg2": cfg, root = scenes.cfg2(workdir, xres=64, yres=96, nsamp=9, max_depth=3)
+    else: cfg, root = scenes.cfg4(workdir, **kw)
+    if which == "cfg4_direct": cfg["Integrator"] = {"integrator_type": "DirectLighting", "max_depth": 3, "light_strategy": "UniformSampleAll"}
+    sc = Scene.loads(cfg, root, flags=RRT_FIXED_BVH)
+    r = Renderer(sc, 0, RRT_F32)
+    if which == "cfg4_stage_b": r.set_option("aux_margin", 0)
+    out = {}
+    for cull in (1, 0):
+        r.set_option("root_cull", cull)
+        if which == "cfg4_bands":
+            parts = [r.render_bands(k, 3, stats=True) for k in range(3)]
+            out[cull] = (sum(f for f, _ in parts), parts[1][1])
+        else:
+            out[cull] = r.render(stats=True)
+    r.close()
+    f1, s1 = out[1]; f0, s0 = out[0]
+    assert np.array_equal(f1, f0) and f1[..., :3].max() > 0
+    assert (s1.camera_rays, s1.closest_queries, s1.any_queries) == (s0.camera_rays, s0.closest_queries, s0.any_queries)
+    assert s0.root_culled == 0
+    if which == "cfg4_direct": assert s1.root_culled == 0
+    else: assert 0 < s1.root_culled < s1.camera_rays
 
 
 @pytest.mark.parametrize("which", ["cfg4", "cfg4_distant", "cfg4_far", "cfg2", "cfg3", "cfg3_direct", "cfg5_area"])
