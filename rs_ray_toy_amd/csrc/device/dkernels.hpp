@@ -1015,7 +1015,8 @@ __global__ void __launch_bounds__((shade_path_block<R, KM>())) __attribute__((am
           TexCtx<R> tc;
           if (!build_bsdf_tex(s, si, ext, dr, &tc, &bsdf)) atomicOr(&p.counters[C_ERROR], (uint32_t)(tc.err ? ERR_MIPMAP : ERR_NULL_BSDF));
         } else if (!build_bsdf(s, si, &bsdf)) atomicOr(&p.counters[C_ERROR], (uint32_t)ERR_KIND_SET);
-        const V4 st_b = p.path[i];
+        // a camera ray's path record is {1, 1, 1, 1} whoever produced it: not read (and, by the dense fp32 camera kernels under this integrator, not written)
+        const V4 st_b = bounces == 0u ? mk4<R>(R(1), R(1), R(1), R(1)) : p.path[i];
         index = qe.index;
         Rgb<R> beta(st_b.x, st_b.y, st_b.z);
         R eta_scale = st_b.w;

@@ -1071,6 +1071,10 @@ static __global__ void __launch_bounds__(kRgDense) k_raygen_main_f32(SceneDev<fl
   RgLane L; L.i = -1; L.phase = 0; L.element_z = 0;
   if (pl < pd.npix && sl < pd.ns) {
     slot = sl * pd.npix + pl;
+    // dead samples: weight 0 (Q2), nothing else is written for them. Every sample's first owner writes it here (coalesced, one store instead of a 1 GB
+    // memset per frame in front of the kernel); a survivor's weight is stored at the end of this kernel - behind the block's barriers, by whichever thread of
+    // the block holds the sample after the re-pack - or by stage B.
+    p.weight[slot] = 0.0f;
     const uint2 po = reinterpret_cast<const uint2*>(p.pix_off)[pl];
     const uint32_t px = po.y & 0xffffu, py = po.y >> 16;
     index = po.x + (pd.s_begin + sl) * s.stride;
@@ -1149,7 +1153,7 @@ static __global__ void __launch_bounds__(kRgDense) k_raygen_main_f32(SceneDev<fl
     } else {
       if (enqueue && meets) {
         p.q_active[qa] = QEnt{slot, 5u, index, 0u};          // five camera dimensions consumed, bounce 0
-        p.path[qa] = make_float4(1.0f, 1.0f, 1.0f, 1.0f);    // beta, eta_scale
+        if (s.integrator != 0 /* RRT_INT_PATH */) p.path[qa] = make_float4(1.0f, 1.0f, 1.0f, 1.0f);    // beta, eta_scale (k_shade_path knows a camera ray's without reading it)
         p.ray_o[qa] = make_float4(wo.x, wo.y, wo.z, Const<float>::inf);
         p.ray_d[qa] = make_float4(wd.x, wd.y, wd.z, __uint_as_float(0xffffffffu));
       }
@@ -1226,7 +1230,7 @@ static __global__ void __launch_bounds__(kRgDense) k_raygen_aux2_f32(SceneDev<fl
   (void)block_push(&p.counters[C_CAMERA_RAYS], alive, push_lds);
   if (enq) {
     p.q_active[q] = QEnt{slot, 5u, p.hindex[i], 0u};   // five camera dimensions consumed, bounce 0
-    p.path[q] = make_float4(1.0f, 1.0f, 1.0f, 1.0f);   // beta, eta_scale
+    if (s.integrator != 0 /* RRT_INT_PATH */) p.path[q] = make_float4(1.0f, 1.0f, 1.0f, 1.0f);   // beta, eta_scale
     p.ray_o[q] = make_float4(ro.x, ro.y, ro.z, Const<float>::inf);
     p.ray_d[q] = make_float4(rd.x, rd.y, rd.z, __uint_as_float(0xffffffffu));
   }

@@ -1567,7 +1567,7 @@ class Handle : public HandleBase {
         const rrt_film& f = desc_.film;
         const int write_samp = (f.filter_type != RRT_FILTER_BOX || f.filter_radius[0] != 0.5 || f.filter_radius[1] != 0.5) ? 1 : 0;   // only k_film_wide reads p_film
         hipLaunchKernelGGL(k_pixel_offsets, dim3((pd.npix + kBlock - 1) / kBlock), dim3(kBlock), 0, st_, scene_, pool_, pd);
-        HIP_CHECK(hipMemsetAsync(pool_.weight, 0, (size_t)total * sizeof(R), st_));   // dead samples: weight 0 (Q2), nothing else is written for them
+        // (dead samples: weight 0, Q2 - written by k_raygen_main_f32 itself, one coalesced store per sample)
         {   // dense two-stage version with the lean lens arithmetic
           const float2* safe_r2 = (aux_margin_ && tex_depth_ == 0) ? reinterpret_cast<const float2*>(lens_safe_.p) : nullptr;   // textured scenes keep the auxiliary rays themselves (ray differentials)
           // pixel blocks over grid y and z (a grid dimension holds at most 65 535 blocks; a pass has up to 2^28 / 512 of them)
