@@ -100,9 +100,12 @@ def main():
     ap.add_argument("--gpus", type=int, default=1)
     ap.add_argument("--steps", type=int, default=6)
     ap.add_argument("--warmup", type=int, default=2)
-    ap.add_argument("--res", type=int, default=1024)
-    ap.add_argument("--spp", type=int, default=256)
-    ap.add_argument("--depth", type=int, default=8)
+    ap.add_argument("--config", default="cfg4", choices=("cfg4", "cfg5"),
+                    help="cfg4 (default): BASELINE.json's headline configuration (configs[3]); cfg5: configs[4] - the same mesh with Plastic / Metal "
+                         "microfacet materials and 4 sphere area lights, 2048^2, 1024 spp, depth 16 (one step = one such frame, ~0.6 s)")
+    ap.add_argument("--res", type=int, default=0, help="default: the configuration's own (1024 / 2048)")
+    ap.add_argument("--spp", type=int, default=0, help="default: the configuration's own (256 / 1024)")
+    ap.add_argument("--depth", type=int, default=0, help="default: the configuration's own (8 / 16)")
     ap.add_argument("--grid", type=int, default=224, help="heightfield cells per side (224 -> 100 352 triangles)")
     ap.add_argument("--compat-bvh", action="store_true", help="reference-exact builder incl. Q26/Q27 (default: fixed-bvh)")
     ap.add_argument("--cpu-seconds", type=float, default=15.0, help="target wall time of the cpu_baseline sample")
@@ -116,6 +119,9 @@ def main():
                          "launches leave more of the chip to fill: tools/band_pipeline.py); n >= 2: alternate n handles (rrt_render_bands_begin / _end): a frame's latency-bound last bounces drain "
                          "while the next frame's camera rays fill the chip; 1: one synchronous frame at a time")
     args = ap.parse_args()
+    full_size = {"cfg4": (1024, 256, 8), "cfg5": (2048, 1024, 16)}[args.config]
+    args.res, args.spp, args.depth = args.res or full_size[0], args.spp or full_size[1], args.depth or full_size[2]
+    at_full_size = (args.res, args.spp, args.depth) == full_size and args.grid == 224
 
     import numpy as np
     import torch
@@ -145,7 +151,8 @@ def main():
 
     # ---- setup (untimed): scene build on the host, upload, pools ------------------------------------------------
     wd = tempfile.mkdtemp(prefix=f"rrt_bench_r{rank}_")
-    cfg, root = scenes.cfg4(wd, xres=args.res, yres=args.res, nsamp=args.spp + 1, max_depth=args.depth, n=args.grid)
+    make = scenes.cfg4 if args.config == "cfg4" else scenes.cfg5
+    cfg, root = make(wd, xres=args.res, yres=args.res, nsamp=args.spp + 1, max_depth=args.depth, n=args.grid)
     flags = 0 if args.compat_bvh else RRT_FIXED_BVH
     t0 = time.time()
     scene = Scene.loads(cfg, root, flags=flags)
@@ -314,27 +321,39 @@ def main():
         # (tools/profile_round.sh: separate --pmc FETCH_SIZE / WRITE_SIZE runs, x1024; reads x the factor calibrated on a known-byte
         # 64-B-node gather, tools/micro/fetch_calib.hip -> profiles/r3_fetch_calibration.txt; Infinity-Cache hits are included). A file
         # measured on other kernel sources is ignored (null) rather than quoted stale.
-        traffic = lane_util = tcp_acc = tcp_insts = None
+        traffic = lane_util = tcp_acc = tcp_insts = l2_req = tcc_hit = tcc_miss = None
         pmc_fetch_factor = (None, None)
-        if args.res == 1024 and args.spp == 256 and args.depth == 8 and world == 1:
+        pmc_file = pmc_stale = None
+        if at_full_size and world == 1:
             import glob
             src = kernel_source_hash()
-            for pmc in sorted(glob.glob(os.path.join(ROOT, "profiles", "r*_pmc_traffic.json")), reverse=True):
+            tag = "" if args.config == "cfg4" else "_" + args.config
+            cands = [f for f in sorted(glob.glob(os.path.join(ROOT, "profiles", "r*%s_pmc_traffic.json" % tag)), reverse=True)
+                     if args.config != "cfg4" or "_cfg" not in os.path.basename(f)]
+            pick = None
+            for pmc in cands:   # the newest file measured on THIS device code; failing that the newest one, flagged stale
                 with open(pmc) as f:
                     j = json.load(f)
                 if j.get("source_hash") == src:
-                    # gathers at the calibrated x1; the coalesced ray-record reads (32 B per query) are tallied at half: + 16 B per query
-                    traffic = round((j["closest"]["hbm_bytes"] + 16.0 * in_queue) / n_launch, 1)
-                    pmc_fetch_factor = ((j.get("fetch_size_factor") or {}).get("closest"), j.get("fetch_size_factor_source"))
-                    lane_util = j.get("closest", {}).get("valu_lane_util")
-                    tcp_acc = j.get("closest", {}).get("tcp_accesses")
-                    tcp_insts = j.get("closest", {}).get("vmem_rd_insts")
+                    pick = (pmc, j, False)
                     break
-        # What binds this kernel. The 11 MB BVH is served by the LDS treelet, the vector L1, the L2 and the Infinity Cache, so SURVEY 8d's byte
-        # model (every node / triangle a ray touches priced as an HBM byte) is no bandwidth at all - it came out above the HBM peak - and the
-        # HBM position is an order of magnitude lower (`hbm`). What the kernel does per lane is GATHER: one 64-B pair-node line per two nodes
-        # visited, one 48-B triangle per test, 48 B of ray + hit records per query. The ceiling that applies is the guide's row-gather rate out
-        # of the XCD's L2 (MI355X_MICROARCH.md "Indexed rows: gather": 16.8-18.8 TB/s chip-wide; Infinity-Cache-resident rows: 8.6 TB/s).
+                if pick is None and "tcp_tcc_read_req" in j.get("closest", {}):
+                    pick = (pmc, j, True)
+            if pick is not None:
+                pmc, j, pmc_stale = pick
+                pmc_file = os.path.relpath(pmc, ROOT)
+                c = j["closest"]
+                # gathers at the calibrated x1; the coalesced ray-record reads (32 B per query) are tallied at half: + 16 B per query
+                traffic = round((c["hbm_bytes"] + 16.0 * in_queue) / n_launch, 1)
+                pmc_fetch_factor = ((j.get("fetch_size_factor") or {}).get("closest"), j.get("fetch_size_factor_source"))
+                lane_util = c.get("valu_lane_util"); tcp_acc = c.get("tcp_accesses"); tcp_insts = c.get("vmem_rd_insts")
+                l2_req = c.get("tcp_tcc_read_req"); tcc_hit = c.get("tcc_hit"); tcc_miss = c.get("tcc_miss")
+        # What binds this kernel, and what is MEASURED about it. The 11 MB BVH is served by LDS copies, the vector L1, the XCDs' L2 and the
+        # Infinity Cache: SURVEY 8d's byte model (every node / triangle a ray touches priced as an HBM byte) comes out above the HBM peak and is
+        # no bandwidth; the HBM position (`hbm`) is an order of magnitude below. The headline fraction is what the counters say reached the L2:
+        # TCP_TCC_READ_REQ (vector L1 -> L2 read requests, 64 B each) per launch / launch duration, against the guide's L2-resident row-gather
+        # rate (MI355X_MICROARCH.md "Indexed rows: gather": 16.8-18.8 TB/s chip-wide; Infinity-Cache-resident rows 8.6 TB/s). The algorithmic
+        # figure (every gathered byte, wherever it was served from) stays beside it as `algorithmic`; it is a throughput, not a utilisation.
         gather_bytes = 64.0 * tot["closest_nodes"] / 2.0 + 48.0 * tot["closest_prims"] + 48.0 * in_queue
         gather = (gather_bytes / n_launch) / launch_s / 1e9
         as_ran_s = mx_tot["ms_closest"] * 1e-3 * world / n_launch
@@ -342,24 +361,36 @@ def main():
         fetch_factor = fetch_src = None
         if traffic is not None:
             fetch_factor, fetch_src = pmc_fetch_factor
+        l2_bytes = None if l2_req is None else 64.0 * l2_req / n_launch
+        l2_gbps = None if l2_bytes is None else l2_bytes / launch_s / 1e9
+        # lane-level accesses the byte model implies: four 16-byte words per pair node (two nodes visited), three per triangle test, two ray words + one hit word per query
+        alg_accesses = 4.0 * tot["closest_nodes"] / 2.0 + 3.0 * tot["closest_prims"] + 3.0 * in_queue
         roofline = {"kernel": "closest-hit BVH traversal, one launch pair per bounce: k_trace_tiles_f32 (camera rays, per-patch sub-trees in LDS) / k_trace_pt_f32<false> (bounces 1..) + k_trace_pairs_f32<false> (small queues)",
                     "bound": "l2_gather",
-                    "achieved": round(gather, 1), "peak": GATHER_L2_GBS, "unit": "GB/s", "frac": round(gather / GATHER_L2_GBS, 4),
+                    "achieved": None if l2_gbps is None else round(l2_gbps, 1), "peak": GATHER_L2_GBS, "unit": "GB/s",
+                    "frac": None if l2_gbps is None else round(l2_gbps / GATHER_L2_GBS, 4),
                     "traffic": traffic,
-                    "what": "gathered bytes per launch (64-B pair-node lines: nodes visited / 2; 48-B triangles tested; 48 B ray + hit record per query; exact device "
-                            "counters of a counting frame of this workload) / average launch duration, against the L2-resident row-gather rate of the guide; the share of the node lines "
-                            "that the LDS copies serve (treelet, per-patch sub-trees of the camera-ray launch) is counted as gathered: the figure is algorithmic, l1_gather has what reached the vector L1",
-                    "gathered_bytes_per_launch": round(gather_bytes / n_launch, 1),
+                    "what": "MEASURED: vector-L1 -> L2 read requests of the closest-hit launches (PMC TCP_TCC_READ_REQ, separate --pmc pass of this workload, x 64 B) per launch / "
+                            "average launch duration, against the guide's L2-resident row-gather rate. `traffic` / `hbm`: fabric-side bytes (FETCH_SIZE / WRITE_SIZE passes). "
+                            "`algorithmic`: the bytes the rays gather wherever they are served from (LDS copies, vector L1, L2) - a throughput, not a utilisation",
+                    "pmc_file": pmc_file, "pmc_stale": pmc_stale,
+                    "l2_bytes_per_launch": None if l2_bytes is None else round(l2_bytes, 1),
+                    "l2_hit_rate": None if not tcc_hit else round(tcc_hit / (tcc_hit + (tcc_miss or 0.0)), 4),
+                    # share of the algorithmic lane-level accesses that never reach the vector L1: served by the LDS copies (treelet, per-patch sub-trees)
+                    "lds_served_share": None if tcp_acc is None else round(1.0 - tcp_acc / alg_accesses, 4),
                     "avg_launch_ms": round(launch_s * 1e3, 4), "launches": int(n_launch),
                     "measured": "HIP events on the handle's stream around every closest-hit launch, frames ONE AT A TIME after the timed region (shadow launches beside "
                                 "them on the second stream, as in the product): the configuration in which an event pair = rocprofv3's per-dispatch duration "
                                 "(profiles/*_kernel_stats_1flight.csv)",
-                    "frac_infinity_cache_rate": round(gather / GATHER_IC_GBS, 4), "peak_infinity_cache": GATHER_IC_GBS,
+                    # every byte the rays gather (64-B pair-node lines: nodes visited / 2; 48-B triangles tested; 48 B ray + hit record per query; exact device counters of a
+                    # counting frame of this workload) per launch / launch duration - last round's headline, now beside the measured one
+                    "algorithmic": {"gathered_bytes_per_launch": round(gather_bytes / n_launch, 1), "GBps": round(gather, 1), "over_l2_peak": round(gather / GATHER_L2_GBS, 4),
+                                    "over_infinity_cache_rate": round(gather / GATHER_IC_GBS, 4), "lane_accesses_per_launch": round(alg_accesses / n_launch, 1)},
                     # the same events inside the timed region (frames in flight share the chip: an event pair then also holds the wait for compute units)
                     "as_ran": {"frames_in_flight": nfl, "avg_launch_ms": round(as_ran_s * 1e3, 4),
-                               "frac": round((gather_bytes / n_launch) / as_ran_s / 1e9 / GATHER_L2_GBS, 4) if as_ran_s > 0 else None},
+                               "frac": round(l2_bytes / as_ran_s / 1e9 / GATHER_L2_GBS, 4) if (as_ran_s > 0 and l2_bytes is not None) else None},
                     # the same launches with the shadow launches back on the main stream and one frame at a time: the kernel alone on the chip
-                    "alone": {"avg_launch_ms": round(alone_s * 1e3, 4), "frac": round((gather_bytes / n_launch) / alone_s / 1e9 / GATHER_L2_GBS, 4) if alone_s > 0 else None},
+                    "alone": {"avg_launch_ms": round(alone_s * 1e3, 4), "frac": round(l2_bytes / alone_s / 1e9 / GATHER_L2_GBS, 4) if (alone_s > 0 and l2_bytes is not None) else None},
                     # HBM position: fabric-side bytes per launch from the committed PMC passes (Infinity-Cache hits included: an upper bound of the HBM bytes)
                     "hbm": None if traffic is None else {"bytes_per_launch": traffic, "GBps": round(traffic / launch_s / 1e9, 1), "peak": HBM_PEAK_GBS,
                                                           "frac": round(traffic / launch_s / 1e9 / HBM_PEAK_GBS, 4), "fetch_size_factor": fetch_factor, "fetch_size_factor_source": fetch_src},
@@ -378,12 +409,12 @@ def main():
         if world == 1 and not args.no_cpu_baseline:
             cpu = cpu_baseline(scene, args.cpu_seconds)
         out = {
-            "metric": "Mrays/s (BVH ray queries, closest+any) @ 100k-tri heightfield 1024^2 256spp depth 8",
+            "metric": "Mrays/s (BVH ray queries, closest+any) @ 100k-tri heightfield %d^2 %dspp depth %d%s" % (args.res, args.spp, args.depth, "" if args.config == "cfg4" else " + microfacet BSDFs + area lights (BASELINE cfg5)"),
             "value": round(value, 3), "unit": "Mrays/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
             "ms_per_step": round(ms_per_step, 3), "higher_is_better": True, "scaling": "strong", "vs_baseline": None,
             "dtype": "f32", "data": "synthetic",
-            "config": {"workload": "BASELINE cfg4: procedural heightfield %d triangles, %dx%d, %d spp, Path max_depth %d, HaltonSampler, RealisticCamera, box filter; %s BVH; film in interleaved 16-row bands, one gather to rank 0 per frame; %d frame(s) in flight" % (
-                scene.desc.n_prims, W, H, args.spp, args.depth, "reference-exact (Q26/Q27)" if args.compat_bvh else "fixed-bvh", nfl),
+            "config": {"workload": "BASELINE %s: procedural heightfield %d triangles%s, %dx%d, %d spp, Path max_depth %d, HaltonSampler, RealisticCamera, box filter; %s BVH; film in interleaved 16-row bands, one gather to rank 0 per frame; %d frame(s) in flight" % (
+                args.config, scene.desc.n_prims, "" if args.config == "cfg4" else " (Plastic + Metal, Trowbridge-Reitz), 4 diffuse sphere area lights", W, H, args.spp, args.depth, "reference-exact (Q26/Q27)" if args.compat_bvh else "fixed-bvh", nfl),
                 "collective": collective, "comm_world": (comm.world if comm is not None else world),
                 "triangles": int(scene.desc.n_prims), "bvh_nodes": int(scene.desc.n_bvh_nodes), "bvh_depth": int(scene.desc.bvh_depth)},
             "roofline": roofline, "cpu_baseline": cpu,

@@ -32,7 +32,7 @@
 extern "C" {
 #endif
 
-#define RRT_ABI_VERSION 10
+#define RRT_ABI_VERSION 11
 
 /* ---- error codes ------------------------------------------------------- */
 enum {
@@ -298,6 +298,10 @@ typedef struct rrt_render_stats {
   uint64_t any_nodes, any_prims;          /* algorithmic-byte model needs the closest-hit kernel's own counts */
   uint64_t tile_launches;       /* closest-hit launches over camera rays issued with the per-patch sub-trees ("tile_trees" option) */
   uint64_t root_culled;         /* closest_queries answered by the camera kernels: camera rays that miss the root box ("root_cull" option) */
+  uint64_t list_launches;       /* any-hit launches served by the shadow candidate lists ("shadow_lists" option) instead of the tree walk */
+  double ms_gather;             /* the collective rrt_film_gather / _gather_all enqueued behind a frame in flight (HIP events on the handle's stream around
+                                 * the grouped send / recv or the reduce): lets a multi-GPU run separate the ranks' render imbalance (ms_total) from the
+                                 * collective (film.rs:248-263 merge_film_tile is what it replaces); 0 when no collective followed the frame */
 } rrt_render_stats;
 
 /* ---- host side: scene build (stays on the host in the north_star) -------- */
@@ -399,24 +403,43 @@ int rrt_film_gather(rrt_handle*, rrt_comm*, void* film_xyzw_device, int root);
  * n into films_device[i] on its own device; communicators (ncclCommInitAll) are created on first use and kept */
 int rrt_film_gather_all(rrt_handle* const* handles, void* const* films_device, int n, int root);
 
-/* handle options: "frame_stats" (see rrt_render_end_stats), "aux_margin" (fp32: 0 = trace the auxiliary camera rays of every surviving
- * sample, 1 = default: skip them where the main ray clears every lens interface by the calibrated margin, DESIGN.md - a CALIBRATED HEURISTIC, not a
- * proven bound: 16 x the largest displacement of an auxiliary ray measured at scene load over 16 384 host samples of the scene's own lens; validated
- * bit for bit against the full traces on the built-in and on randomly perturbed prescriptions, tests/test_gpu_parity.py::test_aux_margins_change_nothing), "max_paths" (wavefront pool slots; default 2^28 clamped to half of the free HBM), "count_traversal"
- * (exact node / triangle-test counters in rrt_render_stats, generic kernels), "persistent_traversal" (fp32: 0 generic
- * kernels, 1 grid-stride pair-node kernel, 2 persistent-thread kernel, 3 = default, by queue size), "pt_split_closest" /
- * "pt_split_any" (queue sizes at which 3 switches), "raygen_pt" (fp32: 0 = the generic two-stage raygen in the reference's
- * operation order, otherwise = default: dense kernels with the lean lens arithmetic), "shade_spec" (fp32: 1 = default: the path shading kernel instantiated for the lobe kinds the
- * scene's materials can produce - Lambertian only / + Oren-Nayar + microfacet reflection / all -, 0 = always the general kernel; the same arithmetic per lobe), "tile_order" (1 = default: the pixels of a pass are enumerated in 8 x 8 tiles where the rect is made of whole tiles - only the
- * order of the work changes, frames are identical bit for bit), "shadow_lists" (fp32, 1 = default: shadow rays of scenes whose lights are all point / distant lights run down their start
- * triangle's list of candidate leaves instead of walking the tree - the same box and triangle tests, frames identical bit for bit), "tile_trees" (fp32, 1 = default:
- * camera rays walk the tree through per-patch copies of its most visited nodes in LDS where the pass allows it, rrt_render_stats::tile_launches counts those launches -
- * the same decisions in the same order, frames identical bit for bit; "tt_census" = camera samples per pixel of the census that chooses the nodes, default 2), "root_cull"
- * (fp32 path integrator, 1 = default: a camera ray that misses the BVH's root box - the traversal kernels' own first test - is answered by the camera kernel and never
- * enters a queue; counted in closest_queries and in rrt_render_stats::root_culled; frames identical bit for bit), and three
- * result-invariant shortcuts of the fp32 mode that tests switch off to show that they are (1 = default): "any_entry" (shadow rays start from
- * their triangle's list of deciding nodes instead of the root), "cam_tables" / "halton_tables" (block tables instead of the digit loops of
- * the camera's / the integrators' Halton dimensions) */
+/* Handle options (rrt_set_option). "fp32" = only the RRT_F32 product mode looks at it. Every option marked "invariant" switches a
+ * shortcut whose results are identical bit for bit with it on or off (frames, filter weights, query counts); the named test holds that.
+ *
+ * name                  default   values / meaning                                                              invariant it keeps (test in tests/test_gpu_parity.py)
+ * --------------------  --------  ----------------------------------------------------------------------------  ------------------------------------------------------
+ * max_paths             2^28      wavefront pool slots (>= 64); clamped to half of the free HBM at creation      frames (fp32: to rounding of the per-pass sums)
+ * frame_stats           0         1: frames in flight record kernel timings (rrt_render_end_stats)              -
+ * nonblocking_streams   0         1: the handle's streams stop synchronising with the legacy default stream     - (see rrt_render_bands_begin)
+ * count_traversal       0         1: exact node / triangle-test counters in rrt_render_stats (generic kernels)  -
+ * overlap_shadow        1         0: shadow launches on the main stream instead of a second one                 frames
+ * persistent_traversal  3  fp32   0 generic kernels, 1 grid-stride pair-node kernel, 2 persistent-thread kernel, frames: every mode makes the reference's decisions in its
+ *                                 3 both by queue size                                                           order (test_trace_modes_agree, sphere / instance tests)
+ * pt_split_closest/_any 100000    queue size at which mode 3 switches kernels                                    frames
+ * quad_nodes            0  fp32   1: closest-hit rays of the persistent kernel fetch two tree levels at a time   invariant (test_quad_nodes_change_nothing)
+ *                                 (128-byte nodes with the four grandchild boxes, visited in the tree's order)
+ * tile_order            1         pixels of a pass enumerated in 8 x 8 tiles where the rect is whole tiles      invariant (test_tile_order_of_the_pixels_changes_nothing)
+ * tile_trees            1  fp32   camera rays walk per-patch copies of the most visited nodes in LDS;            invariant (test_tile_trees_change_nothing);
+ *                                 rrt_render_stats::tile_launches counts those launches                          films above 4096^2 pixels keep the ordinary kernel
+ * tt_census             2  fp32   camera samples per pixel of the census that chooses the copied nodes           invariant (same test, two densities)
+ * root_cull             1  fp32   path integrator: camera rays that miss the BVH's root box are answered by     invariant (test_root_cull_changes_nothing);
+ *                                 the camera kernel (rrt_render_stats::root_culled), never queued                counted in closest_queries
+ * shadow_lists          1  fp32   shadow rays towards point / distant / sphere-area lights run down their       invariant (test_shadow_candidate_lists_change_nothing);
+ *                                 start triangle's list of candidate leaves (rrt_render_stats::list_launches)    same box and triangle tests
+ * sl_grid               32768     workgroup cap of the list kernel                                               frames
+ * any_entry             1  fp32   shadow rays that walk the tree start from their triangle's deciding nodes     invariant (test_any_hit_entry_nodes_change_nothing)
+ * cam_tables            1  fp32   block tables instead of the digit loops of the camera's Halton dimensions      invariant (test_camera_halton_block_tables_change_nothing)
+ * halton_tables         1  fp32   the same for the integrators' first 64 dimensions                             invariant (test_halton_block_tables_change_nothing)
+ * raygen_lean           1  fp32   1: dense camera kernels with the lean lens arithmetic; 0: the generic          fp32 camera samples within 1e-3 of the f64 oracle either
+ *                                 two-stage kernels in the reference's operation order                           way (test_camera_samples)
+ * rg_spb                8  fp32   samples of one 8 x 8 tile per camera workgroup: 1, 2, 4 or 8                   frames
+ * aux_margin            1  fp32   skip the auxiliary camera rays (camera.rs:593-620) where the main ray clears   a CALIBRATED HEURISTIC, not a proven bound: 16 x the largest
+ *                                 every lens interface by the calibrated margin                                  auxiliary-ray displacement measured at scene load (16 384 host
+ *                                                                                                                samples of the scene's own lens); validated bit for bit against
+ *                                                                                                                the full traces (test_aux_margins_change_nothing)
+ * shade_spec            1  fp32   path shading kernel instantiated for the lobe kinds the scene's materials      same arithmetic per lobe: frames equal to fp32 rounding,
+ *                                 can produce; 0: always the general kernel                                      weights and counts identical (test_shading_kernel_specialisation)
+ */
 int rrt_set_option(rrt_handle*, const char* key, double value);
 
 const char* rrt_last_error(void);

@@ -77,7 +77,30 @@ struct LaneRay {
   float lx, ly, lz;   // low word of the double-float origin (dkernels.hpp spawn_point())
   uint32_t neg;       // bit k: inv_dir[k] < 0
   uint32_t skip_plane;
+#ifdef RRT_SLAB_FMA
+  float nox, noy, noz;   // -(o * inv), rounded once: a plane distance is fma(b, inv, no) (see lane_ray_set_inv)
+#endif
 };
+
+// Slab arithmetic, two forms.
+//  default       t = (b - o) * inv - the reference's operations (geometry.rs:1767-1800), relative error 2 ulp of t, which the test's widening factor
+//                1 + 2 gamma(3) on the far planes absorbs: 24 subtract / multiply operations per pair node (12 packed instructions, half rate).
+//  RRT_SLAB_FMA  t = fma(b, inv, -(o * inv)): 12 full-rate instructions per pair node, no subtraction. The rounding of o * inv is an ABSOLUTE error in t
+//                of u |o| |inv| (u = 2^-24), i.e. a plane shifted by up to u (2 |o| + |b|) in world units; the host pads every fp32 box outward by
+//                kSlabPadUlps u M (M = the largest coordinate of the root box and of the camera, rrt_impl.hpp upload_scene), so a box the exact
+//                arithmetic hits is never missed - conservative like the reference's test, for rays that start within M of the world origin.
+//                |inv| is clamped to 1e30 so that an axis-parallel ray gives +-huge plane distances of the right sign instead of inf - inf.
+RRT_DEV void lane_ray_set_inv(LaneRay& r) {
+#ifdef RRT_SLAB_FMA
+  const float ix = fminf(fmaxf(1.0f / r.dx, -1e30f), 1e30f), iy = fminf(fmaxf(1.0f / r.dy, -1e30f), 1e30f), iz = fminf(fmaxf(1.0f / r.dz, -1e30f), 1e30f);
+  r.ixy = v2f{ix, iy}; r.izz = v2f{iz, iz};
+  r.nox = -(r.oxy.x * ix); r.noy = -(r.oxy.y * iy); r.noz = -(r.ozz.x * iz);
+#else
+  r.ixy = v2f{1.0f / r.dx, 1.0f / r.dy}; r.izz.x = 1.0f / r.dz; r.izz.y = r.izz.x;
+#endif
+  r.neg = (r.ixy.x < 0.0f ? 1u : 0u) | (r.ixy.y < 0.0f ? 2u : 0u) | (r.izz.x < 0.0f ? 4u : 0u);
+}
+constexpr float kSlabPadUlps = 4.0f;
 
 // Bounds3::intersect_p geometry.rs:1767-1800, split: everything except the `t_min < ray.t_max` comparison.
 // Returns false when the slabs miss or t_max <= 0; *tmin_out is the entry distance compared against ray.t_max.
@@ -92,9 +115,15 @@ RRT_DEV bool box_slabs_f32(float bminx, float bminy, float bminz, float bmaxx, f
   // that all reach beyond 0 intersect pairwise iff they share a point, and multiplying by g > 0 commutes with min (rounding is monotone).
   // Only a NaN plane distance is treated differently (0 * inf: a ray exactly parallel to a slab AND starting exactly on its plane - the
   // reference lets such an x slab reject and ignores such a y / z slab, v_min / v_max ignore it on every axis).
+#ifdef RRT_SLAB_FMA
+  const float x0 = __builtin_fmaf(bminx, r.ixy.x, r.nox), x1 = __builtin_fmaf(bmaxx, r.ixy.x, r.nox);
+  const float y0 = __builtin_fmaf(bminy, r.ixy.y, r.noy), y1 = __builtin_fmaf(bmaxy, r.ixy.y, r.noy);
+  const float z0 = __builtin_fmaf(bminz, r.izz.x, r.noz), z1 = __builtin_fmaf(bmaxz, r.izz.x, r.noz);
+#else
   const float x0 = (bminx - r.oxy.x) * r.ixy.x, x1 = (bmaxx - r.oxy.x) * r.ixy.x;
   const float y0 = (bminy - r.oxy.y) * r.ixy.y, y1 = (bmaxy - r.oxy.y) * r.ixy.y;
   const float z0 = (bminz - r.ozz.x) * r.izz.x, z1 = (bmaxz - r.ozz.x) * r.izz.x;
+#endif
   const float t_min = fmaxf(fmaxf(fminf(x0, x1), fminf(y0, y1)), fminf(z0, z1));
   const float t_max = fminf(fminf(fmaxf(x0, x1), fmaxf(y0, y1)), fmaxf(z0, z1)) * g;
   *tmin_out = t_min;
@@ -107,9 +136,15 @@ RRT_DEV bool box_slabs_f32(float bminx, float bminy, float bminz, float bmaxx, f
 struct PairHit { float t0, t1; uint64_t s0, s1; };
 RRT_DEV PairHit pair_slabs_f32(const float4 a, const float4 b, const float4 c, const LaneRay& r) {
   const float g = 1.0f + 2.0f * ((3.0f * 5.9604645e-8f) / (1.0f - 3.0f * 5.9604645e-8f));
+#ifdef RRT_SLAB_FMA
+  const v2f lo0 = v2f{__builtin_fmaf(a.x, r.ixy.x, r.nox), __builtin_fmaf(a.y, r.ixy.y, r.noy)}, hi0 = v2f{__builtin_fmaf(a.z, r.ixy.x, r.nox), __builtin_fmaf(a.w, r.ixy.y, r.noy)};
+  const v2f lo1 = v2f{__builtin_fmaf(b.x, r.ixy.x, r.nox), __builtin_fmaf(b.y, r.ixy.y, r.noy)}, hi1 = v2f{__builtin_fmaf(b.z, r.ixy.x, r.nox), __builtin_fmaf(b.w, r.ixy.y, r.noy)};
+  const v2f z0 = v2f{__builtin_fmaf(c.x, r.izz.x, r.noz), __builtin_fmaf(c.y, r.izz.x, r.noz)}, z1 = v2f{__builtin_fmaf(c.z, r.izz.x, r.noz), __builtin_fmaf(c.w, r.izz.x, r.noz)};
+#else
   const v2f lo0 = (v2f{a.x, a.y} - r.oxy) * r.ixy, hi0 = (v2f{a.z, a.w} - r.oxy) * r.ixy;   // child 0: (x, y) plane distances of bmin, bmax
   const v2f lo1 = (v2f{b.x, b.y} - r.oxy) * r.ixy, hi1 = (v2f{b.z, b.w} - r.oxy) * r.ixy;
   const v2f z0 = (v2f{c.x, c.y} - r.ozz) * r.izz, z1 = (v2f{c.z, c.w} - r.ozz) * r.izz;     // (bmin.z, bmax.z) of child 0, of child 1
+#endif
   PairHit h;
   h.t0 = fmaxf(fmaxf(fminf(lo0.x, hi0.x), fminf(lo0.y, hi0.y)), fminf(z0.x, z0.y));
   h.t1 = fmaxf(fmaxf(fminf(lo1.x, hi1.x), fminf(lo1.y, hi1.y)), fminf(z1.x, z1.y));
@@ -170,6 +205,9 @@ struct TravScene {
   // mixed scenes (kSpecialLeaf): the records the generic per-primitive tests of dkernels.hpp read
   const SphereDev<float>* spheres;
   const InstDev<float>* insts;
+  // two levels per fetch (k_trace_pt_f32<false, false, true>): the QuadNode array (root = node 0), its first n_qtreelet nodes in BFS order
+  const void* quads;
+  uint32_t n_qtreelet;
 };
 
 // A lane's position in the walk is one child word: an interior node to visit (byte offset of its PairNode, < kIdle), a leaf to test
@@ -191,8 +229,7 @@ RRT_DEV uint32_t lane_ray_begin(const TravScene& ts, const Pools<float>& p, bool
   r.oxy = v2f{ro.x, ro.y}; r.ozz = v2f{ro.z, ro.z}; r.dx = rd.x; r.dy = rd.y; r.dz = rd.z;
   r.lx = lo.x; r.ly = lo.y; r.lz = lo.z;
   r.skip_plane = sk >= 0 ? __float_as_uint(ts.tris[(size_t)sk * 12 + 11]) : 0xffffffffu;
-  r.ixy = v2f{1.0f / r.dx, 1.0f / r.dy}; r.izz.x = 1.0f / r.dz; r.izz.y = r.izz.x;
-  r.neg = (r.ixy.x < 0.0f ? 1u : 0u) | (r.ixy.y < 0.0f ? 2u : 0u) | (r.izz.x < 0.0f ? 4u : 0u);
+  lane_ray_set_inv(r);
   *start_tri = (POOL_SHADOW && pool_shadow && ts.any_list) ? sk : -1;   // >= 0: the walk starts from any_list[start_tri] (the caller owns the stack)
   if (*start_tri >= 0) return kIdle;
   float tmin;
@@ -370,6 +407,66 @@ __global__ void __launch_bounds__(kTravBlock) k_trace_pairs_f32(TravScene ts, Po
 
 
 // ------------------------------------------------------------------------------------------------------------
+// Two levels per fetch ("quad nodes"), closest-hit rays of the persistent kernel only (option "quad_nodes").
+// A QuadNode belongs to an interior node N and holds the boxes of N's four GRANDCHILDREN (slots 0 / 1 = the children of N's first child,
+// 2 / 3 = of its second child; a child that is a leaf fills one slot with its own box and leaves the other empty: NaN box, kIdle word). The
+// children's own boxes are NOT there and are not tested: the reference (bvh.rs:183-236) visits a child, and then tests its children's boxes,
+// only if the child's own box passes - but a child's box contains its children's (the host narrows the f64 boxes outward, monotonically) and
+// every operation of the slab test is monotone under rounding, so a grandchild's box that passes implies its parent's passes, with an entry
+// distance that is no larger; and a child neither of whose children's boxes passes is a visit that tests two boxes, pushes nothing and pops:
+// leaving it out changes no triangle test. (As everywhere in this file the one exception is a NaN plane distance.)
+// Order: the four slots are visited as the two pair steps would visit them - the first child's two before the second child's two, or the
+// other way round when dir_is_neg[axis of N]; inside a child by dir_is_neg[axis of that child]. The first slot in that order whose box is
+// hit NOW (slabs and t_min < t_max) is where the lane goes; the slots before it are judged now as well - nothing can change t_max before
+// the reference reaches them - and dropped; the slots behind it are pushed whenever their slabs are hit and judged when popped, with the
+// t_max of that moment (Q10: it can grow), exactly as pair_step_f32 treats a far child. The reference's `t_min_child < t_max` for a child
+// whose first slot is popped later is implied by the slot's own comparison at the same moment (t_min_child <= t_min_slot), and for its
+// second slot either nothing happened since (same t_max) or the first slot's subtree was visited, i.e. the child had been accepted.
+// Same leaves in the same order, same triangle tests, same t_max sequence: tests/test_gpu_parity.py::test_quad_nodes_change_nothing.
+// The three split axes ride in bits 28-29 of the first three child words (leaf words keep 9 bits of primitive count, interior words are
+// byte offsets below 2^28).
+// ------------------------------------------------------------------------------------------------------------
+struct alignas(128) QuadNode {
+  float mnx[4], mny[4], mnz[4];   // bmin of the four slots, one axis per 16-byte word
+  float mxx[4], mxy[4], mxz[4];   // bmax
+  uint32_t id[4];                 // child words (interior: byte offset of its QuadNode); bits 28-29: split axis of N / of its first child / of its second child / -
+  uint32_t pad[4];
+};
+constexpr uint32_t kQuadAxisShift = 28u, kQuadAxisMask = 3u << 28;
+constexpr uint32_t kQuadLeafMax = 511u;   // primitives per leaf the stolen bits leave room for
+#ifndef RRT_QUAD_TREELET
+#define RRT_QUAD_TREELET 32
+#endif
+constexpr int kQuadTreelet = RRT_QUAD_TREELET;   // top quad nodes (BFS order) in the persistent kernel's LDS: the 4 KB the pair-node treelet takes
+
+struct QuadStep { uint32_t id[4]; float t[4]; };   // the four slots in visit order; t = entry distance, +inf where the slabs miss
+RRT_DEV QuadStep quad_step_f32(const float4 mnx, const float4 mny, const float4 mnz, const float4 mxx, const float4 mxy, const float4 mxz, const uint4 ids, const LaneRay& r) {
+  const float g = 1.0f + 2.0f * ((3.0f * 5.9604645e-8f) / (1.0f - 3.0f * 5.9604645e-8f));
+  const float ox = r.oxy.x, oy = r.oxy.y, oz = r.ozz.x, ix = r.ixy.x, iy = r.ixy.y, iz = r.izz.x;
+  float t[4];
+#define RRT_QSLOT(k, c)                                                                                                        \
+  {                                                                                                                            \
+    const float x0 = (mnx.c - ox) * ix, x1 = (mxx.c - ox) * ix, y0 = (mny.c - oy) * iy, y1 = (mxy.c - oy) * iy;                \
+    const float z0 = (mnz.c - oz) * iz, z1 = (mxz.c - oz) * iz;                                                                \
+    const float tn = fmaxf(fmaxf(fminf(x0, x1), fminf(y0, y1)), fminf(z0, z1));                                                \
+    const float tf = fminf(fminf(fmaxf(x0, x1), fmaxf(y0, y1)), fmaxf(z0, z1)) * g;                                            \
+    t[k] = ((tn <= tf) & (tf > 0.0f)) ? tn : Const<float>::inf;   /* box_slabs_f32's verdict, folded into the entry distance */ \
+  }
+  RRT_QSLOT(0, x) RRT_QSLOT(1, y) RRT_QSLOT(2, z) RRT_QSLOT(3, w)
+#undef RRT_QSLOT
+  const bool sp = ((r.neg >> ((ids.x >> kQuadAxisShift) & 3u)) & 1u) != 0u;   // dir_is_neg[axis of N]: the second child's slots first
+  const bool sa = ((r.neg >> ((ids.y >> kQuadAxisShift) & 3u)) & 1u) != 0u;   // inside the first child
+  const bool sb = ((r.neg >> ((ids.z >> kQuadAxisShift) & 3u)) & 1u) != 0u;   // inside the second child
+  const uint32_t i0 = ids.x & ~kQuadAxisMask, i1 = ids.y & ~kQuadAxisMask, i2 = ids.z & ~kQuadAxisMask, i3 = ids.w;
+  const uint32_t an = sa ? i1 : i0, af = sa ? i0 : i1, bn = sb ? i3 : i2, bf = sb ? i2 : i3;
+  const float tan_ = sa ? t[1] : t[0], taf = sa ? t[0] : t[1], tbn = sb ? t[3] : t[2], tbf = sb ? t[2] : t[3];
+  QuadStep q;
+  q.id[0] = sp ? bn : an; q.id[1] = sp ? bf : af; q.id[2] = sp ? an : bn; q.id[3] = sp ? af : bf;
+  q.t[0] = sp ? tbn : tan_; q.t[1] = sp ? tbf : taf; q.t[2] = sp ? tan_ : tbn; q.t[3] = sp ? taf : tbf;
+  return q;
+}
+
+// ------------------------------------------------------------------------------------------------------------
 // Persistent-thread variant: the kernel is VALU-issue bound with ~26 % of the lanes doing useful work when a wave
 // owns 64 fixed rays (a wave lasts as long as its longest ray). Here a wave keeps pulling rays: it reserves
 // kGrain rays at a time from a global cursor (one atomic per kGrain rays) and refills idle lanes from that private
@@ -408,20 +505,30 @@ __device__ unsigned long long g_pt_stats[2][16];
 #else
 #define PT_STAT(i, v)
 #endif
-template <bool ANY, bool MIXED = false>
-__global__ void __launch_bounds__(kPtBlock) k_trace_pt_f32(TravScene ts, Pools<float> p, const uint32_t* queue, const uint32_t* count,
+#ifdef RRT_PT_WAVES   // tuning variants: force the register budget of that many waves per SIMD
+#define RRT_PT_ATTR __attribute__((amdgpu_waves_per_eu(RRT_PT_WAVES)))
+#else
+#define RRT_PT_ATTR
+#endif
+template <bool ANY, bool MIXED = false, bool QUAD = false>
+__global__ void __launch_bounds__(kPtBlock) RRT_PT_ATTR k_trace_pt_f32(TravScene ts, Pools<float> p, const uint32_t* queue, const uint32_t* count,
                                                             uint32_t n_fixed, uint32_t* work, uint8_t* occluded, uint32_t n_lo, uint32_t n_hi) {
+  static_assert(!QUAD || (!ANY && !MIXED), "quad nodes: closest-hit rays of plain triangle scenes only");
   {
     const uint32_t nn = count ? *count : n_fixed;
     if (nn < n_lo || nn >= n_hi) return;
   }
-  constexpr int kStack = ANY ? kPtStackAny : kPtStack, kTl = ANY ? 0 : kPtTreelet;
+  constexpr int kStack = ANY ? kPtStackAny : kPtStack, kTl = ANY ? 0 : (QUAD ? 2 * kQuadTreelet : kPtTreelet);   // kTl: LDS treelet in 64-byte units
   __shared__ uint2 stk[kStack * kPtBlock];   // [entry][thread]: {child word, entry distance}, one ds_write_b64 / ds_read_b64 each
   // Top of the tree in LDS. A lane reads the four 16-byte words of ITS node, so with nodes laid out as in memory all lanes of an instruction
   // would hit the 4 of 16 bank groups their word index selects: word w of node n lives at slot w ^ ((n >> 2) & 3) instead.
   __shared__ float4 pt_treelet[kTl > 0 ? kTl * 4 : 1];
-  const uint32_t tl_bytes = kTl > 0 ? (ts.n_treelet < (uint32_t)kTl ? ts.n_treelet : (uint32_t)kTl) * 64u : 0u;
-  if (kTl > 0) {
+  const uint32_t tl_bytes = QUAD ? (ts.n_qtreelet < (uint32_t)kQuadTreelet ? ts.n_qtreelet : (uint32_t)kQuadTreelet) * 128u
+                                  : (kTl > 0 ? (ts.n_treelet < (uint32_t)kTl ? ts.n_treelet : (uint32_t)kTl) * 64u : 0u);
+  if (QUAD) {   // word w (of 8) of quad node n at slot w ^ (n & 7): the 64 lanes of one read spread over every bank group
+    for (uint32_t i = threadIdx.x; i < tl_bytes / 16u; i += kPtBlock) pt_treelet[(i & ~7u) | ((i ^ (i >> 3)) & 7u)] = reinterpret_cast<const float4*>(ts.quads)[i];
+    __syncthreads();
+  } else if (kTl > 0) {
     for (uint32_t i = threadIdx.x; i < tl_bytes / 16u; i += kPtBlock) pt_treelet[(i & ~3u) | ((i ^ (i >> 4)) & 3u)] = reinterpret_cast<const float4*>(ts.pairs)[i];
     __syncthreads();
   }
@@ -431,6 +538,9 @@ __global__ void __launch_bounds__(kPtBlock) k_trace_pt_f32(TravScene ts, Pools<f
   LaneRay r;
   r.oxy = r.ixy = r.ozz = r.izz = v2f{0.0f, 0.0f};
   r.dx = r.dy = r.dz = r.tmax = r.lx = r.ly = r.lz = 0.0f; r.neg = 0; r.skip_plane = 0xffffffffu;
+#ifdef RRT_SLAB_FMA
+  r.nox = r.noy = r.noz = 0.0f;
+#endif
   uint32_t cur = kIdle, qidx = 0, sp = 0;
   int hit = -1;
   float hu = 0.0f, hv = 0.0f;
@@ -527,6 +637,47 @@ __global__ void __launch_bounds__(kPtBlock) k_trace_pt_f32(TravScene ts, Pools<f
       PT_STAT(1, lane == 0 ? 1 : 0); PT_STAT(11, is_leaf(cur) ? 1 : 0);
       for (int rep_k = 0; rep_k < RRT_NODE_STEPS; rep_k++) {
         { const bool any_node = __builtin_amdgcn_ballot_w64(is_node(cur)) != 0ull; PT_STAT(3, (lane == 0 && any_node) ? 1 : 0); (void)any_node; }
+        if (QUAD) {
+          if (is_node(cur)) {
+            PT_STAT(2, 1);
+            const uint32_t off = cur;
+            float4 mnx, mny, mnz, mxx, mxy, mxz; uint4 ids;
+            if (off < tl_bytes) {
+              const char* lp = reinterpret_cast<const char*>(pt_treelet) + off;
+              const uint32_t sw = (off >> 3) & 0x70u;   // (n & 7) << 4
+              mnx = *reinterpret_cast<const float4*>(lp + sw); mny = *reinterpret_cast<const float4*>(lp + (sw ^ 16u)); mnz = *reinterpret_cast<const float4*>(lp + (sw ^ 32u));
+              mxx = *reinterpret_cast<const float4*>(lp + (sw ^ 48u)); mxy = *reinterpret_cast<const float4*>(lp + (sw ^ 64u)); mxz = *reinterpret_cast<const float4*>(lp + (sw ^ 80u));
+              const float4 dd = *reinterpret_cast<const float4*>(lp + (sw ^ 96u));
+              ids = make_uint4(__float_as_uint(dd.x), __float_as_uint(dd.y), __float_as_uint(dd.z), __float_as_uint(dd.w));
+            } else {
+              const char* np = reinterpret_cast<const char*>(ts.quads) + off;
+              mnx = *reinterpret_cast<const float4*>(np); mny = *reinterpret_cast<const float4*>(np + 16); mnz = *reinterpret_cast<const float4*>(np + 32);
+              mxx = *reinterpret_cast<const float4*>(np + 48); mxy = *reinterpret_cast<const float4*>(np + 64); mxz = *reinterpret_cast<const float4*>(np + 80);
+              ids = *reinterpret_cast<const uint4*>(np + 96);
+            }
+            const QuadStep qs = quad_step_f32(mnx, mny, mnz, mxx, mxy, mxz, ids, r);
+            // lane masks: h = hit now (slabs and t_min < t_max), s = slabs hit; a slot behind the one the lane goes to is pushed on its slabs alone
+            const uint64_t h0 = __builtin_amdgcn_ballot_w64(qs.t[0] < r.tmax), h1 = __builtin_amdgcn_ballot_w64(qs.t[1] < r.tmax);
+            const uint64_t h2 = __builtin_amdgcn_ballot_w64(qs.t[2] < r.tmax), h3 = __builtin_amdgcn_ballot_w64(qs.t[3] < r.tmax);
+            const uint64_t s1 = __builtin_amdgcn_ballot_w64(qs.t[1] < Const<float>::inf), s2 = __builtin_amdgcn_ballot_w64(qs.t[2] < Const<float>::inf);
+            const uint64_t s3 = __builtin_amdgcn_ballot_w64(qs.t[3] < Const<float>::inf);
+            const uint64_t e2 = h0 | h1, e3 = e2 | h2;
+            auto push = [&](uint32_t w, float t) {
+              const uint2 e = make_uint2(w, __float_as_uint(t));
+              if (sp < (uint32_t)kStack) stk[sp * kPtBlock + tid] = e;
+              else *reinterpret_cast<uint2*>(ts.overflow + ((size_t)(sp - kStack) * ts.overflow_stride + gtid) * 2) = e;
+              sp++;
+            };
+            if (__builtin_amdgcn_inverse_ballot_w64(s3 & e3)) push(qs.id[3], qs.t[3]);
+            if (__builtin_amdgcn_inverse_ballot_w64(s2 & e2)) push(qs.id[2], qs.t[2]);
+            if (__builtin_amdgcn_inverse_ballot_w64(s1 & h0)) push(qs.id[1], qs.t[1]);
+            uint32_t nxt = __builtin_amdgcn_inverse_ballot_w64(h2) ? qs.id[2] : qs.id[3];
+            nxt = __builtin_amdgcn_inverse_ballot_w64(h1) ? qs.id[1] : nxt;
+            nxt = __builtin_amdgcn_inverse_ballot_w64(h0) ? qs.id[0] : nxt;
+            if (__builtin_amdgcn_inverse_ballot_w64(e3 | h3)) cur = nxt;
+            else pop();
+          }
+        } else
         if (is_node(cur)) {
           PT_STAT(2, 1);
           const uint32_t off = ANY ? (cur & ~63u) : cur;
@@ -658,6 +809,9 @@ __global__ void __launch_bounds__(kTtBlock) __attribute__((amdgpu_waves_per_eu(R
   LaneRay r;
   r.oxy = r.ixy = r.ozz = r.izz = v2f{0.0f, 0.0f};
   r.dx = r.dy = r.dz = r.tmax = r.lx = r.ly = r.lz = 0.0f; r.neg = 0; r.skip_plane = 0xffffffffu;
+#ifdef RRT_SLAB_FMA
+  r.nox = r.noy = r.noz = 0.0f;
+#endif
   uint32_t cur = kIdle, qidx = 0, sp = 0;
   int hit = -1;
   float hu = 0.0f, hv = 0.0f;
@@ -798,7 +952,7 @@ constexpr uint32_t kShadowListMax = 48u;        // candidates per (light table, 
 constexpr uint32_t kShadowTabShift = 24u;       // a pool shadow ray's start word: triangle (24 bits) | light table + 1 (bits 24-27)
 struct LeafRec { float bmin[3]; uint32_t word; float bmax[3]; uint32_t pad; };   // a BVH leaf: its (fp32, outward) box and its leaf word
 struct ShadowLists {
-  const uint32_t* headers;   // [table][triangle]: first entry << 8 | count (0xff: none)
+  const uint32_t* headers;   // [table][triangle]: (first entry / 4) << 8 | count (0xff: none)
   const uint32_t* entries;   // leaf ids
   const LeafRec* leaves;
   uint32_t n_tris, n_tables;
@@ -851,8 +1005,7 @@ static __global__ void __launch_bounds__(kSlBlock) k_shadow_lists_f32(TravScene 
     r.oxy = v2f{ro.x, ro.y}; r.ozz = v2f{ro.z, ro.z}; r.dx = rd.x; r.dy = rd.y; r.dz = rd.z;
     r.lx = lo.x; r.ly = lo.y; r.lz = lo.z;
     r.skip_plane = has_start ? __float_as_uint(ts.tris[(size_t)sk * 12 + 11]) : 0xffffffffu;
-    r.ixy = v2f{1.0f / r.dx, 1.0f / r.dy}; r.izz.x = 1.0f / r.dz; r.izz.y = r.izz.x;
-    r.neg = (r.ixy.x < 0.0f ? 1u : 0u) | (r.ixy.y < 0.0f ? 2u : 0u) | (r.izz.x < 0.0f ? 4u : 0u);
+    lane_ray_set_inv(r);
     uint32_t hdr = 0xffu;
     if (tab != 0u && tab <= sl.n_tables && sk < sl.n_tris) hdr = sl.headers[(size_t)(tab - 1u) * sl.n_tris + sk];
     bool found = false;
@@ -861,7 +1014,7 @@ static __global__ void __launch_bounds__(kSlBlock) k_shadow_lists_f32(TravScene 
       // four candidates per round: their ids are one aligned 16-byte load (the host pads a list to a multiple of four with id 0xffffffff), their
       // eight box words are in flight together, and only then the slab tests - a lane's rounds are a chain of dependent loads otherwise
       const uint32_t cnt = hdr & 0xffu;
-      const uint4* e4 = reinterpret_cast<const uint4*>(sl.entries + (hdr >> 8));
+      const uint4* e4 = reinterpret_cast<const uint4*>(sl.entries) + (hdr >> 8);
       constexpr int U = RRT_SL_UNROLL;   // candidates per round (a multiple of 4)
       for (uint32_t k = 0; k < cnt && !found; k += (uint32_t)U) {
         uint32_t id[U];
@@ -1043,8 +1196,8 @@ constexpr int kRgRepack = RRT_RG_REPACK;   // lens interfaces traced before the 
 // camera kernel's verdict is the traversal kernels' verdict. A ray that fails it is a miss (kIdle at once, hit record {inf, -1}).
 RRT_DEV bool camera_ray_meets_root(const SceneDev<float>& s, const V3<float>& wo, const V3<float>& wd) {
   LaneRay r;
-  r.oxy = v2f{wo.x, wo.y}; r.ozz = v2f{wo.z, wo.z};
-  r.ixy = v2f{1.0f / wd.x, 1.0f / wd.y}; r.izz.x = 1.0f / wd.z; r.izz.y = r.izz.x;
+  r.oxy = v2f{wo.x, wo.y}; r.ozz = v2f{wo.z, wo.z}; r.dx = wd.x; r.dy = wd.y; r.dz = wd.z;
+  lane_ray_set_inv(r);
   float tmin;
   return box_slabs_f32(s.root_box[0], s.root_box[1], s.root_box[2], s.root_box[3], s.root_box[4], s.root_box[5], r, &tmin) && tmin < Const<float>::inf;
 }

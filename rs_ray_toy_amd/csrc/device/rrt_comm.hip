@@ -99,17 +99,22 @@ void cache_drop_locked(bool abort) {
   g_cache_comms.clear(); g_cache_devs.clear();
 }
 
-// one rank's part of the collective, inside an open ncclGroup; `films[r]` only matters on the rank that owns it
-void enqueue_gather(rrtd::HandleBase* h, ncclComm_t comm, int rank, int world, void* film, int root) {
+// One rank's part of the collective, in two steps so that nothing that can throw for a host-side reason runs inside an open ncclGroup:
+// plan_gather() reads the film geometry and lists the transfers (before ncclGroupStart), enqueue_gather() issues them (inside the group).
+struct GatherOp { int kind; void* at; size_t count; int peer; };   // kind 0 = reduce (in place on root), 1 = recv, 2 = send
+struct GatherPlan { std::vector<GatherOp> ops; ncclDataType_t dt = ncclFloat; hipStream_t st = nullptr; };
+GatherPlan plan_gather(rrtd::HandleBase* h, int rank, int world, void* film, int root) {
+  GatherPlan p;
   int W = 0, H = 0;
   bool splats = false;
   h->film_geometry(&W, &H, &splats);
-  const ncclDataType_t dt = h->precision() == RRT_F32 ? ncclFloat : ncclDouble;
+  if (W < 1 || H < 1) throw std::invalid_argument("rrt_film_gather: empty film");
+  p.dt = h->precision() == RRT_F32 ? ncclFloat : ncclDouble;
   const size_t word = h->precision() == RRT_F32 ? 4 : 8;
-  hipStream_t st = h->stream();
+  p.st = h->stream();
   if (splats) {   // overlapping films: sum (in place on root)
-    NCCL_CHECK(rccl().Reduce(film, film, (size_t)W * (size_t)H * 4, dt, ncclSum, root, comm, st));
-    return;
+    p.ops.push_back(GatherOp{0, film, (size_t)W * (size_t)H * 4, root});
+    return p;
   }
   const int n_bands = (H + kBandRows - 1) / kBandRows;
   for (int b = 0; b < n_bands; b++) {
@@ -118,9 +123,23 @@ void enqueue_gather(rrtd::HandleBase* h, ncclComm_t comm, int rank, int world, v
     if (rank != root && rank != owner) continue;
     const int y0 = b * kBandRows, y1 = std::min(H, y0 + kBandRows);
     char* at = (char*)film + (size_t)y0 * (size_t)W * 4 * word;
-    const size_t count = (size_t)(y1 - y0) * (size_t)W * 4;
-    if (rank == root) NCCL_CHECK(rccl().Recv(at, count, dt, owner, comm, st));
-    else NCCL_CHECK(rccl().Send(at, count, dt, root, comm, st));
+    p.ops.push_back(GatherOp{rank == root ? 1 : 2, at, (size_t)(y1 - y0) * (size_t)W * 4, rank == root ? owner : root});
+  }
+  return p;
+}
+// RRT_TEST_FAIL_GATHER=<rank>: that rank's first transfer is issued with an invalid peer, so that the enqueue fails INSIDE the group
+// (tests/test_gpu_multi.py: the error path below must close the group before it aborts the communicator)
+void enqueue_gather(const GatherPlan& p, ncclComm_t comm, int rank, int world, int root) {
+  const char* tf = getenv("RRT_TEST_FAIL_GATHER");
+  const bool inject = tf && *tf && atoi(tf) == rank;
+  if (inject && p.ops.empty()) throw NcclError("RCCL error: injected failure (RRT_TEST_FAIL_GATHER) on a rank with nothing to transfer");
+  bool first = true;
+  for (const GatherOp& op : p.ops) {
+    const int peer = (inject && first) ? world + 7 : op.peer;
+    first = false;
+    if (op.kind == 0) NCCL_CHECK(rccl().Reduce(op.at, op.at, op.count, p.dt, ncclSum, inject ? world + 7 : root, comm, p.st));
+    else if (op.kind == 1) NCCL_CHECK(rccl().Recv(op.at, op.count, p.dt, peer, comm, p.st));
+    else NCCL_CHECK(rccl().Send(op.at, op.count, p.dt, peer, comm, p.st));
   }
 }
 }  // namespace
@@ -178,12 +197,17 @@ int rrt_film_gather(rrt_handle* h, rrt_comm* c, void* film_xyzw_device, int root
   if (!c->comm) { rrt::set_last_error("rrt_film_gather: the communicator was aborted by an earlier failed collective"); return RRT_EDEVICE; }
   return guarded([&]() {
     HIP_CHECK(hipSetDevice(c->device));
+    const GatherPlan plan = plan_gather(h->impl, c->rank, c->world, film_xyzw_device, root);   // everything that can throw for host-side reasons: before the group
+    h->impl->gather_mark(true);
     NCCL_CHECK(rccl().GroupStart());
-    // A failure inside the group leaves it partly enqueued: launching that part (ncclGroupEnd) could leave a peer waiting in a
-    // recv nobody matches. Abort the communicator instead - the peers' calls then fail too instead of hanging - and refuse it from now on.
-    try { enqueue_gather(h->impl, c->comm, c->rank, c->world, film_xyzw_device, root); }
-    catch (...) { (void)rccl().CommAbort(c->comm); c->comm = nullptr; (void)rccl().GroupEnd(); throw; }   // (GroupEnd only closes this thread's group: the aborted communicator launches nothing)
+    // A failure inside the group leaves it partly enqueued. The order of the clean-up matters: ncclGroupEnd FIRST - RCCL discards a group that
+    // holds a failed call and returns the error without launching anything, and it must walk this thread's group state while the communicator
+    // is still alive - and only then ncclCommAbort (which frees the communicator: the peers' calls fail instead of waiting for transfers that
+    // will never be matched), after which the rrt_comm refuses further collectives.
+    try { enqueue_gather(plan, c->comm, c->rank, c->world, root); }
+    catch (...) { (void)rccl().GroupEnd(); (void)rccl().CommAbort(c->comm); c->comm = nullptr; throw; }
     NCCL_CHECK(rccl().GroupEnd());
+    h->impl->gather_mark(false);
   });
 }
 
@@ -205,14 +229,18 @@ int rrt_film_gather_all(rrt_handle* const* handles, void* const* films_device, i
       NCCL_CHECK(rccl().CommInitAll(g_cache_comms.data(), n, want.data()));
       g_cache_devs = want;
     }
+    std::vector<GatherPlan> plans;
+    for (int i = 0; i < n; i++) plans.push_back(plan_gather(handles[i]->impl, i, n, films_device[i], root));
+    for (int i = 0; i < n; i++) handles[i]->impl->gather_mark(true);
     NCCL_CHECK(rccl().GroupStart());
     try {
       for (int i = 0; i < n; i++) {
         HIP_CHECK(hipSetDevice(want[i]));
-        enqueue_gather(handles[i]->impl, g_cache_comms[i], i, n, films_device[i], root);
+        enqueue_gather(plans[i], g_cache_comms[i], i, n, root);
       }
-    } catch (...) { cache_drop_locked(true); (void)rccl().GroupEnd(); throw; }   // (see rrt_film_gather: never launch a partly enqueued group)
+    } catch (...) { (void)rccl().GroupEnd(); cache_drop_locked(true); throw; }   // (see rrt_film_gather: close the group first, then abort the communicators)
     NCCL_CHECK(rccl().GroupEnd());
+    for (int i = 0; i < n; i++) handles[i]->impl->gather_mark(false);
   });
 }
 

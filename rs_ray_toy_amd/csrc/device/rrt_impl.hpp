@@ -51,6 +51,9 @@ struct HandleBase {
   virtual void render_bands_begin(int rank, int world, void* film_device) = 0;
   virtual void render_end(rrt_render_stats* stats) = 0;
   virtual void set_option(const std::string& key, double v) = 0;
+  // rrt_film_gather (rrt_comm.hip): events on the handle's stream around the frame's collective, so that the frame's statistics can tell
+  // the collective (rrt_render_stats::ms_gather) from the render (ms_total) - what a multi-GPU scaling run needs to separate imbalance from xGMI time
+  virtual void gather_mark(bool begin) = 0;
   std::vector<std::string> warnings;   // rrt_warning(): non-fatal diagnostics of the handle's creation
 };
 
@@ -247,6 +250,13 @@ inline AuxMargins calibrate_aux_margins(const rrt_scene_desc* d) {
 // separates the fp32 evaluation from this geometry: the ray's origin word is the fp32 rounding of a point of T (<= 1 ulp of the coordinates),
 // the boxes are rounded outward, the slab test widens the far planes by 1 + 2 gamma(3): 16 ulp of the largest coordinate + 1e-4 in all.
 // Triangles closer to a point light than 8 triangle radii, or with more than kShadowListMax candidates, get no list (the kernel walks the tree).
+// [r4] Area lights (lights/diffuse.rs:63-88 -> Shape::sample_ref shape/mod.rs:33-48: a point of the light's shape) are sources too: every point the
+// light can sample lies in the shape's bounding sphere (centre C, radius r_L), so the direction from q in T to it stays within theta of u_c with
+// sin(theta) <= (r_L + r_T) / dist - the same formula with the light's radius added. With theta of 5-10 degrees one prism fattened by L sin(theta)
+// would list a swept volume (w + 2 L sin(theta))^2 L for a ray that stays in a CONE: the sweep is cut into kShadowSegments pieces in the ray
+// parameter, piece k = T swept from t_k cos(theta) to t_(k+1) and fattened by t_(k+1) sin(theta) only (a point q + t u of the ray lies within
+// t sin(theta) of the axis point q + t' u_c, t' in [t cos(theta), t]); the candidates are the leaves that meet any piece - about half as many.
+constexpr int kShadowSegments = 6;   // pieces of the sweep towards an area light (build_shadow_lists)
 struct ShadowListsHost {
   std::vector<uint32_t> headers, entries;
   std::vector<LeafRec> leaves;
@@ -257,18 +267,37 @@ inline ShadowListsHost build_shadow_lists(const std::vector<Node<float>>& nodes,
   ShadowListsHost out;
   out.table_of_light.assign(d->n_lights, 0u);
   if (nodes.empty() || tris.empty()) return out;
-  struct Src { int type; double v[3]; };
+  struct Src { int type; double v[3]; double radius; };   // radius: bounding sphere of an area light's shape (0 for point / distant lights)
   std::vector<Src> srcs;
+  const ShadowListsHost none{{}, {}, {}, 0u, std::vector<uint32_t>(d->n_lights, 0u)};
   for (size_t i = 0; i < d->n_lights; i++) {
     const rrt_light& l = d->lights[i];
-    Src s{l.type, {0, 0, 0}};
+    Src s{l.type, {0, 0, 0}, 0.0};
     if (l.type == RRT_LIGHT_POINT) for (int k = 0; k < 3; k++) s.v[k] = (double)(float)l.p_light[k];
     else if (l.type == RRT_LIGHT_DISTANT) for (int k = 0; k < 3; k++) s.v[k] = (double)(float)l.w_light[k];
-    else return ShadowListsHost{{}, {}, {}, 0u, std::vector<uint32_t>(d->n_lights, 0u)};   // an area light: the scene keeps the tree walk for every shadow ray
+    else if (l.type == RRT_LIGHT_DIFFUSE && l.shape_type == RRT_PRIM_SPHERE) {
+      // Sphere::sample (sphere.rs:265-285): obj_to_world of a point at distance `radius` from the object-space origin; the Frobenius norm of the linear
+      // part bounds its stretch (exact for a rigid transform times a uniform scale / sqrt(3) ... conservative for anything else)
+      const rrt_sphere& sp = d->spheres[l.shape];
+      const double* m = d->xforms[sp.xform].m;
+      if (m[12] != 0.0 || m[13] != 0.0 || m[14] != 0.0 || m[15] != 1.0) return none;
+      double fro = 0.0, col[3] = {0, 0, 0};
+      for (int r0 = 0; r0 < 3; r0++) for (int c0 = 0; c0 < 3; c0++) { fro += m[4 * r0 + c0] * m[4 * r0 + c0]; col[c0] += m[4 * r0 + c0] * m[4 * r0 + c0]; }
+      double offd = 0.0;   // columns orthogonal and of one length: a rotation times a uniform scale
+      for (int a0 = 0; a0 < 3; a0++) for (int b0 = a0 + 1; b0 < 3; b0++) { double q = 0; for (int r0 = 0; r0 < 3; r0++) q += m[4 * r0 + a0] * m[4 * r0 + b0]; offd = std::max(offd, std::fabs(q)); }
+      const bool uniform = offd <= 1e-12 * fro && std::fabs(col[0] - col[1]) <= 1e-12 * fro && std::fabs(col[0] - col[2]) <= 1e-12 * fro;
+      const double stretch = uniform ? std::sqrt(col[0]) : std::sqrt(fro);
+      for (int k = 0; k < 3; k++) s.v[k] = m[4 * k + 3];
+      s.radius = std::fabs(sp.radius) * stretch * (1.0 + 1e-6) + 1e-6 * (std::fabs(s.v[0]) + std::fabs(s.v[1]) + std::fabs(s.v[2]));
+      s.type = RRT_LIGHT_DIFFUSE;
+    }
+    // (a triangle-shaped area light: Triangle::sample takes its "barycentrics" from a point of the unit SPHERE (triangle.rs:393-418, Q19), so the sampled
+    // point is sum b_k q_k with |b_k| <= 1 each - anywhere within |q_0| + |q_1| + |q_2| of the world origin, no useful bound: such a scene keeps the tree walk)
+    else return none;
     size_t t = 0;
-    for (; t < srcs.size(); t++) if (srcs[t].type == s.type && srcs[t].v[0] == s.v[0] && srcs[t].v[1] == s.v[1] && srcs[t].v[2] == s.v[2]) break;
+    for (; t < srcs.size(); t++) if (srcs[t].type == s.type && srcs[t].v[0] == s.v[0] && srcs[t].v[1] == s.v[1] && srcs[t].v[2] == s.v[2] && srcs[t].radius == s.radius) break;
     if (t == srcs.size()) srcs.push_back(s);
-    if (t >= 15) return ShadowListsHost{{}, {}, {}, 0u, std::vector<uint32_t>(d->n_lights, 0u)};
+    if (t >= 15) return none;
     out.table_of_light[i] = (uint32_t)t + 1u;
   }
   if (srcs.empty()) return out;
@@ -300,22 +329,24 @@ inline ShadowListsHost build_shadow_lists(const std::vector<Node<float>>& nodes,
       for (int k = 0; k < 3; k++) c[k] = (P[0][k] + P[1][k] + P[2][k]) / 3.0;
       for (int v = 0; v < 3; v++) rT = std::max(rT, std::sqrt((P[v][0] - c[0]) * (P[v][0] - c[0]) + (P[v][1] - c[1]) * (P[v][1] - c[1]) + (P[v][2] - c[2]) * (P[v][2] - c[2])));
       for (size_t si = 0; si < srcs.size(); si++) {
-        double u[3], delta = 0.0;
-        if (srcs[si].type == RRT_LIGHT_POINT) {
+        double u[3], sin_t = 0.0, cos_t = 1.0;
+        int n_seg = 1;
+        if (srcs[si].type == RRT_LIGHT_POINT || srcs[si].type == RRT_LIGHT_DIFFUSE) {
           double w[3] = {srcs[si].v[0] - c[0], srcs[si].v[1] - c[1], srcs[si].v[2] - c[2]};
           const double dist = std::sqrt(w[0] * w[0] + w[1] * w[1] + w[2] * w[2]);
-          if (!(dist > 8.0 * rT) || !(dist > 0.0)) continue;   // light too close: the directions over T spread too far
+          const double rho = (rT + srcs[si].radius) * 1.01;    // spread of the ray's two end points around the axis c -> C
+          if (srcs[si].type == RRT_LIGHT_POINT ? !(dist > 8.0 * rT) : !(dist > 3.0 * rho)) continue;   // light too close: the directions over T spread too far
+          if (!(dist > 0.0)) continue;
           for (int k = 0; k < 3; k++) u[k] = w[k] / dist;
-          delta = L * rT / std::sqrt(dist * dist - rT * rT) * 1.01;
+          sin_t = rho / dist; cos_t = std::sqrt(std::max(0.0, 1.0 - sin_t * sin_t));
+          if (srcs[si].type == RRT_LIGHT_POINT) { sin_t = sin_t / cos_t; cos_t = 0.0; }   // (round 3's single prism over the whole length, fattened by L tan(theta): the lists of point lights stay what they were)
+          else n_seg = kShadowSegments;
         } else {
           const double len = std::sqrt(srcs[si].v[0] * srcs[si].v[0] + srcs[si].v[1] * srcs[si].v[1] + srcs[si].v[2] * srcs[si].v[2]);
           if (!(len > 0.0)) continue;
           for (int k = 0; k < 3; k++) u[k] = srcs[si].v[k] / len;
         }
-        const double m = delta + slack;
-        // prism vertices and the axes of the separating-axis test
-        double V[6][3];
-        for (int v = 0; v < 3; v++) for (int k = 0; k < 3; k++) { V[v][k] = P[v][k]; V[3 + v][k] = P[v][k] + L * u[k]; }
+        // the pieces of the sweep: piece g = T swept along u from a_g to b_g, fattened by m_g; prism vertices and the axes of the separating-axis test
         double E[4][3];   // edge directions: the triangle's three edges and the sweep
         for (int k = 0; k < 3; k++) { E[0][k] = P[1][k] - P[0][k]; E[1][k] = P[2][k] - P[1][k]; E[2][k] = P[0][k] - P[2][k]; E[3][k] = u[k]; }
         auto cross = [](const double* a, const double* b, double* o) { o[0] = a[1] * b[2] - a[2] * b[1]; o[1] = a[2] * b[0] - a[0] * b[2]; o[2] = a[0] * b[1] - a[1] * b[0]; };
@@ -324,13 +355,21 @@ inline ShadowListsHost build_shadow_lists(const std::vector<Node<float>>& nodes,
         cross(E[0], E[1], A[na++]);                                   // the triangle's plane
         for (int e = 0; e < 3; e++) cross(E[e], E[3], A[na++]);      // the three side faces
         for (int e = 0; e < 4; e++) for (int ax = 0; ax < 3; ax++) { const double b[3] = {ax == 0 ? 1.0 : 0.0, ax == 1 ? 1.0 : 0.0, ax == 2 ? 1.0 : 0.0}; cross(E[e], b, A[na++]); }
-        double lo[3], hi[3];
-        for (int k = 0; k < 3; k++) { lo[k] = hi[k] = V[0][k]; for (int v = 1; v < 6; v++) { lo[k] = std::min(lo[k], V[v][k]); hi[k] = std::max(hi[k], V[v][k]); } }
-        auto meets = [&](const Node<float>& nd) {
+        struct Piece { double V[6][3], lo[3], hi[3], m; };
+        Piece pieces[kShadowSegments];
+        for (int g = 0; g < n_seg; g++) {
+          const double t0 = L * (double)g / (double)n_seg, t1 = L * (double)(g + 1) / (double)n_seg;
+          Piece& pc = pieces[g];
+          const double a = t0 * cos_t, b = t1;
+          pc.m = t1 * sin_t + slack;
+          for (int v = 0; v < 3; v++) for (int k = 0; k < 3; k++) { pc.V[v][k] = P[v][k] + a * u[k]; pc.V[3 + v][k] = P[v][k] + b * u[k]; }
+          for (int k = 0; k < 3; k++) { pc.lo[k] = pc.hi[k] = pc.V[0][k]; for (int v = 1; v < 6; v++) { pc.lo[k] = std::min(pc.lo[k], pc.V[v][k]); pc.hi[k] = std::max(pc.hi[k], pc.V[v][k]); } }
+        }
+        auto meets_piece = [&](const Node<float>& nd, const Piece& pc) {
           double bc[3], bh[3];
           for (int k = 0; k < 3; k++) {
-            const double b0 = (double)nd.bmin[k] - m, b1 = (double)nd.bmax[k] + m;
-            if (b0 > hi[k] || b1 < lo[k]) return false;   // the box axes
+            const double b0 = (double)nd.bmin[k] - pc.m, b1 = (double)nd.bmax[k] + pc.m;
+            if (b0 > pc.hi[k] || b1 < pc.lo[k]) return false;   // the box axes
             bc[k] = 0.5 * (b0 + b1); bh[k] = 0.5 * (b1 - b0);
           }
           for (int a = 0; a < na; a++) {
@@ -338,12 +377,13 @@ inline ShadowListsHost build_shadow_lists(const std::vector<Node<float>>& nodes,
             const double l2 = ax[0] * ax[0] + ax[1] * ax[1] + ax[2] * ax[2];
             if (!(l2 > 1e-30)) continue;   // degenerate axis: decides nothing
             double pmin = 1e300, pmax = -1e300;
-            for (int v = 0; v < 6; v++) { const double q = V[v][0] * ax[0] + V[v][1] * ax[1] + V[v][2] * ax[2]; pmin = std::min(pmin, q); pmax = std::max(pmax, q); }
+            for (int v = 0; v < 6; v++) { const double q = pc.V[v][0] * ax[0] + pc.V[v][1] * ax[1] + pc.V[v][2] * ax[2]; pmin = std::min(pmin, q); pmax = std::max(pmax, q); }
             const double cc = bc[0] * ax[0] + bc[1] * ax[1] + bc[2] * ax[2], rr = bh[0] * std::fabs(ax[0]) + bh[1] * std::fabs(ax[1]) + bh[2] * std::fabs(ax[2]);
             if (cc - rr > pmax || cc + rr < pmin) return false;
           }
           return true;
         };
+        auto meets = [&](const Node<float>& nd) { for (int g = 0; g < n_seg; g++) if (meets_piece(nd, pieces[g])) return true; return false; };
         std::vector<uint32_t>& list = lists[si * nt + ti];
         bool too_many = false;
         stack.clear(); stack.push_back(0u);
@@ -378,8 +418,8 @@ inline ShadowListsHost build_shadow_lists(const std::vector<Node<float>>& nodes,
   }
   for (size_t i = 0; i < lists.size(); i++) {
     if (out.headers[i] == 0xffu) continue;
-    if (out.entries.size() + 64u >= (1u << 24)) { out.headers[i] = 0xffu; continue; }
-    out.headers[i] = ((uint32_t)out.entries.size() << 8) | (uint32_t)lists[i].size();   // (the offset is a multiple of 4: the kernel reads four ids at a time)
+    if (out.entries.size() / 4u + 64u >= (1u << 24)) { out.headers[i] = 0xffu; continue; }
+    out.headers[i] = ((uint32_t)(out.entries.size() / 4u) << 8) | (uint32_t)lists[i].size();   // (the offset in units of four entries: the kernel reads four ids at a time)
     out.entries.insert(out.entries.end(), lists[i].begin(), lists[i].end());
     while (out.entries.size() % 4u != 0u) out.entries.push_back(0xffffffffu);
   }
@@ -461,7 +501,7 @@ struct FrameRec {
   std::vector<hipEvent_t> all;
   std::vector<std::pair<int, std::pair<hipEvent_t, hipEvent_t>>> evs;   // category, begin, end
   hipEvent_t ev_begin = nullptr, ev_end = nullptr;
-  uint64_t n_closest_launch = 0, n_any_launch = 0, n_tile_launch = 0, camera_samples = 0;
+  uint64_t n_closest_launch = 0, n_any_launch = 0, n_tile_launch = 0, n_list_launch = 0, camera_samples = 0;
   bool timing = false;
   hipEvent_t make() { hipEvent_t e = nullptr; HIP_CHECK(hipEventCreate(&e)); all.push_back(e); return e; }
   ~FrameRec() { for (hipEvent_t e : all) (void)hipEventDestroy(e); }   // on every way out (a panic / HIP error thrown mid-frame included)
@@ -498,6 +538,7 @@ class Handle : public HandleBase {
     if (st2_) (void)hipStreamSynchronize(st2_);
     if (ev_shade_) (void)hipEventDestroy(ev_shade_);
     for (int k = 0; k < 2; k++) if (ev_shadow_[k]) (void)hipEventDestroy(ev_shadow_[k]);
+    for (int k = 0; k < 2; k++) if (ev_gather_[k]) { (void)hipEventDestroy(ev_gather_[k]); ev_gather_[k] = nullptr; }
     if (st2_) (void)hipStreamDestroy(st2_);
     if (st_) (void)hipStreamDestroy(st_);
     ev_shade_ = ev_shadow_[0] = ev_shadow_[1] = nullptr; st_ = st2_ = nullptr;
@@ -505,6 +546,14 @@ class Handle : public HandleBase {
   int precision() const override { return sizeof(R) == 4 ? RRT_F32 : RRT_F64; }
   hipStream_t stream() const override { return st_; }
   int device() const override { return dev_; }
+  void gather_mark(bool begin) override {
+    if (!pending_ || !frame_stats_) return;   // only a frame in flight whose statistics are wanted (rrt_render_end_stats) reports it
+    HIP_CHECK(hipSetDevice(dev_));
+    hipEvent_t& e = ev_gather_[begin ? 0 : 1];
+    if (!e) HIP_CHECK(hipEventCreate(&e));
+    HIP_CHECK(hipEventRecord(e, st_));
+    if (!begin) gather_marked_ = true;
+  }
   void film_geometry(int* xres, int* yres, bool* splats) const override {
     const rrt_film& f = desc_.film;
     *xres = f.xres; *yres = f.yres;
@@ -515,14 +564,18 @@ class Handle : public HandleBase {
     if (key == "max_paths") { if (v < 64) throw std::invalid_argument("max_paths must be >= 64"); max_paths_ = (size_t)v; }
     else if (key == "count_traversal") count_traversal_ = v != 0;
     else if (key == "persistent_traversal") { persistent_ = v != 0; if (v >= 1) trav_mode_ = (int)v; }
-    else if (key == "raygen_pt") raygen_pt_ = v != 0 ? 2 : 0;   // 0: generic two-stage kernels (the reference's operation order), otherwise (default): dense two-stage kernels with the lean lens arithmetic
+    else if (key == "raygen_lean") raygen_lean_ = v != 0;   // 0: generic two-stage kernels (the reference's operation order), 1 (default): dense two-stage kernels with the lean lens arithmetic
     else if (key == "tile_order") tile_order_ = v != 0;
     else if (key == "tile_trees") tile_trees_on_ = v != 0;
+    else if (key == "quad_nodes") quad_on_ = v != 0;
     else if (key == "root_cull") root_cull_on_ = v != 0;
     else if (key == "tt_census") { tt_census_spp_ = std::max(1, (int)v); tt_state_ = 0; }
     else if (key == "shadow_lists") shadow_lists_on_ = v != 0;
     else if (key == "sl_grid") sl_grid_cap_ = std::max(1, (int)v);
-    else if (key == "rg_spb") rg_spb_ = (int)v;
+    else if (key == "rg_spb") {   // the workgroup's 512 threads = 512 / spb pixels x spb samples: spb must divide it evenly, or the last threads would compute the next workgroup's first sample a second time
+      if (v != 1 && v != 2 && v != 4 && v != 8) throw std::invalid_argument("rg_spb must be 1, 2, 4 or 8");
+      rg_spb_ = (int)v;
+    }
     else if (key == "pt_split_closest") pt_split_closest_ = (uint32_t)v;
     else if (key == "pt_split_any") pt_split_any_ = (uint32_t)v;
     else if (key == "overlap_shadow") overlap_shadow_ = v != 0;
@@ -631,6 +684,7 @@ class Handle : public HandleBase {
   // render the next frame meanwhile - its camera rays fill the chip while this frame's last, latency-bound bounces drain.
   void render_bands_begin(int rank, int world, void* film_device) override {
     if (pending_) throw std::invalid_argument("render_bands_begin: the previous frame was not ended");
+    gather_marked_ = false;
     defer_ = true;
     try { render_bands(rank, world, film_device, RRT_MEM_DEVICE, nullptr); } catch (...) { defer_ = false; throw; }
     defer_ = false;
@@ -781,7 +835,7 @@ class Handle : public HandleBase {
               hipLaunchKernelGGL(k_accumulate_shadow, dim3(1), dim3(1), 0, st2_, pool_.shadow_count, totals_.p);
               e = tick(2, st2_);
               launch_shadow(grid, st2_);
-              tock(e, st2_); n_any_launch++;
+              tock(e, st2_); n_any_launch++; if (use_shadow_lists()) fr->n_list_launch++;
               hipLaunchKernelGGL(k_rotate, dim3(1), dim3(1), 0, st2_, counters_.p, 6 + (b & 1));   // this shadow queue + the any-hit work counter
               HIP_CHECK(hipEventRecord(ev_shadow_[b & 1], st2_));
               swap_queues();
@@ -790,7 +844,7 @@ class Handle : public HandleBase {
               hipLaunchKernelGGL(k_accumulate_shadow, dim3(1), dim3(1), 0, st_, pool_.shadow_count, totals_.p);
               e = tick(2);
               launch_shadow(grid);
-              tock(e); n_any_launch++;
+              tock(e); n_any_launch++; if (use_shadow_lists()) fr->n_list_launch++;
               swap_queues();
               hipLaunchKernelGGL(k_rotate, dim3(1), dim3(1), 0, st_, counters_.p, 0);
             }
@@ -832,7 +886,7 @@ class Handle : public HandleBase {
                 hipLaunchKernelGGL(k_accumulate_shadow, dim3(1), dim3(1), 0, st_, pool_.shadow_count, totals_.p);
                 e = tick(2);
                 launch_shadow(grid);
-                tock(e); n_any_launch++;
+                tock(e); n_any_launch++; if (use_shadow_lists()) fr->n_list_launch++;
               }
             }
             e = tick(3);
@@ -894,6 +948,7 @@ class Handle : public HandleBase {
     stats->closest_launches = fr.n_closest_launch;
     stats->any_launches = fr.n_any_launch;
     stats->tile_launches = fr.n_tile_launch;
+    stats->list_launches = fr.n_list_launch;
     stats->root_culled = ht[7];
     if (!fr.timing) return;
     float ms = 0;
@@ -905,6 +960,10 @@ class Handle : public HandleBase {
       cat[ev.first] += ms;
     }
     stats->ms_raygen = cat[0]; stats->ms_closest = cat[1]; stats->ms_any = cat[2]; stats->ms_shade = cat[3]; stats->ms_film = cat[4];
+    if (gather_marked_) {   // the collective rrt_film_gather enqueued behind this frame (render_end has synchronised the stream)
+      HIP_CHECK(hipEventElapsedTime(&ms, ev_gather_[0], ev_gather_[1]));
+      stats->ms_gather = ms;
+    }
   }
 
  private:
@@ -915,6 +974,8 @@ class Handle : public HandleBase {
   // feed L[slot]); both launches end in a latency tail that leaves most of the chip idle, and the tails overlap this way.
   hipStream_t st2_ = nullptr;
   hipEvent_t ev_shade_ = nullptr, ev_shadow_[2] = {nullptr, nullptr};
+  hipEvent_t ev_gather_[2] = {nullptr, nullptr};   // gather_mark()
+  bool gather_marked_ = false;
   typename Vec4T<R>::type* shadow_buf_[2][3] = {{nullptr, nullptr, nullptr}, {nullptr, nullptr, nullptr}};
   bool overlap_shadow_ = true;
   bool defer_ = false, pending_ = false;   // render_bands_begin / render_end
@@ -927,10 +988,10 @@ class Handle : public HandleBase {
   bool deep_ = false, count_traversal_ = false, persistent_ = true;
   bool pairs_ok_ = false;
   bool mixed_ = false;   // the tree has kSpecialLeaf leaves (spheres, kept instances): the MIXED instantiations of the pair-node kernels
-  uint32_t trav_grid_ = 0, pt_grid_ = 0;
+  uint32_t trav_grid_ = 0, pt_grid_ = 0, pt_grid_quad_ = 0;
   int rg_spb_ = 8;          // option "rg_spb": samples per workgroup of the dense camera kernel (the workgroup's 512 threads = 512 / spb pixels x spb samples)
   bool tile_order_ = true;  // option "tile_order": pixels of a pass enumerated tile by tile (PassDesc::tiled)
-  int raygen_pt_ = 2;
+  bool raygen_lean_ = true;   // option "raygen_lean"
   bool has_transmissive_ = false, has_translucent_ = false;
   bool area_lights_ = true;   // some light is a DiffuseAreaLight (else the Lambert shading kernel drops the area-light code)
   uint32_t shade_kinds_scene_ = kAllKinds, shade_kinds_ = kAllKinds;   // lobe-kind set of the scene's materials / of the shading kernel in use (option "shade_spec")
@@ -962,6 +1023,8 @@ class Handle : public HandleBase {
   DevBuf<uint32_t> pix_off_;
   TravScene trav_{};
   DevBuf<PairNode> pairs_;
+  DevBuf<QuadNode> quads_;                 // two levels per fetch (dtraverse_f32.hpp "quad nodes"); empty = not built for this scene
+  bool quad_on_ = false;                   // option "quad_nodes"
   DevBuf<uint32_t> overflow_, overflow_any_;
   DevBuf<Node<R>> nodes_;
   DevBuf<Tri<R>> tris_;
@@ -1098,6 +1161,19 @@ class Handle : public HandleBase {
       nodes[i].offset = n.offset;
       nodes[i].meta = (n.n_primitives << 2) | (n.axis & 3u);
     }
+#ifdef RRT_SLAB_FMA
+    if constexpr (std::is_same<R, float>::value) {
+      // fp32 boxes padded outward for the FMA slab form (dtraverse_f32.hpp lane_ray_set_inv): kSlabPadUlps x 2^-24 x M, M = the largest coordinate
+      // a ray origin or a box plane can have - the root box and the camera's position (its rays start on the front lens element, within the lens' length of it)
+      double M = 0.0;
+      if (d->n_bvh_nodes) for (int k = 0; k < 6; k++) M = std::max(M, std::fabs(d->bvh_nodes[0].bounds[k]));
+      double lens_len = 0.0;
+      for (int i = 0; i < d->camera.n_elems; i++) lens_len += std::fabs(d->camera.elems[i].thickness);
+      for (int k = 0; k < 3; k++) M = std::max(M, std::fabs(d->camera.camera_to_world.m[4 * k + 3]) + lens_len);
+      const float pad = (float)((double)kSlabPadUlps * 5.9604645e-8 * M);
+      for (auto& nd : nodes) for (int k = 0; k < 3; k++) { nd.bmin[k] = nextafterf(nd.bmin[k] - pad, -INFINITY); nd.bmax[k] = nextafterf(nd.bmax[k] + pad, INFINITY); }
+    }
+#endif
     // triangles in traversal order, flattened to world space (TransformedPrimitive, primitives.rs:115-139)
     std::vector<Tri<R>> tris(d->n_prim_order);
     std::vector<TriShade<R>> shades;
@@ -1560,7 +1636,7 @@ class Handle : public HandleBase {
       // the dense fp32 kernels cover Halton scenes with lenses of up to 32 interfaces on films below 65 536 px per side; everything else
       // (StratifiedSampler, longer lens tables) takes the generic kernels below, which have no such limits
       const bool pt_ok = scene_.n_lens <= 32 && scene_.sampler_type == RRT_SAMPLER_HALTON && scene_.xres < 65536 && scene_.yres < 65536;
-      if (raygen_pt_ >= 1 && pt_ok) {
+      if (raygen_lean_ && pt_ok) {
         const uint32_t total = pd.npix * pd.ns;
         if (pix_off_.n < 2 * (size_t)pd.npix) { HIP_CHECK(hipStreamSynchronize(st_)); pix_off_.alloc(2 * (size_t)pd.npix); }
         pool_.pix_off = pix_off_.p;
@@ -1663,15 +1739,26 @@ class Handle : public HandleBase {
           if (mixed_) HIP_CHECK(hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu, (k_trace_pt_f32<false, true>), kPtBlock, 0));
           else HIP_CHECK(hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu, (k_trace_pt_f32<false, false>), kPtBlock, 0));
           pt_grid_ = (uint32_t)(std::max(1, per_cu) * std::max(1, cus));
-          if (pairs_ok_ && scene_.stack_depth > (uint32_t)kPtStack) pt_overflow_.alloc((size_t)(scene_.stack_depth - kPtStack) * (size_t)pt_grid_ * kPtBlock * 2);
+          if (quads_.n) {   // the two-levels-per-fetch kernel has its own register count, and pushes up to three entries per two levels
+            int per_cu_q = 0;
+            HIP_CHECK(hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu_q, (k_trace_pt_f32<false, false, true>), kPtBlock, 0));
+            pt_grid_quad_ = (uint32_t)(std::max(1, per_cu_q) * std::max(1, cus));
+            if (getenv("RRT_DEBUG")) fprintf(stderr, "[rrt] quad nodes: %zu nodes, %d workgroup(s) per CU (pair-node kernel: %d)\n", quads_.n, per_cu_q, per_cu);
+          }
+          const uint32_t quad_depth = quads_.n ? 3u * ((scene_.stack_depth + 1u) / 2u) + 3u : 0u;   // deepest stack of a quad walk
+          const uint32_t depth_cl = std::max(scene_.stack_depth, quad_depth);
+          if (pairs_ok_ && depth_cl > (uint32_t)kPtStack) pt_overflow_.alloc((size_t)(depth_cl - kPtStack) * (size_t)std::max(pt_grid_, pt_grid_quad_) * kPtBlock * 2);
           if (pairs_ok_ && scene_.stack_depth > (uint32_t)kPtStackAny) pt_overflow_any_.alloc((size_t)(scene_.stack_depth - kPtStackAny) * (size_t)pt_grid_ * kPtBlock * 2);
         }
         TravScene t2 = trav_;
         t2.overflow = any ? pt_overflow_any_.p : pt_overflow_.p;
-        t2.overflow_stride = pt_grid_ * kPtBlock;
+        t2.overflow_stride = (any ? pt_grid_ : std::max(pt_grid_, pt_grid_quad_)) * kPtBlock;
         const uint32_t g2 = std::max(1u, std::min(grid_in, pt_grid_));
         uint32_t* work = &counters_.p[any ? C_WORK8_SHADOW : C_WORK8_CLOSEST];   // 8 cursors, one 128-B line each
-        if (mixed_) {
+        if (!any && !mixed_ && quad_on_ && quads_.n && pt_grid_quad_) {
+          const uint32_t gq = std::max(1u, std::min(grid_in, pt_grid_quad_));
+          hipLaunchKernelGGL((k_trace_pt_f32<false, false, true>), dim3(gq), dim3(kPtBlock), 0, stream, t2, pool_, queue, count, n_fixed, work, occluded, lo_pt, 0xffffffffu);
+        } else if (mixed_) {
           if (any) hipLaunchKernelGGL((k_trace_pt_f32<true, true>), dim3(g2), dim3(kPtBlock), 0, stream, t2, pool_, queue, count, n_fixed, work, occluded, lo_pt, 0xffffffffu);
           else hipLaunchKernelGGL((k_trace_pt_f32<false, true>), dim3(g2), dim3(kPtBlock), 0, stream, t2, pool_, queue, count, n_fixed, work, occluded, lo_pt, 0xffffffffu);
         } else {
@@ -1690,9 +1777,16 @@ class Handle : public HandleBase {
   void build_tile_trees() {
     tt_state_ = -1;
     if constexpr (std::is_same<R, float>::value) {
+      // the host copies of the tree are held only while a census needs them: fetched back from the device here, released at the end
+      struct HostCopies { std::vector<PairNode>& a; std::vector<Tri<float>>& b; ~HostCopies() { std::vector<PairNode>().swap(a); std::vector<Tri<float>>().swap(b); } } host_copies{pairs_host_, tris_host_};
+      if (pairs_host_.empty() && pairs_.n) {
+        pairs_host_.resize(pairs_.n); tris_host_.resize(tris_.n);
+        HIP_CHECK(hipMemcpy(pairs_host_.data(), pairs_.p, pairs_.n * sizeof(PairNode), hipMemcpyDeviceToHost));
+        if (tris_.n) HIP_CHECK(hipMemcpy(tris_host_.data(), tris_.p, tris_.n * sizeof(Tri<float>), hipMemcpyDeviceToHost));
+      }
       const size_t n_int = pairs_host_.size();
       const bool pt_ok = scene_.n_lens <= 32 && scene_.sampler_type == RRT_SAMPLER_HALTON && scene_.xres < 65536 && scene_.yres < 65536;
-      if (!use_persistent() || mixed_ || !pt_ok || raygen_pt_ < 1 || n_int <= kTtNodes || trav_.root_id != 0u || (uint64_t)n_int * 64u + kTtLocalBytes >= kIdle) return;
+      if (!use_persistent() || mixed_ || !pt_ok || !raygen_lean_ || n_int <= kTtNodes || trav_.root_id != 0u || (uint64_t)n_int * 64u + kTtLocalBytes >= kIdle) return;
       const uint64_t s_total = desc_.sampler.samples_per_pixel > 1 ? desc_.sampler.samples_per_pixel - 1 : 0;
       if (s_total == 0 || cap_ == 0) return;
       const auto t_begin = std::chrono::steady_clock::now();
@@ -1702,6 +1796,10 @@ class Handle : public HandleBase {
       // the census renders the image in pixel groups of what the pools hold: with very small pools (option "max_paths") that would be thousands of launches
       // for passes that do not qualify anyway - try again when the pools have grown
       if (cap_ / S < std::min<size_t>(W * H, 65536)) { tt_state_ = 0; return; }
+      // Bounded cost: the census copies ~32 B per camera ray to the host and the copies take (patches + 1) x kTtNodes x 64 B on both sides. Films beyond
+      // kTtMaxPixels (4096^2: 1 GB of transient host memory, 240 MB of HBM per handle) keep the ordinary kernels instead of a blocking, unbounded first frame.
+      constexpr size_t kTtMaxPixels = (size_t)4096 * 4096;
+      if (W * H > kTtMaxPixels) { warnings.push_back("tile_trees: film larger than 4096 x 4096 pixels - camera rays keep the ordinary traversal kernel"); return; }
       // ---- camera rays of the census, bucketed by patch
       struct CRay { float o[3], d[3]; };
       std::vector<CRay> rays;
@@ -1840,10 +1938,14 @@ class Handle : public HandleBase {
         }
       };
       {
+        // (an exception escaping a std::thread terminates the process: a worker that runs out of memory leaves the scene without tile trees instead)
+        std::atomic<bool> failed{false};
+        auto guarded_worker = [&]() { try { worker(); } catch (...) { failed = true; next_tree = n_trees; } };
         const unsigned nt = std::max(1u, std::min(16u, std::thread::hardware_concurrency()));
         std::vector<std::thread> pool;
-        for (unsigned k = 0; k < nt; k++) pool.emplace_back(worker);
+        for (unsigned k = 0; k < nt; k++) pool.emplace_back(guarded_worker);
         for (auto& th : pool) th.join();
+        if (failed) { warnings.push_back("tile_trees: the census ran out of host memory - camera rays keep the ordinary traversal kernel"); return; }
       }
       constexpr size_t kFront = kTtLocalBytes / sizeof(PairNode);
       std::vector<PairNode> shifted(kFront + n_int);
@@ -2008,7 +2110,6 @@ class Handle : public HandleBase {
       }
       pairs_.upload(packed, st_);
       HIP_CHECK(hipStreamSynchronize(st_));
-      if constexpr (std::is_same<R, float>::value) { pairs_host_ = packed; tris_host_.assign(tris.begin(), tris.end()); }
       trav_.any_list = (any_entry_on_ && any_list_.n) ? reinterpret_cast<const uint4*>(any_list_.p) : nullptr;
       trav_.pairs = pairs_.p;
       trav_.tris = reinterpret_cast<const float*>(tris_.p);
@@ -2017,6 +2118,75 @@ class Handle : public HandleBase {
       trav_.spheres = spheres_.p; trav_.insts = insts_.p;
       trav_.n_nodes = (uint32_t)nodes.size();
       pairs_ok_ = true;
+      build_quads(nodes);
+    }
+  }
+  // QuadNode array of the two-levels-per-fetch closest-hit kernel (dtraverse_f32.hpp): one node per interior node that a walk from the root in
+  // steps of two levels can reach; numbered BFS for the top kQuadTreelet (the kernel's LDS treelet), pre-order below
+  void build_quads(const std::vector<Node<R>>& nodes) {
+    if constexpr (std::is_same<R, float>::value) {
+      quads_.release(); trav_.quads = nullptr; trav_.n_qtreelet = 0;
+      if (mixed_ || nodes.empty() || (nodes[0].meta >> 2) != 0) return;
+      for (const auto& nd : nodes) if ((nd.meta >> 2) > kQuadLeafMax) return;
+      auto interior = [&](uint32_t i) { return (nodes[i].meta >> 2) == 0; };
+      // slots of N: (child, grandchild) linear indices; a leaf child = one slot holding the child itself
+      struct Slots { uint32_t n[4]; };
+      auto slots_of = [&](uint32_t N) {
+        Slots sl{{0xffffffffu, 0xffffffffu, 0xffffffffu, 0xffffffffu}};
+        const uint32_t c[2] = {N + 1u, nodes[N].offset};
+        for (int k = 0; k < 2; k++) {
+          if (interior(c[k])) { sl.n[2 * k] = c[k] + 1u; sl.n[2 * k + 1] = nodes[c[k]].offset; }
+          else sl.n[2 * k] = c[k];
+        }
+        return sl;
+      };
+      std::vector<uint32_t> qidx(nodes.size(), 0xffffffffu), order;
+      {   // BFS for the treelet
+        std::vector<uint32_t> frontier{0u};
+        while (!frontier.empty() && order.size() < (size_t)kQuadTreelet) {
+          std::vector<uint32_t> next;
+          for (uint32_t N : frontier) {
+            if (order.size() >= (size_t)kQuadTreelet) break;
+            qidx[N] = (uint32_t)order.size(); order.push_back(N);
+            const Slots sl = slots_of(N);
+            for (uint32_t g : sl.n) if (g != 0xffffffffu && interior(g)) next.push_back(g);
+          }
+          frontier.swap(next);
+        }
+        trav_.n_qtreelet = (uint32_t)order.size();
+        // the rest in pre-order
+        std::vector<uint32_t> todo{0u};
+        while (!todo.empty()) {
+          const uint32_t N = todo.back(); todo.pop_back();
+          if (qidx[N] == 0xffffffffu) { qidx[N] = (uint32_t)order.size(); order.push_back(N); }
+          const Slots sl = slots_of(N);
+          for (int k = 3; k >= 0; k--) if (sl.n[k] != 0xffffffffu && interior(sl.n[k])) todo.push_back(sl.n[k]);
+        }
+      }
+      if ((uint64_t)order.size() * 128u >= (1ull << 28)) { trav_.n_qtreelet = 0; return; }
+      std::vector<QuadNode> q(order.size());
+      const float nan = std::nanf("");
+      for (size_t i = 0; i < order.size(); i++) {
+        const uint32_t N = order[i];
+        const Slots sl = slots_of(N);
+        QuadNode& d = q[i];
+        memset(&d, 0, sizeof(d));
+        for (int k = 0; k < 4; k++) {
+          const uint32_t g = sl.n[k];
+          if (g == 0xffffffffu) { d.mnx[k] = d.mny[k] = d.mnz[k] = d.mxx[k] = d.mxy[k] = d.mxz[k] = nan; d.id[k] = kIdle & ~kQuadAxisMask; continue; }
+          d.mnx[k] = nodes[g].bmin[0]; d.mny[k] = nodes[g].bmin[1]; d.mnz[k] = nodes[g].bmin[2];
+          d.mxx[k] = nodes[g].bmax[0]; d.mxy[k] = nodes[g].bmax[1]; d.mxz[k] = nodes[g].bmax[2];
+          const uint32_t np = nodes[g].meta >> 2;
+          d.id[k] = np ? (kLeafBit | (np << 19) | nodes[g].offset) : qidx[g] * 128u;
+        }
+        const uint32_t c0 = N + 1u, c1 = nodes[N].offset;
+        d.id[0] |= (nodes[N].meta & 3u) << kQuadAxisShift;
+        d.id[1] |= (interior(c0) ? (nodes[c0].meta & 3u) : 0u) << kQuadAxisShift;
+        d.id[2] |= (interior(c1) ? (nodes[c1].meta & 3u) : 0u) << kQuadAxisShift;
+      }
+      quads_.upload(q, st_);
+      HIP_CHECK(hipStreamSynchronize(st_));
+      trav_.quads = quads_.p;
     }
   }
   // (the shading kernels that feed the shadow queue - k_shade_path, k_shade_nee - store the light table with the ray's start triangle)

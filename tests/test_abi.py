@@ -4,6 +4,7 @@ import ctypes as C
 import os
 import re
 import subprocess
+import sys
 
 import pytest
 
@@ -140,7 +141,7 @@ def test_missing_rccl_is_a_device_error_with_a_message(tmp_path):
         "assert lib.rrt_comm_id(buf) == A.RRT_EDEVICE\n"      # and again: the failure is remembered, not re-derived from a cleared dlerror()
         "print('ok')\n")
     env = dict(os.environ, RRT_RCCL_LIBRARY=str(tmp_path / "no_such_rccl.so"))
-    out = subprocess.run(["python", "-c", code], env=env, capture_output=True, text=True, timeout=300)
+    out = subprocess.run([sys.executable, "-c", code], env=env, capture_output=True, text=True, timeout=300)
     assert out.returncode == 0 and "ok" in out.stdout, out.stderr
 
 
@@ -162,7 +163,7 @@ STRUCTS = {"rrt_xform": A.Xform, "rrt_tri": A.Tri, "rrt_sphere": A.Sphere, "rrt_
 FIELDS = {"rrt_texture": ["image", "fallback", "world_to_texture"], "rrt_material": ["tex"], "rrt_image": ["levels"],
           "rrt_scene_desc": ["flags", "tris", "n_prims", "textures", "image_texels", "bvh_nodes", "prim_order", "bvh_depth", "world_bound", "camera", "film", "sampler", "integrator"],
           "rrt_camera": ["elems", "exit_pupil_bounds", "exit_pupil_valid"], "rrt_film": ["filter_table", "max_sample_luminance"],
-          "rrt_sampler": ["perms", "perm_seed", "jitter"], "rrt_render_stats": ["ms_total", "any_prims"], "rrt_rays": ["skip_prim"]}
+          "rrt_sampler": ["perms", "perm_seed", "jitter"], "rrt_render_stats": ["ms_total", "any_prims", "list_launches", "ms_gather"], "rrt_rays": ["skip_prim"]}
 
 
 def test_ctypes_mirror_matches_c_layout(tmp_path):

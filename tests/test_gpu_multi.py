@@ -81,6 +81,17 @@ def test_rccl_collective_through_the_c_abi(workdir):
         film = torch.zeros((H, W, 4), dtype=torch.float32, device="cuda:0")
         torch.cuda.synchronize()
         comm = Comm(Comm.new_id(), 0, 1, 0)
+        r.set_option("frame_stats", 1)
+        r.render_bands_begin(0, 1, film.data_ptr())
+        comm.gather(r, film.data_ptr(), 0)
+        st = r.render_end(stats=True)
+        # rrt_render_stats::ms_gather: HIP events on the handle's stream around the collective, apart from the render (ms_total)
+        assert st.ms_total > 0 and st.ms_gather >= 0
+        if filt:
+            assert st.ms_gather > 0          # a real ncclReduce ran between the two events
+        r.render_bands_begin(0, 1, film.data_ptr())
+        assert r.render_end(stats=True).ms_gather == 0    # a frame no collective followed reports none
+        film.zero_(); torch.cuda.synchronize()
         r.render_bands_begin(0, 1, film.data_ptr())
         comm.gather(r, film.data_ptr(), 0)
         r.render_end()
@@ -93,6 +104,45 @@ def test_rccl_collective_through_the_c_abi(workdir):
         assert np.array_equal(film.cpu().numpy(), ref)
         comm.close()
         r.close()
+
+
+def test_a_failure_inside_the_rccl_group_closes_it_before_the_communicator_is_aborted(workdir):
+    """an enqueue error inside an open ncclGroup. RRT_TEST_FAIL_GATHER makes this rank's transfer name a peer that does not exist, so
+    RCCL refuses the call inside the group; rrt_film_gather must end the group first (RCCL discards a group that holds a failed call), then abort
+    the communicator, report RRT_EDEVICE, refuse the rrt_comm from then on - and the process, the handle and a fresh communicator must go on working."""
+    from rs_ray_toy_amd import RRT_F32, Renderer, RrtError, Scene, scenes
+    from rs_ray_toy_amd.api import Comm
+    cfg, root = scenes.cfg2(workdir, xres=64, yres=48, nsamp=5, max_depth=2)
+    cfg["Film"]["Filter"] = {"filter_type": "GaussianFilter", "radius": [1.5, 1.5], "alpha": 2.0}   # the reduce form: one rank has something to issue
+    sc = Scene.loads(cfg, root)
+    W, H = sc.resolution
+    r = Renderer(sc, 0, RRT_F32)
+    film = torch.zeros((H, W, 4), dtype=torch.float32, device="cuda:0")
+    torch.cuda.synchronize()
+    ref = r.render()
+    comm = Comm(Comm.new_id(), 0, 1, 0)
+    os.environ["RRT_TEST_FAIL_GATHER"] = "0"
+    try:
+        r.render_bands_begin(0, 1, film.data_ptr())
+        with pytest.raises(RrtError) as e:
+            comm.gather(r, film.data_ptr(), 0)
+        assert "RCCL error" in str(e.value)
+        r.render_end()
+        assert np.array_equal(film.cpu().numpy(), ref)      # the frame itself is intact: nothing of the failed group was launched
+    finally:
+        del os.environ["RRT_TEST_FAIL_GATHER"]
+    with pytest.raises(RrtError) as e:                      # the aborted communicator is refused, not reused
+        comm.gather(r, film.data_ptr(), 0)
+    assert "aborted" in str(e.value)
+    comm.close()
+    comm2 = Comm(Comm.new_id(), 0, 1, 0)                    # and RCCL is still usable in this process
+    film.zero_(); torch.cuda.synchronize()
+    r.render_bands_begin(0, 1, film.data_ptr())
+    comm2.gather(r, film.data_ptr(), 0)
+    r.render_end()
+    assert np.array_equal(film.cpu().numpy(), ref)
+    comm2.close()
+    r.close()
 
 
 @pytest.mark.parametrize("filt", [None, {"filter_type": "TriangleFilter", "radius": [2.0, 2.0]}], ids=["box", "triangle"])

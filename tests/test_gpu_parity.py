@@ -691,6 +691,50 @@ def test_tile_trees_change_nothing(which, workdir):
         assert (out[tt][1].camera_rays, out[tt][1].closest_queries, out[tt][1].any_queries) == (out[0][1].camera_rays, out[0][1].closest_queries, out[0][1].any_queries)
 
 
+@pytest.mark.parametrize("which", ["cfg4", "cfg4_no_tile_trees", "cfg2", "cfg3", "cfg4_compat_bvh", "cfg4_direct", "cfg5"])
+def test_quad_nodes_change_nothing(which, workdir):
+    """Two levels per fetch (dtraverse_f32.hpp QuadNode, option "quad_nodes"): the closest-hit rays of the persistent kernel walk nodes that hold an
+    interior node's four grandchild boxes; the children's own boxes are not tested (a grandchild's box passing implies its parent's, monotone
+    rounding), slots are visited in the binary tree's order, every slot behind the one taken is judged when popped. Same leaves in the same
+    order, same triangle tests, same t_max sequence as the pair-node walk: frames, weights and query counts identical bit for bit - on the
+    heightfield (deep tree, 1-3 triangles per leaf), on the reference's tilted cubes (cfg2: exact box / face ties, t_max that grows, Q10), with
+    the reference-exact builder's overlapping children (Q26 / Q27), under DirectLighting and with glossy materials + area lights - and a ray
+    batch through the public entry point returns the same winners, t, u, v."""
+    kw = dict(xres=128, yres=96, nsamp=9, max_depth=5, n=64)
+    flags = RRT_FIXED_BVH
+    if which == "cfg2": cfg, root = scenes.cfg2(workdir, xres=96, yres=96, nsamp=9, max_depth=4)
+    elif which == "cfg3": cfg, root = scenes.cfg3(workdir, xres=96, yres=96, nsamp=9)
+    elif which == "cfg5": cfg, root = scenes.cfg5(workdir, xres=96, yres=96, nsamp=9, max_depth=6, n=64)
+    else: cfg, root = scenes.cfg4(workdir, **kw)
+    if which == "cfg4_compat_bvh": flags = 0
+    if which == "cfg4_direct": cfg["Integrator"] = {"integrator_type": "DirectLighting", "max_depth": 3, "light_strategy": "UniformSampleAll"}
+    sc = Scene.loads(cfg, root, flags=flags)
+    r = Renderer(sc, 0, RRT_F32)
+    r.set_option("pt_split_closest", 0)    # the persistent kernels at every queue size (the product switches at 100 000 rays)
+    if which == "cfg4_no_tile_trees": r.set_option("tile_trees", 0)   # the camera rays through the quad nodes as well
+    rng = np.random.default_rng(7)
+    wb = np.array(sc.desc.world_bound)
+    n = 20000
+    o = rng.uniform(wb[:3] - 2.0, wb[3:] + 2.0, (n, 3))
+    tgt = rng.uniform(wb[:3], wb[3:], (n, 3))
+    d = tgt - o; d /= np.linalg.norm(d, axis=1, keepdims=True)
+    d[:64, 0] = 0.0; d[64:128, 1] = 0.0; d[:128] /= np.linalg.norm(d[:128], axis=1, keepdims=True)   # axis-parallel components: inf inverse directions
+    tmax = np.full(n, np.inf)
+    out, hits = {}, {}
+    for q in (0, 1):
+        r.set_option("quad_nodes", q)
+        out[q] = r.render(stats=True)
+        r.set_option("persistent_traversal", 2)
+        hits[q] = r.trace_closest(o, d, tmax)
+        r.set_option("persistent_traversal", 3)
+    r.close()
+    assert out[1][0][..., :3].max() > 0 and (hits[0]["prim"] >= 0).mean() > 0.2
+    assert np.array_equal(out[1][0], out[0][0])
+    assert (out[1][1].camera_rays, out[1][1].closest_queries, out[1][1].any_queries) == (out[0][1].camera_rays, out[0][1].closest_queries, out[0][1].any_queries)
+    for k in ("prim", "t", "u", "v"):
+        assert np.array_equal(hits[1][k], hits[0][k]), k
+
+
 @pytest.mark.parametrize("which", ["cfg4", "cfg4_stage_b", "cfg4_bands", "cfg2", "cfg4_direct"])
 def test_root_cull_changes_nothing(which, workdir):
     """The fp32 path integrator's camera kernels answer a camera ray that misses the BVH's root box themselves - with the traversal kernels' own
@@ -722,14 +766,16 @@ def test_root_cull_changes_nothing(which, workdir):
     else: assert 0 < s1.root_culled < s1.camera_rays
 
 
-@pytest.mark.parametrize("which", ["cfg4", "cfg4_distant", "cfg4_far", "cfg2", "cfg3", "cfg3_direct", "cfg5_area"])
+@pytest.mark.parametrize("which", ["cfg4", "cfg4_distant", "cfg4_far", "cfg2", "cfg3", "cfg3_direct", "cfg5_area", "cfg5_area_near", "cfg5_area_xform"])
 def test_shadow_candidate_lists_change_nothing(which, workdir):
     """Shadow rays towards point / distant lights run down a per-(light, triangle) list of candidate leaves instead of walking the tree
     (dtraverse_f32.hpp k_shadow_lists_f32, rrt_impl.hpp build_shadow_lists()): a leaf's box test implies its ancestors', an occlusion query does
     not depend on the order, and the host lists every leaf whose box can meet a ray that starts on the triangle and points at the light. The
     same slab test on the same leaf boxes, the same triangle tests: frames and query counts with and without the lists are identical bit for
-    bit - mesh at the origin and 1e5 units away, axis-aligned instanced cubes, an enclosure whose light sits inside it. A scene with an area
-    light keeps the tree walk for every shadow ray (cfg5_area: the option changes nothing because nothing was built)."""
+    bit - mesh at the origin and 1e5 units away, axis-aligned instanced cubes, an enclosure whose light sits inside it. Sphere-shaped area
+    lights are sources too (cfg5_area: every point the light samples lies in its bounding sphere, the sweep towards it is a cone cut into
+    pieces; rrt_render_stats::list_launches says the lists served the launches) - also close to the surface, where most triangles get no
+    list and walk the tree inside the same kernel (cfg5_area_near), and with a scaled, rotated light transform."""
     if which == "cfg4": cfg, root = scenes.cfg4(workdir, xres=128, yres=128, nsamp=9, max_depth=6, n=96)
     elif which == "cfg4_distant": cfg, root = _cfg4_distant(workdir)
     elif which == "cfg4_far":
@@ -744,12 +790,19 @@ def test_shadow_candidate_lists_change_nothing(which, workdir):
     elif which == "cfg3_direct":
         cfg, root = scenes.cfg3(workdir, xres=128, yres=128, nsamp=9)
         cfg["Integrator"] = {"integrator_type": "DirectLighting", "light_strategy": "all", "max_depth": 3}
-    else: cfg, root = scenes.cfg5(workdir, xres=96, yres=96, nsamp=9, max_depth=6, n=64)
+    else:
+        cfg, root = scenes.cfg5(workdir, xres=96, yres=96, nsamp=9, max_depth=6, n=64)
+        if which == "cfg5_area_near":      # lights 1.2 units above the surface, radius 1: directions spread over half a hemisphere
+            for l in cfg["lights"]: l["light_shape"]["world_pos"][1] = 1.2
+        if which == "cfg5_area_xform":     # a scaled, rotated sphere transform: the bounding sphere must follow it
+            for k, l in enumerate(cfg["lights"]): l["light_shape"].update(scale=[1.5, 1.5, 1.5] if k % 2 else [0.5, 2.0, 1.0], rotation_axis=[1.0, 2.0, 3.0], rotation_angle=40.0)
     sc = Scene.loads(cfg, root, flags=RRT_FIXED_BVH)
     r = Renderer(sc, 0, RRT_F32)
     a, st_a = r.render(stats=True)
+    assert st_a.list_launches == st_a.any_launches > 0, (st_a.list_launches, st_a.any_launches)
     r.set_option("shadow_lists", 0)
     b, st_b = r.render(stats=True)
+    assert st_b.list_launches == 0
     r.set_option("any_entry", 0)               # ... and against the plain walk from the root
     c, st_c = r.render(stats=True)
     r.close()

@@ -30,7 +30,9 @@ for f in glob.glob(f"{root}/pass*/**/*counter_collection.csv", recursive=True):
             if re.search(pat, r["Kernel_Name"]):
                 tot[k][r["Counter_Name"]] += float(r["Counter_Value"]); disp[k][r["Counter_Name"]] += 1
 # product frames in the profiled run = closest-hit dispatches / 16 (8 bounces x the two regime kernels; the counting frame uses the generic kernels)
-FRAMES = max(1, round(disp["closest"]["FETCH_SIZE"] / 16))
+# (argv[2]: closest-hit dispatches per frame of other workloads - BASELINE cfg5 renders 16 passes x 16 bounces x 2 = 512)
+PER_FRAME = int(sys.argv[2]) if len(sys.argv) > 2 else 16
+FRAMES = max(1, round(disp["closest"]["FETCH_SIZE"] / PER_FRAME))
 out = {"units": "bytes per frame; FETCH_SIZE x1024 x factor (traversal gathers x1, streaming families x2: profiles/r3_fetch_calibration.txt), WRITE_SIZE x1024",
        "fetch_size_factor": {"closest": 1.0, "any": 1.0, "raygen": 2.0, "shade": 2.0, "film": 2.0},
        "fetch_size_factor_source": "profiles/r3_fetch_calibration.txt (tools/micro/fetch_calib.hip): 64-B-node gather 1.003, coalesced 16 B per lane 0.500 of the known bytes",
@@ -48,6 +50,9 @@ for k in fam:
     if acc > 0:
         nf = FRAMES if k in ("closest", "any") else FRAMES + 1
         out[k]["tcp_accesses"] = acc / nf
+        # vector L1 -> L2 read requests (64 B each) and the L2's hits / misses: what bench.py's measured `frac` is made of
+        for name, key in (("TCP_TCC_READ_REQ_sum", "tcp_tcc_read_req"), ("TCC_HIT_sum", "tcc_hit"), ("TCC_MISS_sum", "tcc_miss")):
+            if tot[k].get(name, 0.0) > 0: out[k][key] = tot[k][name] / nf
         if tot[k].get("SQ_INSTS_VMEM_RD", 0.0) > 0:   # wave-level vector loads: accesses / (64 x this) = how full the loading waves are
             out[k]["vmem_rd_insts"] = tot[k]["SQ_INSTS_VMEM_RD"] / nf
 # VALU lane utilisation of the traversal kernels where the SQ pass was collected too (tools/pmc.sh pass 1)

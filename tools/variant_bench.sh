@@ -8,6 +8,6 @@ for v in "$@"; do
 import json, sys
 d = json.load(open(f"gpurun_out/vb_{sys.argv[1]}.json"))
 k = d["kernel_ms_per_frame"]; r = d["roofline"]
-print(f"{sys.argv[1]:24s} frame {d['ms_per_step']:7.3f} ms  closest {k['ms_closest']:6.2f} (alone {r['alone_avg_launch_ms'] * r['launches']:6.2f})  any {k['ms_any']:6.2f}  raygen {k['ms_raygen']:6.2f}  shade {k['ms_shade']:5.2f}")
+print(f"{sys.argv[1]:24s} frame {d['ms_per_step']:7.3f} ms  closest {k['ms_closest']:6.2f} (alone {r['alone']['avg_launch_ms'] * r['launches']:6.2f})  any {k['ms_any']:6.2f}  raygen {k['ms_raygen']:6.2f}  shade {k['ms_shade']:5.2f}")
 PY
 done
