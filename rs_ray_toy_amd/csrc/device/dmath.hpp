@@ -585,6 +585,13 @@ template <typename R> RRT_DEV Rgb<R> fr_conductor(R cos_i_in, Rgb<R> eta_i, Rgb<
   return (rp + rs) * Rgb<R>(R(0.5));
 }
 
+// tuning variants: the microfacet helpers as real calls (code size of the glossy / general shading kernels against the 64 KB instruction cache two CUs share)
+#ifdef RRT_MICRO_NOINLINE
+#define RRT_MICRO __attribute__((noinline)) __device__
+#else
+#define RRT_MICRO RRT_DEV
+#endif
+
 template <typename R>
 struct Lobe {
   uint32_t kind, type, fr;
@@ -595,22 +602,25 @@ struct Lobe {
 };
 
 // TrowbridgeReitzDistribution microfacet.rs:253-425
-template <typename R> RRT_DEV R tr_d(const Lobe<R>& l, V3<R> wh) {
+// (the arithmetic takes its parameters by value: as real calls - RRT_MICRO_NOINLINE - nothing of the Lobe has to live in memory)
+template <typename R> RRT_MICRO R tr_d_v(R alpha_x, R alpha_y, V3<R> wh) {
   R tan2 = tan2_theta(wh);
   if (isinf(tan2)) return R(0);
   R cos4 = cos2_theta(wh) * cos2_theta(wh);
   R cp = cos_phi(wh), sp = sin_phi(wh);
-  R e = ((cp * cp) / (l.alpha_x * l.alpha_x) + (sp * sp) / (l.alpha_y * l.alpha_y)) * tan2;
-  return R(1) / (R(RRT_PI) * l.alpha_x * l.alpha_y * cos4 * (R(1) + e) * (R(1) + e));
+  R e = ((cp * cp) / (alpha_x * alpha_x) + (sp * sp) / (alpha_y * alpha_y)) * tan2;
+  return R(1) / (R(RRT_PI) * alpha_x * alpha_y * cos4 * (R(1) + e) * (R(1) + e));
 }
-template <typename R> RRT_DEV R tr_lambda(const Lobe<R>& l, V3<R> w) {
+template <typename R> RRT_DEV R tr_d(const Lobe<R>& l, V3<R> wh) { return tr_d_v(l.alpha_x, l.alpha_y, wh); }
+template <typename R> RRT_MICRO R tr_lambda_v(R alpha_x, R alpha_y, V3<R> w) {
   R abs_tan = rabs(tan_theta(w));
   if (isinf(abs_tan)) return R(0);
   R cp = cos_phi(w), sp = sin_phi(w);
-  R alpha = sqrt((cp * cp) * (l.alpha_x * l.alpha_x) + (sp * sp) * (l.alpha_y * l.alpha_y));
+  R alpha = sqrt((cp * cp) * (alpha_x * alpha_x) + (sp * sp) * (alpha_y * alpha_y));
   R a2t2 = (alpha * abs_tan) * (alpha * abs_tan);
   return (R(-1) + R(sqrt(R(1) + a2t2))) / R(2);
 }
+template <typename R> RRT_DEV R tr_lambda(const Lobe<R>& l, V3<R> w) { return tr_lambda_v(l.alpha_x, l.alpha_y, w); }
 template <typename R> RRT_DEV R tr_g1(const Lobe<R>& l, V3<R> w) { return R(1) / (R(1) + tr_lambda(l, w)); }
 template <typename R> RRT_DEV R tr_g(const Lobe<R>& l, V3<R> wo, V3<R> wi) { return R(1) / (R(1) + tr_lambda(l, wo) + tr_lambda(l, wi)); }
 template <typename R> RRT_DEV R tr_pdf(const Lobe<R>& l, V3<R> wo, V3<R> wh) { return tr_d(l, wh) * tr_g1(l, wo) * absdot(wo, wh) / abs_cos_theta(wo); }
@@ -639,7 +649,7 @@ template <typename R> RRT_DEV void tr_sample_11(R cos_t, R u1, R u2, R* slope_x,
         (nu2 * (nu2 * (nu2 * R(0.093073) + R(0.309420)) - R(1)) + R(0.597999));
   *slope_y = sg * z * R(sqrt(R(1) + *slope_x * *slope_x));
 }
-template <typename R> RRT_DEV V3<R> tr_sample(V3<R> wi, R ax, R ay, R u1, R u2) {  // :325-363
+template <typename R> RRT_MICRO V3<R> tr_sample(V3<R> wi, R ax, R ay, R u1, R u2) {  // :325-363
   V3<R> ws = vnormalize(V3<R>(ax * wi.x, ay * wi.y, wi.z));
   R sx = 0, sy = 0;
   tr_sample_11(cos_theta(ws), u1, u2, &sx, &sy);
@@ -653,11 +663,12 @@ template <typename R> RRT_DEV V3<R> tr_sample_wh(const Lobe<R>& l, V3<R> wo, R u
   if (wo.z < R(0)) return -tr_sample(-wo, l.alpha_x, l.alpha_y, u0, u1);
   return tr_sample(wo, l.alpha_x, l.alpha_y, u0, u1);
 }
-template <typename R> RRT_DEV Rgb<R> fresnel_eval(const Lobe<R>& l, R cos_i) {  // reflection.rs:599-615
-  if (l.fr == FR_NOOP) return Rgb<R>(R(1));
-  if (l.fr == FR_DIELECTRIC) return Rgb<R>(fr_dielectric(cos_i, l.eta_i.r, l.eta_t.r));
-  return fr_conductor(rabs(cos_i), l.eta_i, l.eta_t, l.k);
+template <typename R> RRT_MICRO Rgb<R> fresnel_eval_v(uint32_t fr, Rgb<R> eta_i, Rgb<R> eta_t, Rgb<R> k, R cos_i) {  // reflection.rs:599-615
+  if (fr == FR_NOOP) return Rgb<R>(R(1));
+  if (fr == FR_DIELECTRIC) return Rgb<R>(fr_dielectric(cos_i, eta_i.r, eta_t.r));
+  return fr_conductor(rabs(cos_i), eta_i, eta_t, k);
 }
+template <typename R> RRT_DEV Rgb<R> fresnel_eval(const Lobe<R>& l, R cos_i) { return fresnel_eval_v(l.fr, l.eta_i, l.eta_t, l.k, cos_i); }
 // Lobe-kind sets. A scene's materials fix which BxDFs can ever exist at its hits; the shading kernels are instantiated for a few such sets
 // (KM = bit mask over LOBE_*, ~0u = every kind) so that the code - and above all the registers - of the kinds a scene cannot produce are not
 // part of its kernel (Lambert-only scenes: 128 -> 99 VGPRs, 4 -> 5 waves per SIMD in the latency-bound path shading kernel). Same arithmetic

@@ -1100,11 +1100,14 @@ RRT_DEV float rg_begin_lean(const SceneDev<float>& s, float pfx, float pfy, floa
   const float fx = -p2x, fy = p2y;
   const float r2 = fx * fx + fy * fy;
   const float r_film = __builtin_amdgcn_sqrtf(r2);
-  const float* pb = (r_film / (s.diagonal / 2.0f) >= 1.0f) ? s.pupil63 : s.pupil0;   // Q6
-  const float plx = pb[0] * (1.0f - lx) + pb[2] * lx, ply = pb[1] * (1.0f - ly) + pb[3] * ly;
+  // Q6: the last exit-pupil box beyond the film's half diagonal, else the first one. Both boxes are kernel arguments (scalar registers): the choice is
+  // four selects, not a per-lane pointer into the argument block (which compiled to vector loads of the kernel arguments in every thread)
+  const bool outer = r_film / (s.diagonal / 2.0f) >= 1.0f;
+  const float pb0 = outer ? s.pupil63[0] : s.pupil0[0], pb1 = outer ? s.pupil63[1] : s.pupil0[1], pb2 = outer ? s.pupil63[2] : s.pupil0[2], pb3 = outer ? s.pupil63[3] : s.pupil0[3];
+  const float plx = pb0 * (1.0f - lx) + pb2 * lx, ply = pb1 * (1.0f - ly) + pb3 * ly;
   const float inv_r = __builtin_amdgcn_rcpf(r_film);
   const float sin_t = r_film != 0.0f ? fy * inv_r : 0.0f, cos_t = r_film != 0.0f ? fx * inv_r : 1.0f;
-  const float area = (pb[2] - pb[0]) * (pb[3] - pb[1]);
+  const float area = (pb2 - pb0) * (pb3 - pb1);
   const float rear_z = s.lens[s.n_lens - 1].thickness;
   const V3<float> dir(cos_t * plx - sin_t * ply - fx, sin_t * plx + cos_t * ply - fy, rear_z);
   const float il = __builtin_amdgcn_rsqf(len2(dir));
@@ -1187,6 +1190,7 @@ namespace rrtd {
 #define RRT_RG_DENSE 512
 #endif
 constexpr int kRgDense = RRT_RG_DENSE;
+static_assert((kRgDense & (kRgDense - 1)) == 0, "the camera workgroup is split into pixels x samples by shifts");
 #ifndef RRT_RG_REPACK
 #define RRT_RG_REPACK 3
 #endif
@@ -1216,8 +1220,10 @@ static __global__ void __launch_bounds__(kRgDense) k_raygen_main_f32(SceneDev<fl
   // grid: x = sample of the pass, (y, z) = pixel block - blocks are dispatched x first, so the survivors reach the queue pixel block by pixel
   // block (all samples of 512 neighbouring pixels together): the queue is in image order, which the XCD-aware traversal relies on
   // A block is kRgPix pixels x (kRgDense / kRgPix) consecutive samples (spb: samples per block, a kernel argument: 1 = one sample of kRgDense pixels)
-  const uint32_t ppb = blockDim.x / spb;   // pixels per block
-  const uint32_t pl = (blockIdx.z * gridDim.y + blockIdx.y) * ppb + tid % ppb, sl = blockIdx.x * spb + tid / ppb;
+  // (spb is 1, 2, 4 or 8 - rrt_impl.hpp checks -, so the workgroup's split into pixels x samples is shifts and masks, not the divisions by a kernel argument that
+  // used to open every thread's prologue with ~40 instructions)
+  const uint32_t spb_log2 = (uint32_t)__builtin_ctz(spb), ppb_log2 = (uint32_t)__builtin_ctz((uint32_t)kRgDense) - spb_log2, ppb = 1u << ppb_log2;   // pixels per block
+  const uint32_t pl = ((blockIdx.z * gridDim.y + blockIdx.y) << ppb_log2) + (tid & (ppb - 1u)), sl = (blockIdx.x << spb_log2) + (tid >> ppb_log2);
   bool alive = false;
   uint32_t slot = 0, index = 0;
   float pfx = 0, pfy = 0, lx = 0, ly = 0, w = 0;
