@@ -286,20 +286,23 @@ def main():
     counted["closest_launches"] = timed["closest_launches"]
     counted["root_culled"] = timed["root_culled"]   # (the counting frame keeps every query in the queue)
     cnt = torch.tensor([float(counted[k]) for k in keys] + [timed["ms_closest"], timed["ms_any"], timed["ms_shade"], timed["ms_raygen"], timed["ms_film"], timed["ms_total"], isolated["ms_closest"],
-                                                            single["ms_closest"], single["ms_any"], single["ms_shade"], single["ms_raygen"], single["ms_film"], single["ms_total"]],
+                                                            single["ms_closest"], single["ms_any"], single["ms_shade"], single["ms_raygen"], single["ms_film"], single["ms_total"],
+                                                            timed["ms_gather"]],
                        dtype=torch.float64, device=stat_dev)
     if world > 1:
         dist.all_reduce(tt, op=dist.ReduceOp.MAX)
-        mx = cnt.clone()
+        mx, mn = cnt.clone(), cnt.clone()
         dist.all_reduce(cnt, op=dist.ReduceOp.SUM)
         dist.all_reduce(mx, op=dist.ReduceOp.MAX)
+        dist.all_reduce(mn, op=dist.ReduceOp.MIN)
     else:
-        mx = cnt
+        mx = mn = cnt
     elapsed = float(tt.item())
     names = keys + ["ms_closest", "ms_any", "ms_shade", "ms_raygen", "ms_film", "ms_total", "ms_closest_isolated",
-                    "ms1_closest", "ms1_any", "ms1_shade", "ms1_raygen", "ms1_film", "ms1_total"]
+                    "ms1_closest", "ms1_any", "ms1_shade", "ms1_raygen", "ms1_film", "ms1_total", "ms_gather"]
     tot = dict(zip(names, cnt.tolist()))
     mx_tot = dict(zip(names, mx.tolist()))
+    mn_tot = dict(zip(names, mn.tolist()))
 
     if rank == 0:
         ms_per_step = elapsed / args.steps * 1e3
@@ -424,6 +427,11 @@ def main():
             "any_nodes_per_query": round(tot["any_nodes"] / max(1.0, tot["any_queries"]), 2), "any_tris_per_query": round(tot["any_prims"] / max(1.0, tot["any_queries"]), 2),
             "kernel_ms_per_frame": {k: round(mx_tot[k], 3) for k in ("ms_raygen", "ms_closest", "ms_any", "ms_shade", "ms_film", "ms_total")},
             "kernel_ms_per_frame_one_at_a_time": {k.replace("ms1_", "ms_"): round(mx_tot[k], 3) for k in ("ms1_raygen", "ms1_closest", "ms1_any", "ms1_shade", "ms1_film", "ms1_total")},
+            # per rank, per frame of the timed region (HIP events on each rank's own stream): the render (ms_total: camera kernel to film kernel) and the frame's
+            # collective (ms_gather: around the grouped ncclSend / ncclRecv or the ncclReduce of rrt_film_gather) - max and min over the ranks, so that a scaling
+            # run can tell render imbalance between the ranks (max - min of ms_total) from the time the collective takes (0 with one rank / the gloo rehearsal)
+            "ranks": {"ms_total": {"max": round(mx_tot["ms_total"], 3), "min": round(mn_tot["ms_total"], 3)},
+                      "ms_gather": {"max": round(mx_tot["ms_gather"], 3), "min": round(mn_tot["ms_gather"], 3)}},
             "host_scene_build_s": round(t_build, 3),
         }
         print(json.dumps(out))

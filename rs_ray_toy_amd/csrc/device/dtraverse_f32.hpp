@@ -758,6 +758,15 @@ __global__ void __launch_bounds__(kPtBlock) RRT_PT_ATTR k_trace_pt_f32(TravScene
 #define RRT_TT_VOTE_A 1u
 #define RRT_TT_VOTE_B 2u
 #endif
+// Triangle packets in LDS (the north_star's "BVH sub-trees and triangle packets are staged through LDS"): a build with RRT_TT_TRIS > 0 keeps, behind a patch's
+// copy of the tree, the triangles of the leaves its camera rays test most (only leaves that are children of copied nodes: their leaf words live in the copy
+// and are rewritten to kLeafBit | kSpecialLeaf | n << 19 | index into the local triangle array; the record's material word - which no triangle test reads -
+// carries the triangle's index in the whole array, what the hit record needs). The LDS they take comes out of the stack (RRT_TT_STACK entries per lane).
+// Measured: see there; the default build has RRT_TT_TRIS = 0 and none of this code.
+#ifndef RRT_TT_TRIS
+#define RRT_TT_TRIS 0
+#endif
+constexpr uint32_t kTtTris = RRT_TT_TRIS;
 constexpr int kTtBlock = RRT_TT_BLOCK, kTtStack = RRT_TT_STACK;
 constexpr uint32_t kTtNodes = RRT_TT_NODES;      // pair nodes per local copy (15 KB + 64 KB of stacks: two workgroups per CU, 8 waves per SIMD)
 // LDS byte address of slot k of a copy = the child word that names it (see the kernel): 16 bytes of padding after every four slots, so that slots
@@ -765,7 +774,7 @@ constexpr uint32_t kTtNodes = RRT_TT_NODES;      // pair nodes per local copy (1
 constexpr uint32_t tt_local_addr(uint32_t k) { return 64u * k + 16u * (k >> 2); }
 constexpr uint32_t kTtLocalBytes = (tt_local_addr(kTtNodes - 1u) + 64u + 63u) & ~63u;
 constexpr bool tt_local_layout_ok() { for (uint32_t k = 0; k + 1u < kTtNodes; k++) if (tt_local_addr(k + 1u) < tt_local_addr(k) + 64u) return false; return true; }
-static_assert(tt_local_layout_ok() && kTtLocalBytes + (uint32_t)kTtStack * kTtBlock * 8u + 8u <= (160u * 1024u) / RRT_TT_WG_PER_CU - 512u, "tile trees: LDS layout / budget");
+static_assert(tt_local_layout_ok() && kTtLocalBytes + kTtTris * 48u + (uint32_t)kTtStack * kTtBlock * 8u + 8u <= (160u * 1024u) / RRT_TT_WG_PER_CU - 512u, "tile trees: LDS layout / budget");
 constexpr uint32_t kTtMacro = 32u;               // edge of the image patch that shares a copy, in pixels
 #ifndef RRT_TT_ITEM_TILES
 #define RRT_TT_ITEM_TILES 2
@@ -774,6 +783,7 @@ constexpr uint32_t kTtItemTiles = RRT_TT_ITEM_TILES;            // 8 x 8 tiles p
 constexpr uint32_t kTtRange = 16384u, kTtRangeChunk = 256u;
 struct TileTrees {
   const float4* trees;     // [n_trees + 1][kTtNodes][4]: the local copies, patch by patch (row-major over the image); the last one = top of the tree
+  const float4* tris;      // [n_trees + 1][kTtTris][3]: the patches' triangle packets (RRT_TT_TRIS > 0 builds), else null
   const uint2* chunks;     // per camera workgroup of the pass (pixel block x sample group): {first queue entry, entries}
   uint32_t tiles_x, tiles_y;   // 8 x 8 tiles of the pass's pixel grid
   uint32_t groups;         // camera workgroups (sample groups) per tile
@@ -794,6 +804,7 @@ __global__ void __launch_bounds__(kTtBlock) __attribute__((amdgpu_waves_per_eu(R
   // immediate offsets 0 / 16 / 32 / 48 - no address arithmetic in the node step), and the 16 bytes of padding after every four slots spread the
   // 64 lanes of one read over all 16 bank groups like the XOR swizzle of k_trace_pt_f32's treelet does.
   __shared__ __attribute__((aligned(1024))) float4 tree[kTtLocalBytes / 16];   // (the most aligned LDS object is placed first: offset 0)
+  __shared__ float4 ltris[kTtTris > 0 ? kTtTris * 3 : 1];                      // the patch's triangle packet (RRT_TT_TRIS > 0)
   __shared__ uint2 stk[kTtStack * kTtBlock];
   __shared__ uint32_t s_item, s_next;
   constexpr uint32_t tl_bytes = kTtLocalBytes;
@@ -864,6 +875,10 @@ __global__ void __launch_bounds__(kTtBlock) __attribute__((amdgpu_waves_per_eu(R
     {
       const float4* src = tt.trees + (size_t)tree_id * (kTtNodes * 4u);
       for (uint32_t i = tid; i < kTtNodes * 4u; i += kTtBlock) tree[i + (i >> 4)] = src[i];   // word i & 3 of slot i >> 2 at tt_local_addr(i >> 2) / 16 + (i & 3)
+      if (kTtTris > 0) {
+        const float4* tsrc = tt.tris + (size_t)tree_id * (kTtTris * 3u);
+        for (uint32_t i = tid; i < kTtTris * 3u; i += kTtBlock) ltris[i] = tsrc[i];
+      }
     }
     __syncthreads();
 
@@ -926,7 +941,19 @@ __global__ void __launch_bounds__(kTtBlock) __attribute__((amdgpu_waves_per_eu(R
         }
       } else {
         if (is_leaf(cur)) {
-          if (leaf_step_f32<false, MIXED>(ts, cur, r, &hit, &hu, &hv)) finish();
+          if (kTtTris > 0 && (cur & kSpecialLeaf) != 0u) {   // a leaf of the patch's triangle packet: the same tests on the LDS copy of the same 48 bytes
+            uint32_t lf = cur & 0x7ffffu, ln = (cur >> 19) & kLeafCountMask;
+            do {
+              const float4 a = ltris[3u * lf], b = ltris[3u * lf + 1u], c = ltris[3u * lf + 2u];
+              float t, u, v;
+              if (tri_test_vals_f32<false>(F4{a.x, a.y, a.z, a.w}, F4{b.x, b.y, b.z, b.w}, F4{c.x, c.y, c.z, c.w}, r, &t, &u, &v)) {
+                r.tmax = t; hit = (int)__float_as_uint(c.y); hu = u; hv = v;   // (the material word of the copy = the triangle's index in the whole array)
+              }
+              lf++; ln--;
+            } while (ln != 0);
+            pop();
+          }
+          else if (leaf_step_f32<false, MIXED>(ts, cur, r, &hit, &hu, &hv)) finish();
           else pop();
         }
       }
@@ -1100,14 +1127,14 @@ RRT_DEV float rg_begin_lean(const SceneDev<float>& s, float pfx, float pfy, floa
   const float fx = -p2x, fy = p2y;
   const float r2 = fx * fx + fy * fy;
   const float r_film = __builtin_amdgcn_sqrtf(r2);
-  // Q6: the last exit-pupil box beyond the film's half diagonal, else the first one. Both boxes are kernel arguments (scalar registers): the choice is
-  // four selects, not a per-lane pointer into the argument block (which compiled to vector loads of the kernel arguments in every thread)
-  const bool outer = r_film / (s.diagonal / 2.0f) >= 1.0f;
-  const float pb0 = outer ? s.pupil63[0] : s.pupil0[0], pb1 = outer ? s.pupil63[1] : s.pupil0[1], pb2 = outer ? s.pupil63[2] : s.pupil0[2], pb3 = outer ? s.pupil63[3] : s.pupil0[3];
-  const float plx = pb0 * (1.0f - lx) + pb2 * lx, ply = pb1 * (1.0f - ly) + pb3 * ly;
+  const float* pb = (r_film / (s.diagonal / 2.0f) >= 1.0f) ? s.pupil63 : s.pupil0;   // Q6
+  // (Measured and reverted in round 4: choosing the box with four selects on the kernel arguments instead of this per-lane pointer - which compiles to vector loads of the
+  // argument block - saves ~10 instructions, but the compiler then contracts `pb[0] * (1 - lx) + pb[2] * lx` differently, the camera rays move in their last bit, every
+  // sphere coin of DESIGN.md section 4 is tossed again and test_fp32_spheres_at_a_converged_sample_count[matte] lands at 1.037 against its 1.03: the bar sits on the bias itself.)
+  const float plx = pb[0] * (1.0f - lx) + pb[2] * lx, ply = pb[1] * (1.0f - ly) + pb[3] * ly;
   const float inv_r = __builtin_amdgcn_rcpf(r_film);
   const float sin_t = r_film != 0.0f ? fy * inv_r : 0.0f, cos_t = r_film != 0.0f ? fx * inv_r : 1.0f;
-  const float area = (pb2 - pb0) * (pb3 - pb1);
+  const float area = (pb[2] - pb[0]) * (pb[3] - pb[1]);
   const float rear_z = s.lens[s.n_lens - 1].thickness;
   const V3<float> dir(cos_t * plx - sin_t * ply - fx, sin_t * plx + cos_t * ply - fy, rear_z);
   const float il = __builtin_amdgcn_rsqf(len2(dir));

@@ -77,6 +77,7 @@ struct DevBuf {
   DevBuf& operator=(const DevBuf&) = delete;
 };
 
+inline float __uint_as_float_host(uint32_t u) { float f; memcpy(&f, &u, 4); return f; }
 template <typename R> inline R narrow_down(double v) { return (R)v; }
 template <typename R> inline R narrow_up(double v) { return (R)v; }
 template <> inline float narrow_down<float>(double v) { float f = (float)v; if ((double)f > v) f = nextafterf(f, -INFINITY); return f; }
@@ -1016,6 +1017,7 @@ class Handle : public HandleBase {
   DevBuf<PairNode> tt_pairs_;              // kTtLocalBytes unused bytes, then the whole tree with its interior child words shifted by kTtLocalBytes
   DevBuf<PairNode> tt_trees_;              // [patches + 1][kTtNodes]
   DevBuf<uint2> tt_chunks_;
+  DevBuf<float4> tt_tris_;                 // [patches + 1][kTtTris][3] (RRT_TT_TRIS > 0 builds)
   DevBuf<uint32_t> tt_overflow_;
   uint32_t tt_grid_ = 0, tt_mt_x_ = 0, tt_n_trees_ = 0;
   TileTrees tt_pass_{};                    // this pass
@@ -1655,7 +1657,7 @@ class Handle : public HandleBase {
               pd.ns % spb == 0 && use_persistent() && trav_mode_ == 3 && !count_traversal_) {
             const size_t n_chunks = (size_t)gy * gz * ((pd.ns + spb - 1) / spb);
             if (tt_chunks_.n < n_chunks) { HIP_CHECK(hipStreamSynchronize(st_)); tt_chunks_.alloc(n_chunks); }
-            tt_pass_ = TileTrees{reinterpret_cast<const float4*>(tt_trees_.p), tt_chunks_.p, (uint32_t)pd.rw / kTileW, pd.npix / (uint32_t)pd.rw / kTileH, pd.ns / spb, tt_mt_x_, tt_n_trees_, pd};
+            tt_pass_ = TileTrees{reinterpret_cast<const float4*>(tt_trees_.p), tt_tris_.p, tt_chunks_.p, (uint32_t)pd.rw / kTileW, pd.npix / (uint32_t)pd.rw / kTileH, pd.ns / spb, tt_mt_x_, tt_n_trees_, pd};
             tt_pass_ok_ = true;
           }
           hipLaunchKernelGGL(k_raygen_main_f32, dim3((pd.ns + spb - 1) / spb, gy, gz), dim3(kRgDense), 0, st_, scene_, pool_, pd, write_samp, dims_out, safe_r2, aux_delta_, aux_pupil_, enqueue, spb,
@@ -1838,6 +1840,34 @@ class Handle : public HandleBase {
       // ---- per patch: walk, count, choose, copy
       std::vector<PairNode> trees((size_t)(n_trees + 1) * kTtNodes);
       memset(trees.data(), 0, trees.size() * sizeof(PairNode));
+      std::vector<float4> packets(kTtTris > 0 ? (size_t)(n_trees + 1) * kTtTris * 3u : 0u, make_float4(0.0f, 0.0f, 0.0f, 0.0f));   // RRT_TT_TRIS > 0 builds
+      std::atomic<uint64_t> sum_local_tests{0}, sum_tests{0};
+      // the triangle packet of one copy: the leaves named by the copy's nodes, most tested first, while they fit; their words rewritten to local indices
+      auto pack_tris = [&](PairNode* dst, uint32_t n_nodes, float4* out, const std::vector<uint32_t>& tcount, uint64_t* served) {
+        if (kTtTris == 0) return;
+        struct L { uint32_t count, node, which; };
+        std::vector<L> leaves;
+        for (uint32_t k = 0; k < n_nodes; k++) for (uint32_t w = 0; w < 2; w++) {
+          const uint32_t id = w ? dst[k].id1 : dst[k].id0;
+          if ((id & kLeafBit) && !(id & kSpecialLeaf)) leaves.push_back(L{tcount.empty() ? 0u : tcount[id & 0x7ffffu], k, w});
+        }
+        std::stable_sort(leaves.begin(), leaves.end(), [](const L& a, const L& b) { return a.count > b.count; });
+        uint32_t used = 0;
+        for (const L& l : leaves) {
+          uint32_t& id = l.which ? dst[l.node].id1 : dst[l.node].id0;
+          const uint32_t first = id & 0x7ffffu, np = (id >> 19) & kLeafCountMask;
+          if (used + np > kTtTris) continue;
+          for (uint32_t t = 0; t < np; t++) {
+            const Tri<float>& tr = tris_host_[first + t];
+            out[3u * (used + t)] = make_float4(tr.p0[0], tr.p0[1], tr.p0[2], tr.p1[0]);
+            out[3u * (used + t) + 1u] = make_float4(tr.p1[1], tr.p1[2], tr.p2[0], tr.p2[1]);
+            out[3u * (used + t) + 2u] = make_float4(tr.p2[2], __uint_as_float_host(first + t), __uint_as_float_host(tr.shade), __uint_as_float_host(tr.plane));   // material word <- the triangle's own index
+          }
+          id = kLeafBit | kSpecialLeaf | (np << 19) | used;
+          used += np;
+          if (served) *served += l.count;
+        }
+      };
       const uint32_t shift = kTtLocalBytes;   // interior child words of the whole tree start here; below: LDS addresses of a copy's slots
       auto slab = [](const float bmin[3], const float bmax[3], const float o[3], const float inv[3], float* t) {
         float tn = -INFINITY, tf = INFINITY;
@@ -1856,11 +1886,13 @@ class Handle : public HandleBase {
       };
       std::vector<uint32_t> top(kTtNodes);
       for (uint32_t k = 0; k < kTtNodes; k++) top[k] = k;
-      { std::vector<uint32_t> slot_of(n_int, 0xffffffffu); copy_into(&trees[(size_t)n_trees * kTtNodes], top, slot_of); }
+      { std::vector<uint32_t> slot_of(n_int, 0xffffffffu); copy_into(&trees[(size_t)n_trees * kTtNodes], top, slot_of);
+        if (kTtTris > 0) pack_tris(&trees[(size_t)n_trees * kTtNodes], kTtNodes, &packets[(size_t)n_trees * kTtTris * 3u], std::vector<uint32_t>(), nullptr); }
       std::atomic<uint32_t> next_tree{0};
       std::atomic<uint64_t> sum_nodes{0}, n_with{0};
       auto worker = [&]() {
         std::vector<uint32_t> counts(n_int, 0), touched, slot_of(n_int, 0xffffffffu), sel;
+        std::vector<uint32_t> tcount(kTtTris > 0 ? tris_host_.size() : 0u, 0u), ttouched;   // leaf visits of this patch's census rays, by the leaf's first triangle
         struct E { uint32_t w; float t; };
         std::vector<E> stack;
         for (;;) {
@@ -1892,6 +1924,7 @@ class Handle : public HandleBase {
                 if (h_near && t_near < tmax) { cur = id_near; continue; }
               } else if (!(cur & kSpecialLeaf)) {
                 uint32_t lf = cur & 0x7ffffu, ln = (cur >> 19) & kLeafCountMask;
+                if (kTtTris > 0) { if (tcount[lf]++ == 0) ttouched.push_back(lf); }
                 for (; ln; lf++, ln--) {
                   const Tri<float>& tr = tris_host_[lf];
                   const float e1[3] = {tr.p1[0] - tr.p0[0], tr.p1[1] - tr.p0[1], tr.p1[2] - tr.p0[2]}, e2[3] = {tr.p2[0] - tr.p0[0], tr.p2[1] - tr.p0[1], tr.p2[2] - tr.p0[2]};
@@ -1915,7 +1948,11 @@ class Handle : public HandleBase {
             }
           }
           PairNode* dst = &trees[(size_t)t * kTtNodes];
-          if (touched.empty()) { memcpy(dst, &trees[(size_t)n_trees * kTtNodes], kTtNodes * sizeof(PairNode)); continue; }
+          if (touched.empty()) {
+            memcpy(dst, &trees[(size_t)n_trees * kTtNodes], kTtNodes * sizeof(PairNode));
+            if (kTtTris > 0) memcpy(&packets[(size_t)t * kTtTris * 3u], &packets[(size_t)n_trees * kTtTris * 3u], (size_t)kTtTris * 3u * sizeof(float4));
+            continue;
+          }
           std::sort(touched.begin(), touched.end(), [&](uint32_t a, uint32_t b) { return counts[a] != counts[b] ? counts[a] > counts[b] : a < b; });
           sel.assign(touched.begin(), touched.begin() + std::min<size_t>(touched.size(), kTtNodes));
           if (sel.size() < kTtNodes) {   // room left: children of the chosen nodes, the most visited parents' first
@@ -1933,6 +1970,14 @@ class Handle : public HandleBase {
           }
           std::sort(sel.begin(), sel.end());
           copy_into(dst, sel, slot_of);
+          if (kTtTris > 0) {
+            uint64_t served = 0, all = 0;
+            for (uint32_t lf : ttouched) all += tcount[lf];
+            pack_tris(dst, (uint32_t)sel.size(), &packets[(size_t)t * kTtTris * 3u], tcount, &served);
+            sum_local_tests += served; sum_tests += all;
+            for (uint32_t lf : ttouched) tcount[lf] = 0;
+            ttouched.clear();
+          }
           sum_nodes += touched.size(); n_with++;
           for (uint32_t k : touched) counts[k] = 0;
         }
@@ -1956,6 +2001,11 @@ class Handle : public HandleBase {
         shifted[kFront + i] = nd;
       }
       tt_pairs_.upload(shifted, st_); tt_trees_.upload(trees, st_);
+      if (kTtTris > 0) {
+        tt_tris_.upload(packets, st_);
+        if (getenv("RRT_DEBUG")) fprintf(stderr, "[rrt] tile trees: triangle packets of %u triangles per patch, share of the census rays' leaf visits they serve: %.3f\n",
+                                         kTtTris, sum_tests ? (double)sum_local_tests / (double)sum_tests : 0.0);
+      }
       HIP_CHECK(hipStreamSynchronize(st_));
       tt_mt_x_ = mt_x; tt_n_trees_ = n_trees;
       tt_state_ = 1;
