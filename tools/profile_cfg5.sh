@@ -22,5 +22,5 @@ for set in "SQ_WAVES SQ_WAVE_CYCLES SQ_BUSY_CYCLES SQ_INSTS_VALU SQ_ACTIVE_INST_
 done
 python3 tools/pmc_traffic.py $o/pmc 512 > $o/pmc_traffic.json
 python3 tools/pmc_kernels.py $o/pmc > $o/pmc_kernels.txt
-rm -rf $o/trace1/*/*kernel_trace.csv $o/pmc/pass*/*/*agent_info.csv
+rm -rf $o/trace1 $o/pmc   # (the raw per-dispatch files of 16 passes x 16 bounces per frame exceed what gpurun copies back: the summaries above are what is kept)
 cat $o/bench.json; head -c 1500 $o/pmc_traffic.json; head -12 $o/pmc_kernels.txt | cut -c1-250
