@@ -995,7 +995,7 @@ __global__ void __launch_bounds__((shade_path_block<R, KM>())) __attribute__((am
     const V4 h = p.hit[i];
     prim = (int)real_to_bits(h.y);
     const uint32_t db = qe.db;
-    uint32_t dim = db & 0xffffu, bounces = db >> 16;
+    uint32_t dim = db_dim(s, db), bounces = db_bounce(s, db);
     // `if !found_intersection || bounces >= max_depth { break }` (:91); emitted light is 0 (Q18)
     if (prim >= 0 && (int)bounces < s.max_depth) {
       const V4 ro = p.ray_o[i], rd = p.ray_d[i];
@@ -1076,7 +1076,7 @@ __global__ void __launch_bounds__((shade_path_block<R, KM>())) __attribute__((am
           if (cont && (int)bounces < s.max_depth) {
             nx_o = si.p; nx_d = nd;
             nx_beta = beta; nx_eta_scale = eta_scale;
-            nx_db = (dim & 0xffffu) | (bounces << 16);
+            nx_db = db_pack(s, dim, bounces);
             want_next = true;
           }
         }
@@ -1126,7 +1126,7 @@ __global__ void __launch_bounds__(ShadeBlock<R>::n) k_shade_nee(SceneDev<R> s, P
         Bsdf<R> bsdf;
         build_bsdf(s, si, &bsdf, false);   // allow_multiple_lobes = false (directlighting.rs:91)
         const uint32_t db = qe.db;
-        uint32_t dim = db & 0xffffu;
+        uint32_t dim = db_dim(s, db);
         const V4 st_b = p.path[i];
         const uint32_t index = qe.index;
         Rgb<R> beta(st_b.x, st_b.y, st_b.z);
@@ -1157,7 +1157,7 @@ __global__ void __launch_bounds__(ShadeBlock<R>::n) k_shade_nee(SceneDev<R> s, P
           sh_tab = s.use_shadow_tabs ? s.lights[ln].shadow_tab : 0u;
           want_shadow = true;
         }
-        p.q_active[i].db = (dim & 0xffffu) | (db & 0xffff0000u);
+        p.q_active[i].db = db_pack(s, dim, db_bounce(s, db));
       }
     }
   }
@@ -1196,8 +1196,8 @@ __global__ void __launch_bounds__(ShadeBlock<R>::n) k_shade_specular(SceneDev<R>
     if (prim >= 0) {
       const V4 st_b = p.path[i];
       const uint32_t db = qe.db;
-      uint32_t dim = db & 0xffffu;
-      const uint32_t depth = (db >> 16) + 1;
+      uint32_t dim = db_dim(s, db);
+      const uint32_t depth = db_bounce(s, db) + 1;
       Rgb<R> beta(st_b.x, st_b.y, st_b.z);
       index = qe.index;
       if (grey_only) {  // Debug with no lights still adds the 0.1 grey
@@ -1222,7 +1222,7 @@ __global__ void __launch_bounds__(ShadeBlock<R>::n) k_shade_specular(SceneDev<R>
           if (pdf > R(0) && !f.is_black() && absdot(wi, si.sn) != R(0)) {
             nx_beta = beta * (f * absdot(wi, si.sn) / pdf);
             nx_o = si.p; nx_d = vnormalize(wi); o_lo = si.p_lo;
-            nx_db = (dim & 0xffffu) | (depth << 16);
+            nx_db = db_pack(s, dim, depth);
             want_next = true;
           }
         }
@@ -1257,7 +1257,7 @@ __global__ void __launch_bounds__(kBlock) k_direct_tree(SceneDev<R> s, Pools<R> 
   uint32_t n_closest = 0, n_any = 0;   // query counts for rrt_stats (totals[2], totals[3])
   const QEnt qe = p.q_active[i];
   const uint32_t index = qe.index;
-  uint32_t dim = qe.db & 0xffffu;
+  uint32_t dim = db_dim(s, qe.db);
   using Frame = TreeFrame<R>;
   Frame st[kTreeMax];
   auto frame = [&](int k) -> Frame& { return k < kTreeMax ? st[k] : deep[(size_t)(k - kTreeMax) * deep_stride + i]; };

@@ -337,12 +337,21 @@ RRT_DEV uint32_t st_permute(uint32_t i, uint32_t n, uint32_t p) {   // Kensler, 
   return (i + p) % n;
 }
 RRT_DEV double st_rand(uint32_t key, uint32_t i) { return (double)st_mix(key ^ st_mix(i + 0x632be5abu)) * 2.3283064365386963e-10; }   // [0, 1)
-// index word of a stratified sample: pixel (22 bits) << 10 | sample number (10 bits); d = 1D counter | 2D counter << 8
-constexpr uint32_t kErrStDims = 64u;   // ERR_ST_DIMS of dkernels.hpp: a sample ran out of the 8-bit dimension counters (device limit, not a reference panic)
+// index word of a stratified sample: pixel (22 bits) << 10 | sample number (10 bits); d = 1D counter | 2D counter << kStBits
+// A path's sampler position rides in its queue entry as one word: the dimension counter(s) in the low SceneDev::db_shift bits, the bounce (DirectLighting: depth - 1)
+// above them (db_pack). HaltonSampler: one counter below 1 000 in 16 bits, 65 535 bounces (a mirror box reaches the reference's 1 000-dimension panic at bounce ~498).
+// StratifiedSampler: two counters of kStBits each, 255 bounces. [r4] The stratified counters were 8 bits each (a sample that drew more than 255 1D or 2D dimensions - deep
+// DirectLighting / Debug trees do - was refused); now 4 095 each.
+constexpr uint32_t kStBits = 12u, kStMask = (1u << kStBits) - 1u;
+constexpr uint32_t kDbShiftHalton = 16u, kDbShiftStratified = 2u * kStBits, kDbMaxBounceStratified = (1u << (32u - kDbShiftStratified)) - 1u;
+template <typename S> RRT_DEV uint32_t db_dim(const S& s, uint32_t db) { return db & ((1u << s.db_shift) - 1u); }
+template <typename S> RRT_DEV uint32_t db_bounce(const S& s, uint32_t db) { return db >> s.db_shift; }
+template <typename S> RRT_DEV uint32_t db_pack(const S& s, uint32_t dim, uint32_t bounce) { return (dim & ((1u << s.db_shift) - 1u)) | (bounce << s.db_shift); }
+constexpr uint32_t kErrStDims = 64u;   // ERR_ST_DIMS of dkernels.hpp: a sample ran out of the 12-bit dimension counters (device limit, not a reference panic)
 template <typename R> RRT_DEV double st_get_1d(const SceneDev<R>& s, uint32_t index, uint32_t* d) {
-  const uint32_t pixel = index >> 10, sn = index & 1023u, k = *d & 0xffu;
-  if (k == 0xffu) atomicOr(s.err, kErrStDims);
-  *d = (*d & ~0xffu) | ((k + 1u) & 0xffu);
+  const uint32_t pixel = index >> 10, sn = index & 1023u, k = *d & kStMask;
+  if (k == kStMask) atomicOr(s.err, kErrStDims);
+  *d = (*d & ~kStMask) | ((k + 1u) & kStMask);
   if (k >= s.st_dims) return 2.0 * st_rand(st_key(s.st_seed_lo, s.st_seed_hi, pixel, 0x10000u + k), sn) - 1.0;
   const uint32_t spp = s.st_nx * s.st_ny, key = st_key(s.st_seed_lo, s.st_seed_hi, pixel, k);
   const uint32_t j = st_permute(sn, spp, key);
@@ -350,9 +359,9 @@ template <typename R> RRT_DEV double st_get_1d(const SceneDev<R>& s, uint32_t in
   return fmin(((double)j + delta) * (1.0 / (double)spp), 0.99999999999999989);
 }
 template <typename R> RRT_DEV void st_get_2d(const SceneDev<R>& s, uint32_t index, uint32_t* d, double* a, double* b) {
-  const uint32_t pixel = index >> 10, sn = index & 1023u, k = (*d >> 8) & 0xffu;
-  if (k == 0xffu) atomicOr(s.err, kErrStDims);
-  *d = (*d & ~0xff00u) | (((k + 1u) & 0xffu) << 8);
+  const uint32_t pixel = index >> 10, sn = index & 1023u, k = (*d >> kStBits) & kStMask;
+  if (k == kStMask) atomicOr(s.err, kErrStDims);
+  *d = (*d & ~(kStMask << kStBits)) | (((k + 1u) & kStMask) << kStBits);
   if (k >= s.st_dims) {
     const uint32_t key = st_key(s.st_seed_lo, s.st_seed_hi, pixel, 0x20000u + k);
     *a = 2.0 * st_rand(key, 2u * sn) - 1.0; *b = 2.0 * st_rand(key, 2u * sn + 1u) - 1.0;
@@ -364,7 +373,7 @@ template <typename R> RRT_DEV void st_get_2d(const SceneDev<R>& s, uint32_t inde
   *a = fmin(((double)x + jx) * (1.0 / (double)s.st_nx), 0.99999999999999989);
   *b = fmin(((double)y + jy) * (1.0 / (double)s.st_ny), 0.99999999999999989);
 }
-// ISampler::get_1d / get_2d of the scene's sampler. `d` = low 16 bits of the queue entry's counter word.
+// ISampler::get_1d / get_2d of the scene's sampler. `d` = db_dim() of the queue entry's counter word.
 template <typename R> RRT_DEV double draw_1d(const SceneDev<R>& s, uint32_t index, uint32_t* d) {
   if (s.sampler_type == 1u) return st_get_1d(s, index, d);
   const double v = halton_dim(s, index, *d);
@@ -378,11 +387,11 @@ template <typename R> RRT_DEV void draw_2d(const SceneDev<R>& s, uint32_t index,
 }
 // a 2D draw whose value is never read (u_scattering of the removed BSDF-sampling half): only the counters move
 template <typename R> RRT_DEV void skip_2d(const SceneDev<R>& s, uint32_t* d) {
-  if (s.sampler_type == 1u) { const uint32_t k = (*d >> 8) & 0xffu; if (k == 0xffu) atomicOr(s.err, kErrStDims); *d = (*d & ~0xff00u) | (((k + 1u) & 0xffu) << 8); }
+  if (s.sampler_type == 1u) { const uint32_t k = (*d >> kStBits) & kStMask; if (k == kStMask) atomicOr(s.err, kErrStDims); *d = (*d & ~(kStMask << kStBits)) | (((k + 1u) & kStMask) << kStBits); }
   else { if (*d + 1u >= 1000u) atomicOr(s.err, kErrHaltonDims); *d += 2u; }
 }
 template <typename R> RRT_DEV void skip_1d(const SceneDev<R>& s, uint32_t* d) {
-  if (s.sampler_type == 1u) { const uint32_t k = *d & 0xffu; if (k == 0xffu) atomicOr(s.err, kErrStDims); *d = (*d & ~0xffu) | ((k + 1u) & 0xffu); }
+  if (s.sampler_type == 1u) { const uint32_t k = *d & kStMask; if (k == kStMask) atomicOr(s.err, kErrStDims); *d = (*d & ~kStMask) | ((k + 1u) & kStMask); }
   else { if (*d >= 1000u) atomicOr(s.err, kErrHaltonDims); *d += 1u; }   // (the reference computes the value, so it panics here too)
 }
 template <typename R> RRT_DEV R to_real(double u) { return (R)u; }

@@ -706,7 +706,7 @@ class Handle : public HandleBase {
     HIP_CHECK(hipMemcpy(&err, counters_.p + C_ERROR, sizeof(err), hipMemcpyDeviceToHost));
     if (err & ERR_SHADING_NORMAL) throw PanicError("primitives.rs:66 assert!(dot3(&si.ist.n, &si.shading.n) >= 0.0) (vertex normals oppose the winding, Q14)");
     if (err & ERR_NO_LIGHTS) throw PanicError("directlighting.rs:91 unbounded recursion on a miss with an empty light list (Q20)");
-    if (err & ERR_ST_DIMS) throw UnsupportedError("StratifiedSampler on the device: a sample drew more than 255 1D or 2D dimensions (8-bit counters); deep DirectLighting / Debug trees do");
+    if (err & ERR_ST_DIMS) throw UnsupportedError("StratifiedSampler on the device: a sample drew more than 4095 1D or 2D dimensions (12-bit counters); very deep DirectLighting / Debug trees do");
     if (err & ERR_HALTON_DIMS) throw PanicError("samplers/halton.rs:65 HaltonSampler can only sample 1000 dimensions.");
     if (err & ERR_MIPMAP) throw PanicError("mipmap.rs:217 / memory.rs:84 index out of bounds in an ImageTexture lookup (EWA of the level past the last one: images with fewer than two pyramid levels, or a footprint >= the whole texture)");
     if (err & ERR_NULL_BSDF) throw PanicError("glass.rs:70 / translucent.rs:66 null BSDF (textures evaluate to black): path.rs:103 `bounces -= 1` underflows");
@@ -1115,11 +1115,13 @@ class Handle : public HandleBase {
       if (deep_) throw UnsupportedError("DirectLighting / Debug with transmissive materials on a BVH deeper than 64");
     }
     if (desc_.sampler.type == RRT_SAMPLER_STRATIFIED) {
-      // index word = pixel << 10 | sample number; 8-bit 1D / 2D dimension counters (<= 3 of each per bounce)
+      // index word = pixel << 10 | sample number; 12-bit 1D / 2D dimension counters (<= 3 of each per bounce; deep DirectLighting / Debug trees draw more: checked on the device)
       if (desc_.sampler.samples_per_pixel > 1024 || (uint64_t)desc_.film.xres * (uint64_t)desc_.film.yres > (1ull << 22))
         throw UnsupportedError("StratifiedSampler on the device: at most 1024 samples per pixel and 2^22 pixels");
-      if (desc_.sampler.dimension > 255 || 3 * (int64_t)desc_.integrator.max_depth + 4 > 255)
-        throw UnsupportedError("StratifiedSampler on the device: dimension counters are 8 bits");
+      if (desc_.sampler.dimension > (int64_t)kStMask || 3 * (int64_t)desc_.integrator.max_depth + 4 > (int64_t)kStMask)
+        throw UnsupportedError("StratifiedSampler on the device: dimension counters are 12 bits");
+      // under this sampler a path's bounce count rides in the 8 bits the two counters leave of its queue word (dmath.hpp db_pack)
+      if (desc_.integrator.max_depth > (int64_t)kDbMaxBounceStratified) throw UnsupportedError("StratifiedSampler on the device: max_depth above 255");
       if (desc_.sampler.xsamp < 1 || desc_.sampler.ysamp < 1) throw PanicError("stratified sampler with zero strata");
       // `dimension` 0: even the film sample is one of the rng.gen_range(-1.0..1.0) draws (samplers/mod.rs:211-226), i.e. it can leave
       // its pixel towards -x / -y; the film kernels assume p_film inside the sample's pixel
@@ -1541,7 +1543,8 @@ class Handle : public HandleBase {
     s.st_nx = (uint32_t)std::max(1, d->sampler.xsamp); s.st_ny = (uint32_t)std::max(1, d->sampler.ysamp);
     s.st_jitter = d->sampler.jitter ? 1u : 0u; s.st_dims = (uint32_t)std::max(0, d->sampler.dimension);
     s.st_seed_lo = (uint32_t)d->sampler.perm_seed; s.st_seed_hi = (uint32_t)(d->sampler.perm_seed >> 32);
-    s.cam_db = d->sampler.type == RRT_SAMPLER_STRATIFIED ? (1u | (2u << 8)) : 5u;
+    s.cam_db = d->sampler.type == RRT_SAMPLER_STRATIFIED ? (1u | (2u << kStBits)) : 5u;
+    s.db_shift = d->sampler.type == RRT_SAMPLER_STRATIFIED ? kDbShiftStratified : kDbShiftHalton;
     s.integrator = d->integrator.type; s.max_depth = d->integrator.max_depth; s.light_strategy = d->integrator.light_strategy;
     s.rr_threshold = (R)d->integrator.rr_threshold;
     counters_.alloc(C_COUNT);

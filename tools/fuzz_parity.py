@@ -155,7 +155,7 @@ for case in range(n_cases):
         film, d_err = None, str(e)
     if o_err or d_err:
         same = (o_err is not None) == (d_err is not None)
-        limit = o_err is None and "more than 255" in str(d_err)    # documented device limit (8-bit stratified dimension counters): refused, never approximated
+        limit = o_err is None and "more than 4095" in str(d_err)    # documented device limit (12-bit stratified dimension counters): refused, never approximated
         print(("ok-both-refuse " if same else "ok-device-limit " if limit else "MISMATCH-REFUSAL ") + tag + f" oracle={str(o_err)[:80]} device={str(d_err)[:80]}")
         continue
     scale = max(np.abs(ref[..., :3]).max(), 1e-300)
