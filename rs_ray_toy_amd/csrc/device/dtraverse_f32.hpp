@@ -1018,11 +1018,54 @@ RRT_DEV bool walk_any_private_f32(const TravScene& ts, LaneRay& r) {
 #ifndef RRT_SL_BLOCK
 #define RRT_SL_BLOCK 256
 #endif
+#ifndef RRT_SL_MERGE
+#define RRT_SL_MERGE 1
+#endif
+#ifndef RRT_SL_SORT
+#define RRT_SL_SORT 0   // measured and off: see the kernel
+#endif
 constexpr int kSlBlock = RRT_SL_BLOCK;
 static __global__ void __launch_bounds__(kSlBlock) k_shadow_lists_f32(TravScene ts, ShadowLists sl, Pools<float> p, const uint32_t* count) {
   const uint32_t n = *count;
+#if RRT_SL_SORT
+  // MEASURED AND OFF (round 4). A wave lasts as long as its longest list (0 .. 48 candidates, 11.5 on average on config 4), so this variant deals the workgroup's
+  // kSlBlock consecutive rays to its waves BY LIST LENGTH - a counting sort of the ray indices over the list length through LDS (rays without a list sort behind every
+  // list). Same verdicts (the list tests pass with it on); any-hit alone 3.12 -> 3.47 ms at 256 threads, 3.9 ms at 512 / 1 024: neighbouring lanes no longer serve
+  // neighbouring rays, whose candidate lists and leaf records are mostly the same lines - the coherence the queue order gives is worth more than even list lengths.
+  __shared__ uint32_t s_bin[64], s_order[kSlBlock];
+  const uint32_t tid = threadIdx.x;
+  for (uint32_t base = blockIdx.x * blockDim.x; base < n; base += gridDim.x * blockDim.x) {   // (block-uniform trip count: barriers inside)
+    const uint32_t i0 = base + tid;
+    uint32_t key = 63u;   // no ray
+    if (i0 < n) {
+      const uint32_t sw0 = __float_as_uint(p.sray_d[i0].w);
+      const uint32_t sk0 = sw0 & ((1u << kShadowTabShift) - 1u), tab0 = (int32_t)sw0 >= 0 ? (sw0 >> kShadowTabShift) & 15u : 0u;
+      uint32_t h0 = 0xffu;
+      if (tab0 != 0u && tab0 <= sl.n_tables && sk0 < sl.n_tris) h0 = sl.headers[(size_t)(tab0 - 1u) * sl.n_tris + sk0];
+      key = (h0 & 0xffu) == 0xffu ? 62u : min(h0 & 0xffu, 61u);
+    }
+    if (tid < 64u) s_bin[tid] = 0u;
+    __syncthreads();
+    const uint32_t in_bin = atomicAdd(&s_bin[key], 1u);
+    __syncthreads();
+    if (tid < 64u) {   // exclusive prefix over the 64 bins, one wave
+      const uint32_t v = s_bin[tid];
+      uint32_t incl = v;
+#pragma unroll
+      for (int d = 1; d < 64; d <<= 1) { const uint32_t up = __shfl_up(incl, d); if ((int)tid >= d) incl += up; }
+      s_bin[tid] = incl - v;
+    }
+    __syncthreads();
+    s_order[s_bin[key] + in_bin] = i0;
+    __syncthreads();
+    const uint32_t i = s_order[tid];
+    __syncthreads();   // (s_bin / s_order are rewritten by the next trip)
+    if (i >= n) continue;
+    const float4 ro = p.sray_o[i], rd = p.sray_d[i];
+#else
   for (uint32_t i = blockIdx.x * blockDim.x + threadIdx.x; i < n; i += gridDim.x * blockDim.x) {
     const float4 ro = p.sray_o[i], rd = p.sray_d[i];
+#endif
     LaneRay r;
     V3<float> lo;
     ray_tail(ro, kShadowTmax, &r.tmax, &lo);
@@ -1056,6 +1099,30 @@ static __global__ void __launch_bounds__(kSlBlock) k_shadow_lists_f32(TravScene 
           const float4* lp = reinterpret_cast<const float4*>(sl.leaves + (id[j] != 0xffffffffu ? id[j] : 0u));
           a[j] = lp[0]; b[j] = lp[1];   // {bmin.xyz, word}, {bmax.xyz, -}
         }
+#if RRT_SL_MERGE
+        // All U box tests first, then the leaves that passed, ONE PER LANE AND STEP: with `if (box j passes) test leaf j` per candidate slot every slot's triangle
+        // tests ran as their own divergent block - U of them per round, each with the few lanes whose j-th candidate passed (a sixth of the candidates pass on
+        // config 4: some lane of 64 nearly always does) - where max over the lanes of the number of passing boxes, mostly 1 or 2, steps do. Same boxes, same
+        // leaves, same triangle tests per ray (an occlusion query does not depend on their order; a lane still stops at its first hit).
+        uint32_t pass = 0u;
+#pragma unroll
+        for (int j = 0; j < U; j++) {
+          float tmin;
+          const bool ok = id[j] != 0xffffffffu && box_slabs_f32(a[j].x, a[j].y, a[j].z, b[j].x, b[j].y, b[j].z, r, &tmin) && tmin < r.tmax;
+          pass |= ok ? (1u << j) : 0u;
+        }
+        while (__ballot(pass != 0u) != 0ull) {
+          if (pass != 0u) {
+            const uint32_t j = (uint32_t)__ffs((int)pass) - 1u;
+            uint32_t word = __float_as_uint(a[0].w);
+#pragma unroll
+            for (int q = 1; q < U; q++) word = j == (uint32_t)q ? __float_as_uint(a[q].w) : word;
+            int hit; float hu, hv;
+            found = leaf_step_f32<true, false>(ts, word, r, &hit, &hu, &hv);
+            pass = found ? 0u : (pass & (pass - 1u));
+          }
+        }
+#else
 #pragma unroll
         for (int j = 0; j < U; j++) {
           float tmin;
@@ -1064,6 +1131,7 @@ static __global__ void __launch_bounds__(kSlBlock) k_shadow_lists_f32(TravScene 
             found = leaf_step_f32<true, false>(ts, __float_as_uint(a[j].w), r, &hit, &hu, &hv);
           }
         }
+#endif
       }
     }
     if (!found) add_pending(p, i);
