@@ -948,6 +948,9 @@ RRT_DEV uint32_t sample_light_discrete(const SceneDev<R>& s, R u) {
 // PathIntegrator::li loop body (path.rs:74-223) for one bounce of every active path.
 // occupancy target of the path shading kernel: asking for 4 waves per SIMD lets the register allocator use the full
 // 128-VGPR budget of that occupancy (measured: 8.9 ms against 9.9 ms without the hint; 5 or 6 waves spill: 10.6 / 13.2 ms)
+#ifndef RRT_SHADE_CHUNK
+#define RRT_SHADE_CHUNK 4u   // queue entries per workgroup and trip of the hit compaction, in workgroup sizes (measured: 2 / 4 / 8 - see DESIGN.md)
+#endif
 #ifndef RRT_SHADE_WAVES
 #define RRT_SHADE_WAVES 4
 #endif
@@ -976,12 +979,34 @@ template <uint32_t KM> constexpr int shade_path_waves() { return KM == kKindsLam
 template <typename R, int NL, bool TEX = false, uint32_t KM = kAllKinds, bool AREA = true>
 __global__ void __launch_bounds__((shade_path_block<R, KM>())) __attribute__((amdgpu_waves_per_eu(TEX ? 1 : shade_path_waves<KM>(), 8))) k_shade_path(SceneDev<R> s, Pools<R> p) {
   __shared__ uint32_t push_lds[shade_path_block<R, KM>() / 64 + 1];
+  // [r4] Hit compaction (option "shade_compact"). More than half of a queue's rays MISS on an open scene (config 4: 104 M queued closest-hit rays, ~47 M hits per
+  // frame), and the path integrator shades a miss with nothing (Q18) - with one thread per queue entry half of every wave sat idle through the whole kernel. A
+  // workgroup now takes kShadeChunk x its size consecutive entries, reads their hit words, packs the indices of the hits into LDS in queue order (block_rank) and
+  // shades those with full waves. The next / shadow queues receive the same entries in the same order inside a workgroup's chunk; every sample adds to its own slot:
+  // frames are identical bit for bit (tests/test_gpu_parity.py::test_shade_compaction_changes_nothing).
+  constexpr uint32_t kShadeChunk = RRT_SHADE_CHUNK;
+  __shared__ uint32_t hit_idx[kShadeChunk * shade_path_block<R, KM>()];
   const uint32_t n = p.counters[C_ACTIVE];
   using V4 = typename Vec4T<R>::type;
-  // a bounded grid walks the queue (block-uniform trip count, as block_push needs): the host does not know the queue
+  const uint32_t chunk = s.shade_compact ? kShadeChunk : 1u;
+  // a bounded grid walks the queue (block-uniform trip counts, as block_push needs): the host does not know the queue
   // size, and a grid sized for the whole pass costs 0.2 ms of empty blocks per launch once the queues are short
-  for (uint32_t base = blockIdx.x * blockDim.x; base < n; base += gridDim.x * blockDim.x) {
-  const uint32_t i = base + threadIdx.x;
+  for (uint32_t base0 = blockIdx.x * blockDim.x * chunk; base0 < n; base0 += gridDim.x * blockDim.x * chunk) {
+  uint32_t n_hits = min(blockDim.x, n - base0);   // (no compaction: the entries themselves)
+  if (chunk > 1u) {
+    n_hits = 0u;
+    for (uint32_t k = 0; k < chunk; k++) {
+      const uint32_t e = base0 + k * blockDim.x + threadIdx.x;
+      const bool is_hit = e < n && (int)real_to_bits(p.hit[e].y) >= 0;
+      uint32_t cnt = 0;
+      const uint32_t at = block_rank(is_hit, push_lds, &cnt);
+      if (is_hit) hit_idx[n_hits + at] = e;
+      n_hits += cnt;
+    }
+    __syncthreads();
+  }
+  for (uint32_t base = 0; base < n_hits; base += blockDim.x) {
+  const uint32_t i = base + threadIdx.x < n_hits ? (chunk > 1u ? hit_idx[base + threadIdx.x] : base0 + base + threadIdx.x) : n;   // n: no entry for this thread
   bool want_shadow = false, want_next = false;
   uint32_t slot = 0;
   int prim = -1;
@@ -1094,6 +1119,8 @@ __global__ void __launch_bounds__((shade_path_block<R, KM>())) __attribute__((am
     p.npath[qn] = mk4<R>(nx_beta.r, nx_beta.g, nx_beta.b, nx_eta_scale);
     store_ray<R>(p.nray_o, p.nray_d, qn, nx_o, o_lo, nx_d, Const<R>::inf, self_prim<R>(prim));
   }
+  }  // the chunk's hits
+  __syncthreads();   // hit_idx is rewritten by the next chunk
   }  // queue walk
 }
 

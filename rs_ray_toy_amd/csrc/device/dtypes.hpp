@@ -182,6 +182,7 @@ struct SceneDev {
   uint32_t sampler_type;       // RRT_SAMPLER_*
   uint32_t st_nx, st_ny, st_jitter, st_dims, st_seed_lo, st_seed_hi;
   uint32_t cam_db;             // dimension-counter word after the camera sample (Halton: 5; stratified: one 1D, two 2D)
+  uint32_t shade_compact;      // k_shade_path packs the hits of a chunk of queue entries before shading them (option "shade_compact")
   uint32_t db_shift;           // a path's queue word = dimension counter(s) | bounce << db_shift: 16 under the HaltonSampler (one counter below 1 000, 65 535 bounces), 24 under the StratifiedSampler (two 12-bit counters, 255 bounces); dmath.hpp db_pack
   // camera lens dimensions 2 and 3 (bases 5 and 7): digit permutation packed 3 bits per digit, and the
   // reference's running product inv_base^k (lowdiscrepancy.rs:204-227) tabulated by the same f64 multiplications

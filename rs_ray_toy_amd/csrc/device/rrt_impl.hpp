@@ -569,6 +569,7 @@ class Handle : public HandleBase {
     else if (key == "tile_order") tile_order_ = v != 0;
     else if (key == "tile_trees") tile_trees_on_ = v != 0;
     else if (key == "quad_nodes") quad_on_ = v != 0;
+    else if (key == "shade_compact") scene_.shade_compact = v != 0 ? 1u : 0u;
     else if (key == "root_cull") root_cull_on_ = v != 0;
     else if (key == "tt_census") { tt_census_spp_ = std::max(1, (int)v); tt_state_ = 0; }
     else if (key == "shadow_lists") shadow_lists_on_ = v != 0;
@@ -1545,6 +1546,7 @@ class Handle : public HandleBase {
     s.st_seed_lo = (uint32_t)d->sampler.perm_seed; s.st_seed_hi = (uint32_t)(d->sampler.perm_seed >> 32);
     s.cam_db = d->sampler.type == RRT_SAMPLER_STRATIFIED ? (1u | (2u << kStBits)) : 5u;
     s.db_shift = d->sampler.type == RRT_SAMPLER_STRATIFIED ? kDbShiftStratified : kDbShiftHalton;
+    s.shade_compact = 1u;
     s.integrator = d->integrator.type; s.max_depth = d->integrator.max_depth; s.light_strategy = d->integrator.light_strategy;
     s.rr_threshold = (R)d->integrator.rr_threshold;
     counters_.alloc(C_COUNT);

@@ -735,6 +735,35 @@ def test_quad_nodes_change_nothing(which, workdir):
         assert np.array_equal(hits[1][k], hits[0][k]), k
 
 
+@pytest.mark.parametrize("which", ["cfg4", "cfg4_passes", "cfg2_f64", "cfg5", "cfg4_textured_translucent"])
+def test_shade_compaction_changes_nothing(which, workdir):
+    """k_shade_path packs the HITS of a chunk of queue entries (4 x the workgroup's size) into LDS before shading them (option "shade_compact"): on an
+    open scene more than half of a queue's rays miss, the path integrator shades a miss with nothing (Q18), and one thread per queue entry left half of every
+    wave idle. The hits keep their queue order inside a chunk and every sample adds to its own slot, so frames, weights and query counts are identical bit for
+    bit with and without - also over several pool passes, in the f64 mode, with glossy materials and area lights, and in the general kernel."""
+    prec = RRT_F32
+    if which == "cfg2_f64":
+        cfg, root = scenes.cfg2(workdir, xres=96, yres=96, nsamp=9, max_depth=4); prec = RRT_F64
+    elif which == "cfg5":
+        cfg, root = scenes.cfg5(workdir, xres=96, yres=96, nsamp=9, max_depth=6, n=64)
+    else:
+        cfg, root = scenes.cfg4(workdir, xres=128, yres=96, nsamp=9, max_depth=5, n=64)
+    if which == "cfg4_textured_translucent":
+        _with_material(cfg, "tl", ("TranslucentMaterial", {"kd": [0.4, 0.5, 0.6], "ks": [0.2, 0.2, 0.2], "reflect": [0.7, 0.7, 0.7], "transmit": [0.5, 0.5, 0.5]}, {"roughness": 0.2}, {}))
+        cfg["Aggregate"]["primitives"][0]["material_name"] = "tl"
+    sc = Scene.loads(cfg, root, flags=RRT_FIXED_BVH)
+    r = Renderer(sc, 0, prec)
+    if which == "cfg4_passes": r.set_option("max_paths", 128 * 96 * 3)
+    out = {}
+    for c in (1, 0):
+        r.set_option("shade_compact", c)
+        out[c] = r.render(stats=True)
+    r.close()
+    assert out[1][0][..., :3].max() > 0
+    assert np.array_equal(out[1][0], out[0][0])
+    assert (out[1][1].camera_rays, out[1][1].closest_queries, out[1][1].any_queries) == (out[0][1].camera_rays, out[0][1].closest_queries, out[0][1].any_queries)
+
+
 @pytest.mark.parametrize("which", ["cfg4", "cfg4_stage_b", "cfg4_bands", "cfg2", "cfg4_direct"])
 def test_root_cull_changes_nothing(which, workdir):
     """The fp32 path integrator's camera kernels answer a camera ray that misses the BVH's root box themselves - with the traversal kernels' own
