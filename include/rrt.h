@@ -437,6 +437,8 @@ int rrt_film_gather_all(rrt_handle* const* handles, void* const* films_device, i
  *                                 every lens interface by the calibrated margin                                  auxiliary-ray displacement measured at scene load (16 384 host
  *                                                                                                                samples of the scene's own lens); validated bit for bit against
  *                                                                                                                the full traces (test_aux_margins_change_nothing)
+ * shade_compact         1         path shading kernel packs the HITS of a chunk of queue entries through LDS       invariant (test_shade_compaction_changes_nothing)
+ *                                 before shading them (a miss is shaded with nothing)
  * shade_spec            1  fp32   path shading kernel instantiated for the lobe kinds the scene's materials      same arithmetic per lobe: frames equal to fp32 rounding,
  *                                 can produce; 0: always the general kernel                                      weights and counts identical (test_shading_kernel_specialisation)
  */

@@ -1098,6 +1098,9 @@ __global__ void __launch_bounds__((shade_path_block<R, KM>())) __attribute__((am
           bounces += 1;
           // the next loop iteration would trace and then break on `bounces >= max_depth` without using the
           // hit (emission is 0): that dead closest-hit query is not issued.
+#ifdef RRT_SKY_HACK   // premise experiment only (NOT exact): what the closest-hit launches would cost without the bounce rays that leave steeply upward
+          if (nd.y > R(RRT_SKY_HACK)) cont = false;
+#endif
           if (cont && (int)bounces < s.max_depth) {
             nx_o = si.p; nx_d = nd;
             nx_beta = beta; nx_eta_scale = eta_scale;
