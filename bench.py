@@ -159,7 +159,9 @@ def main():
     t_build = time.time() - t0
     W, H = scene.resolution
     nfl = args.frames_in_flight or (2 if world == 1 else 4)
+    t0 = time.time()
     handles = [Renderer(scene, local_rank, RRT_F32) for _ in range(nfl)]
+    t_handles = time.time() - t0      # upload + the device-side tables (pair nodes, tile trees on first use, shadow lists, horizon tables)
     for h in handles:
         if args.max_paths:
             h.set_option("max_paths", args.max_paths)
@@ -282,9 +284,9 @@ def main():
 
     stat_dev = "cpu" if args.dist_backend == "gloo" else f"cuda:{local_rank}"
     tt = torch.tensor([elapsed], dtype=torch.float64, device=stat_dev)
-    keys = ["camera_samples", "camera_rays", "closest_queries", "any_queries", "closest_nodes", "closest_prims", "any_nodes", "any_prims", "closest_launches", "root_culled"]
+    keys = ["camera_samples", "camera_rays", "closest_queries", "any_queries", "closest_nodes", "closest_prims", "any_nodes", "any_prims", "closest_launches", "root_culled", "sky_culled"]
     counted["closest_launches"] = timed["closest_launches"]
-    counted["root_culled"] = timed["root_culled"]   # (the counting frame keeps every query in the queue)
+    counted["root_culled"] = timed["root_culled"]   # (the counting frame keeps every camera ray in the queue; the horizon cull - geometry, not a kernel's test - applies to it too)
     cnt = torch.tensor([float(counted[k]) for k in keys] + [timed["ms_closest"], timed["ms_any"], timed["ms_shade"], timed["ms_raygen"], timed["ms_film"], timed["ms_total"], isolated["ms_closest"],
                                                             single["ms_closest"], single["ms_any"], single["ms_shade"], single["ms_raygen"], single["ms_film"], single["ms_total"],
                                                             timed["ms_gather"]],
@@ -314,8 +316,9 @@ def main():
         # one-frame-at-a-time pass above (shadow launches beside them on the second stream, as in the product): what rocprofv3's kernel trace
         # of `bench.py --frames-in-flight 1` shows per dispatch (profiles/). `as_ran` = the same events inside the timed region.
         n_launch = max(1.0, tot["closest_launches"])
-        # camera rays that miss the root box are answered by the camera kernel (option "root_cull"): queries, but no records through the traversal launches
-        in_queue = tot["closest_queries"] - tot["root_culled"]
+        # camera rays that miss the root box are answered by the camera kernel (option "root_cull"), bounce rays that provably leave the scene by the shading kernel's
+        # horizon tables (option "horizon_cull"): queries, but no records through the traversal launches
+        in_queue = tot["closest_queries"] - tot["root_culled"] - tot["sky_culled"]
         bytes_closest = in_queue * 44.0 + 32.0 * tot["closest_nodes"] + 48.0 * tot["closest_prims"]
         ms_closest = mx_tot["ms1_closest"]   # per frame; ranks run concurrently: the slowest rank's sum
         launch_s = ms_closest * 1e-3 / (n_launch / world) if ms_closest > 0 else float("inf")
@@ -423,7 +426,7 @@ def main():
             "roofline": roofline, "cpu_baseline": cpu,
             "camera_mrays_per_s": round(tot["camera_rays"] / (ms_per_step * 1e-3) / 1e6, 3),
             "camera_samples": int(tot["camera_samples"]), "camera_rays": int(tot["camera_rays"]),
-            "closest_queries": int(tot["closest_queries"]), "root_culled": int(tot["root_culled"]), "any_queries": int(tot["any_queries"]),
+            "closest_queries": int(tot["closest_queries"]), "root_culled": int(tot["root_culled"]), "sky_culled": int(tot["sky_culled"]), "any_queries": int(tot["any_queries"]),
             "any_nodes_per_query": round(tot["any_nodes"] / max(1.0, tot["any_queries"]), 2), "any_tris_per_query": round(tot["any_prims"] / max(1.0, tot["any_queries"]), 2),
             "kernel_ms_per_frame": {k: round(mx_tot[k], 3) for k in ("ms_raygen", "ms_closest", "ms_any", "ms_shade", "ms_film", "ms_total")},
             "kernel_ms_per_frame_one_at_a_time": {k.replace("ms1_", "ms_"): round(mx_tot[k], 3) for k in ("ms1_raygen", "ms1_closest", "ms1_any", "ms1_shade", "ms1_film", "ms1_total")},
@@ -432,7 +435,10 @@ def main():
             # run can tell render imbalance between the ranks (max - min of ms_total) from the time the collective takes (0 with one rank / the gloo rehearsal)
             "ranks": {"ms_total": {"max": round(mx_tot["ms_total"], 3), "min": round(mn_tot["ms_total"], 3)},
                       "ms_gather": {"max": round(mx_tot["ms_gather"], 3), "min": round(mn_tot["ms_gather"], 3)}},
-            "host_scene_build_s": round(t_build, 3),
+            # bounce rays answered by the horizon tables and camera rays answered by the root-box test are queries of the reference (BVHAccel::intersect calls that
+            # return false) and count in `value`; the rate of the queries that went through a traversal launch is given beside it
+            "traversed_mrays_per_s": round((queries - tot["root_culled"] - tot["sky_culled"]) / (ms_per_step * 1e-3) / 1e6, 3),
+            "host_scene_build_s": round(t_build, 3), "handles_create_s": round(t_handles, 3), "horizon_tables_build_s": round(counted["s_horizon_build"], 3),
         }
         print(json.dumps(out))
     if comm is not None:

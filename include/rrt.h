@@ -298,10 +298,13 @@ typedef struct rrt_render_stats {
   uint64_t any_nodes, any_prims;          /* algorithmic-byte model needs the closest-hit kernel's own counts */
   uint64_t tile_launches;       /* closest-hit launches over camera rays issued with the per-patch sub-trees ("tile_trees" option) */
   uint64_t root_culled;         /* closest_queries answered by the camera kernels: camera rays that miss the root box ("root_cull" option) */
+  uint64_t sky_culled;          /* closest_queries answered by the horizon tables: bounce rays the path shading kernel proves to leave the scene ("horizon_cull" option) */
   uint64_t list_launches;       /* any-hit launches served by the shadow candidate lists ("shadow_lists" option) instead of the tree walk */
   double ms_gather;             /* the collective rrt_film_gather / _gather_all enqueued behind a frame in flight (HIP events on the handle's stream around
                                  * the grouped send / recv or the reduce): lets a multi-GPU run separate the ranks' render imbalance (ms_total) from the
                                  * collective (film.rs:248-263 merge_film_tile is what it replaces); 0 when no collective followed the frame */
+  double s_horizon_build;       /* host seconds rrt_create spent building this handle's horizon tables (a setup cost, like the BVH build; 0 when another handle
+                                 * of the process had built them for the same geometry, or the scene gets none) */
 } rrt_render_stats;
 
 /* ---- host side: scene build (stays on the host in the north_star) -------- */
@@ -437,6 +440,12 @@ int rrt_film_gather_all(rrt_handle* const* handles, void* const* films_device, i
  *                                 every lens interface by the calibrated margin                                  auxiliary-ray displacement measured at scene load (16 384 host
  *                                                                                                                samples of the scene's own lens); validated bit for bit against
  *                                                                                                                the full traces (test_aux_margins_change_nothing)
+ * horizon_cull          1  fp32   path integrator: a bounce ray whose elevation exceeds everything visible from  invariant (test_horizon_cull_changes_nothing);
+ *                                 its start triangle in its azimuth sector (host-built tables) is answered as    counted in closest_queries and sky_culled
+ *                                 the miss it is, never queued. The tables are built by rrt_create (host, all
+ *                                 cores; ~5 s for 100k triangles, once per geometry and process:
+ *                                 rrt_render_stats::s_horizon_build); RRT_HORIZON_TABLES=0 in the environment
+ *                                 builds none
  * shade_compact         1         path shading kernel packs the HITS of a chunk of queue entries through LDS       invariant (test_shade_compaction_changes_nothing)
  *                                 before shading them (a miss is shaded with nothing)
  * shade_spec            1  fp32   path shading kernel instantiated for the lobe kinds the scene's materials      same arithmetic per lobe: frames equal to fp32 rounding,

@@ -150,7 +150,7 @@ class RenderStats(C.Structure):
                 ("ms_any", C.c_double), ("ms_shade", C.c_double), ("ms_film", C.c_double),
                 ("closest_launches", C.c_uint64), ("any_launches", C.c_uint64),
                 ("closest_nodes", C.c_uint64), ("closest_prims", C.c_uint64), ("any_nodes", C.c_uint64),
-                ("any_prims", C.c_uint64), ("tile_launches", C.c_uint64), ("root_culled", C.c_uint64), ("list_launches", C.c_uint64), ("ms_gather", C.c_double)]
+                ("any_prims", C.c_uint64), ("tile_launches", C.c_uint64), ("root_culled", C.c_uint64), ("sky_culled", C.c_uint64), ("list_launches", C.c_uint64), ("ms_gather", C.c_double), ("s_horizon_build", C.c_double)]
 
 
 # every symbol include/rrt.h declares (tests/test_abi.py checks the library exports all of them)

@@ -15,7 +15,9 @@ enum { C_ACTIVE = 0, C_NEXT = 32, C_SHADOW = 64, C_CAMERA_RAYS = 96, C_ERROR = 1
        // queue entries [0, C_TT_DONE) came from the camera workgroups in whole chunks (k_raygen_main_f32's chunk records), the rest from stage B
        C_TT_DONE = 800,
        // camera rays answered by the camera kernels (SceneDev::root_cull): closest-hit queries that never entered a queue
-       C_CULLED = 832, C_COUNT = 864 };
+       C_CULLED = 832,
+       // bounce rays the path shading kernel proves to leave the scene (SceneDev::horizon): closest-hit queries that never entered a queue
+       C_SKY = 864, C_COUNT = 896 };
 // shading kernels push to their queues once per block (measured: 256 <= 512 <= 1024 threads by 5 %: smaller blocks retire
 // and refill a CU sooner, and one atomic per 256 paths no longer serialises)
 template <typename R> struct ShadeBlock { static constexpr int n = 256; };
@@ -1007,7 +1009,7 @@ __global__ void __launch_bounds__((shade_path_block<R, KM>())) __attribute__((am
   }
   for (uint32_t base = 0; base < n_hits; base += blockDim.x) {
   const uint32_t i = base + threadIdx.x < n_hits ? (chunk > 1u ? hit_idx[base + threadIdx.x] : base0 + base + threadIdx.x) : n;   // n: no entry for this thread
-  bool want_shadow = false, want_next = false;
+  bool want_shadow = false, want_next = false, sky = false;
   uint32_t slot = 0;
   int prim = -1;
   V3<R> sh_o, sh_d, nx_o, nx_d, o_lo;   // shadow ray / next ray + path state, stored at their queue positions at the end
@@ -1101,6 +1103,15 @@ __global__ void __launch_bounds__((shade_path_block<R, KM>())) __attribute__((am
 #ifdef RRT_SKY_HACK   // premise experiment only (NOT exact): what the closest-hit launches would cost without the bounce rays that leave steeply upward
           if (nd.y > R(RRT_SKY_HACK)) cont = false;
 #endif
+          // Horizon cull (SceneDev::horizon, rrt_impl.hpp build_horizons()): the next ray starts on triangle `prim`; if its elevation above / below the scene's
+          // flattest axis exceeds everything the host found visible from ANY point of that triangle in the ray's azimuth sector, BVHAccel::intersect would
+          // return false for it and the path would end at `if !found_intersection { break }` (path.rs:91) - it is counted as the closest-hit query it is, and not traced.
+          if (cont && (int)bounces < s.max_depth && s.horizon != nullptr) {
+            const float u = s.hz_axis == 0u ? (float)nd.x : (s.hz_axis == 1u ? (float)nd.y : (float)nd.z);
+            const float a = s.hz_axis == 0u ? (float)nd.y : (s.hz_axis == 1u ? (float)nd.z : (float)nd.x), b = s.hz_axis == 0u ? (float)nd.z : (s.hz_axis == 1u ? (float)nd.x : (float)nd.y);
+            const uint32_t q = s.horizon[(size_t)prim * 32u + (u < 0.0f ? 16u : 0u) + hz_sector(a, b)];
+            if (fabsf(u) * 254.0f > (float)q) { cont = false; sky = true; }
+          }
           if (cont && (int)bounces < s.max_depth) {
             nx_o = si.p; nx_d = nd;
             nx_beta = beta; nx_eta_scale = eta_scale;
@@ -1122,6 +1133,7 @@ __global__ void __launch_bounds__((shade_path_block<R, KM>())) __attribute__((am
     p.npath[qn] = mk4<R>(nx_beta.r, nx_beta.g, nx_beta.b, nx_eta_scale);
     store_ray<R>(p.nray_o, p.nray_d, qn, nx_o, o_lo, nx_d, Const<R>::inf, self_prim<R>(prim));
   }
+  if (s.horizon != nullptr) (void)block_push(&p.counters[C_SKY], sky, push_lds);   // (block-uniform condition)
   }  // the chunk's hits
   __syncthreads();   // hit_idx is rewritten by the next chunk
   }  // queue walk
@@ -1430,6 +1442,8 @@ static __global__ void k_accumulate_counts(uint32_t* c, unsigned long long* tota
   totals[2] += c[C_ACTIVE];
 }
 static __global__ void k_accumulate_shadow(const uint32_t* shadow_count, unsigned long long* totals) { totals[3] += *shadow_count; }
+// bounce rays answered by the horizon tables in the shading launch just finished: queries all the same (totals[8] says how many)
+static __global__ void k_accumulate_sky(uint32_t* c, unsigned long long* totals) { totals[2] += c[C_SKY]; totals[8] += c[C_SKY]; c[C_SKY] = 0; }
 static __global__ void k_accumulate_camera(uint32_t* c, unsigned long long* totals) {
   totals[4] += c[C_CAMERA_RAYS]; c[C_CAMERA_RAYS] = 0;
   totals[2] += c[C_CULLED]; totals[7] += c[C_CULLED]; c[C_CULLED] = 0;   // queries all the same: answered by the root-box test in the camera kernel

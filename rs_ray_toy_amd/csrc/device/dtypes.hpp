@@ -6,8 +6,8 @@
 #include <hip/hip_runtime.h>
 #include <stdint.h>
 
+#include "horizon_build.hpp"   // hz_sector(): shared with the host builder
 namespace rrtd {
-
 // LinearBVHNode bvh.rs:103-109, narrowed: f32 = 32 B (bounds rounded outward from the f64 build), f64 = 64 B.
 // Block tables of a sampler dimension's digit loop (fp32 mode): the sample index is split as hi * block + lo, block = base^low_digits;
 // lo[lo_off + lo] = the permuted reversal of exactly low_digits digits, hi[hi_off + hi] = {permuted reversal of hi's digits, base^(digits of hi),
@@ -156,6 +156,10 @@ struct SceneDev {
   // fp32 path integrator: the camera kernels answer a camera ray that misses the root box themselves (the test lane_ray_begin() makes, on the ray as stored:
   // such a ray is a miss, which the path integrator shades with nothing) instead of sending it through the queue - see camera_ray_meets_root()
   uint32_t root_cull;
+  // horizon tables (fp32 path integrator, rrt_impl.hpp build_horizons()): per triangle 2 x 16 bytes - hemisphere +hz_axis / -hz_axis, 16 azimuth sectors (hz_sector) -
+  // holding ceil(254 x sin(max elevation at which anything is visible from any point of the triangle in that sector)) + margin; null = off
+  const uint8_t* horizon;
+  uint32_t hz_axis;
   float root_box[6];
   // camera
   const LensElem<R>* lens;

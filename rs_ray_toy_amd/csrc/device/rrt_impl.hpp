@@ -8,6 +8,8 @@
 #include <cmath>
 #include <cstdio>
 #include <cstring>
+#include <deque>
+#include <mutex>
 #include <memory>
 #include <queue>
 #include <stdexcept>
@@ -428,6 +430,27 @@ inline ShadowListsHost build_shadow_lists(const std::vector<Node<float>>& nodes,
   return out;
 }
 
+// Horizon tables (host/horizon_build.cpp) are a function of the fp32 geometry alone, and a process usually opens several handles on one scene (an fp32 and an f64
+// one, one per stream, a bench's second configuration): the last few results are kept, keyed by the CONTENT of the builder's input (never by address).
+inline std::shared_ptr<const HzTables> horizons_cached(const std::vector<HzNode>& hn, const std::vector<HzTri>& ht, long check_rays, bool* was_cached) {
+  struct Entry { uint64_t key[2]; size_t n_nodes, n_tris; std::shared_ptr<const HzTables> tab; };
+  static std::mutex mu;
+  static std::deque<Entry> kept;
+  auto hash = [](const void* p, size_t n, uint64_t h) { const unsigned char* b = (const unsigned char*)p; for (size_t i = 0; i < n; i++) { h ^= b[i]; h *= 0x100000001b3ull; } return h; };
+  const uint64_t k0 = hash(ht.data(), ht.size() * sizeof(HzTri), hash(hn.data(), hn.size() * sizeof(HzNode), 0xcbf29ce484222325ull));
+  const uint64_t k1 = hash(hn.data(), hn.size() * sizeof(HzNode), hash(ht.data(), ht.size() * sizeof(HzTri), 0x9e3779b97f4a7c15ull));
+  *was_cached = false;
+  if (check_rays <= 0) {   // (a self-check wants the build to happen)
+    std::lock_guard<std::mutex> lk(mu);
+    for (const Entry& e : kept) if (e.key[0] == k0 && e.key[1] == k1 && e.n_nodes == hn.size() && e.n_tris == ht.size()) { *was_cached = true; return e.tab; }
+  }
+  auto tab = std::make_shared<const HzTables>(build_horizons(hn.data(), hn.size(), ht.data(), ht.size(), check_rays));
+  std::lock_guard<std::mutex> lk(mu);
+  kept.push_back(Entry{{k0, k1}, hn.size(), ht.size(), tab});
+  while (kept.size() > 4u) kept.pop_front();
+  return tab;
+}
+
 // A desc normally comes from rrt_scene_load, but the ABI lets a caller fill one: every index the kernels follow is checked here once
 // (a kernel reading past an array can take the GPU down for everybody on the host)
 inline void validate_desc(const rrt_scene_desc* d) {
@@ -570,6 +593,7 @@ class Handle : public HandleBase {
     else if (key == "tile_trees") tile_trees_on_ = v != 0;
     else if (key == "quad_nodes") quad_on_ = v != 0;
     else if (key == "shade_compact") scene_.shade_compact = v != 0 ? 1u : 0u;
+    else if (key == "horizon_cull") horizon_on_ = v != 0;
     else if (key == "root_cull") root_cull_on_ = v != 0;
     else if (key == "tt_census") { tt_census_spp_ = std::max(1, (int)v); tt_state_ = 0; }
     else if (key == "shadow_lists") shadow_lists_on_ = v != 0;
@@ -744,8 +768,8 @@ class Handle : public HandleBase {
     // internal full-frame film (zeroed), merged into the caller's buffer at the end
     if (film_.n != W * H * 4) film_.alloc(W * H * 4);
     HIP_CHECK(hipMemsetAsync(film_.p, 0, W * H * 4 * sizeof(R), st_));
-    if (totals_.n == 0) totals_.alloc(8);
-    HIP_CHECK(hipMemsetAsync(totals_.p, 0, 8 * sizeof(unsigned long long), st_));
+    if (totals_.n == 0) totals_.alloc(12);
+    HIP_CHECK(hipMemsetAsync(totals_.p, 0, 12 * sizeof(unsigned long long), st_));
     HIP_CHECK(hipMemsetAsync(counters_.p, 0, C_COUNT * sizeof(uint32_t), st_));
 
     size_t P = std::min(max_paths_, std::max<size_t>(rpix * (size_t)std::max<uint64_t>(s_total, 1), 64));
@@ -816,6 +840,7 @@ class Handle : public HandleBase {
               if (b > 1) HIP_CHECK(hipStreamWaitEvent(st_, ev_shadow_[b & 1], 0));   // shading refills the queue the shadow launch of bounce b - 2 read
             }
             scene_.use_shadow_tabs = use_shadow_lists() ? 1u : 0u;
+            scene_.horizon = (horizon_on_ && horizon_.n) ? horizon_.p : nullptr; scene_.hz_axis = hz_axis_;   // (counting frames too: the cull is geometry, not a kernel's arithmetic - their node counters then hold the rays that are traced)
             e = tick(3);
             if (tex_depth_ > 0) hipLaunchKernelGGL((k_shade_path<R, 4, true>), dim3(std::min((uint32_t)((nslots + 255) / 256), 16384u)), dim3(256), 0, st_, scene_, pool_);
             else if (has_translucent_) hipLaunchKernelGGL((k_shade_path<R, 4>), dim3(std::min((uint32_t)((nslots + 255) / 256), 16384u)), dim3(256), 0, st_, scene_, pool_);
@@ -831,6 +856,7 @@ class Handle : public HandleBase {
             }
             else hipLaunchKernelGGL((k_shade_path<R, 2>), dim3(std::min(sgrid, 16384u)), dim3(ShadeBlock<R>::n), 0, st_, scene_, pool_);
             tock(e);
+            if (scene_.horizon) hipLaunchKernelGGL(k_accumulate_sky, dim3(1), dim3(1), 0, st_, counters_.p, totals_.p);
             if (overlap) {
               HIP_CHECK(hipEventRecord(ev_shade_, st_));
               HIP_CHECK(hipStreamWaitEvent(st2_, ev_shade_, 0));
@@ -937,7 +963,7 @@ class Handle : public HandleBase {
     if (stats) frame_stats(*fr, stats);
   }
   void frame_stats(const FrameRec& fr, rrt_render_stats* stats) {
-    unsigned long long ht[8];
+    unsigned long long ht[12];
     HIP_CHECK(hipMemcpy(ht, totals_.p, sizeof(ht), hipMemcpyDeviceToHost));
     memset(stats, 0, sizeof(*stats));
     stats->camera_samples = fr.camera_samples;
@@ -952,6 +978,8 @@ class Handle : public HandleBase {
     stats->tile_launches = fr.n_tile_launch;
     stats->list_launches = fr.n_list_launch;
     stats->root_culled = ht[7];
+    stats->sky_culled = ht[8];
+    stats->s_horizon_build = hz_build_s_;
     if (!fr.timing) return;
     float ms = 0;
     HIP_CHECK(hipEventElapsedTime(&ms, fr.ev_begin, fr.ev_end));
@@ -1026,6 +1054,10 @@ class Handle : public HandleBase {
   DevBuf<uint32_t> pix_off_;
   TravScene trav_{};
   DevBuf<PairNode> pairs_;
+  DevBuf<uint8_t> horizon_;                // horizon tables (build_horizons()): 32 bytes per triangle; empty = not built for this scene
+  uint32_t hz_axis_ = 1u;
+  bool horizon_on_ = true;                 // option "horizon_cull"
+  double hz_build_s_ = 0.0;                // host seconds this handle spent building the tables when it was created (0: found in the process cache, or none built)
   DevBuf<QuadNode> quads_;                 // two levels per fetch (dtraverse_f32.hpp "quad nodes"); empty = not built for this scene
   bool quad_on_ = false;                   // option "quad_nodes"
   DevBuf<uint32_t> overflow_, overflow_any_;
@@ -1416,6 +1448,28 @@ class Handle : public HandleBase {
           for (uint32_t h : sl.headers) if ((h & 0xffu) != 0xffu) { n_with++; n_entries += h & 0xffu; }
           if (getenv("RRT_DEBUG")) fprintf(stderr, "[rrt] shadow lists: %u table(s), %zu of %zu (table, triangle) pairs listed, %.2f candidate leaves on average, built in %.3f s\n", sl.n_tables, n_with, sl.headers.size(), n_with ? (double)n_entries / (double)n_with : 0.0, t_sl);
         }
+      }
+    }
+    if constexpr (std::is_same<R, float>::value) {
+      // horizon tables: which bounce rays of the path integrator provably leave the scene (build_horizons())
+      horizon_.release();
+      const char* hz_env = getenv("RRT_HORIZON_TABLES");   // =0: build none (the "horizon_cull" option then has nothing to switch on)
+      if (pairs_ok_ && !mixed_ && d->integrator.type == RRT_INT_PATH && d->bvh_depth + 1 <= 64 && tris.size() < (1u << 27) && !(hz_env && atoi(hz_env) == 0)) {
+        const auto t_h0 = std::chrono::steady_clock::now();
+        std::vector<HzNode> hn(nodes.size());
+        std::vector<HzTri> ht(tris.size());
+        for (size_t i = 0; i < nodes.size(); i++) { for (int c = 0; c < 3; c++) { hn[i].bmin[c] = nodes[i].bmin[c]; hn[i].bmax[c] = nodes[i].bmax[c]; } hn[i].offset = nodes[i].offset; hn[i].n_prims = nodes[i].meta >> 2; }
+        for (size_t i = 0; i < tris.size(); i++) { for (int c = 0; c < 3; c++) { ht[i].p[0][c] = tris[i].p0[c]; ht[i].p[1][c] = tris[i].p1[c]; ht[i].p[2][c] = tris[i].p2[c]; } ht[i].skip = (tris[i].plane == kSphereMark || (tris[i].material & kInstFlag) != 0u) ? 1u : 0u; }
+        const char* chk = getenv("RRT_HZ_CHECK");
+        bool cached = false;
+        const std::shared_ptr<const HzTables> hz = horizons_cached(hn, ht, chk ? atol(chk) : 0, &cached);
+        if (hz->check_hits != 0) throw DeviceError("internal: horizon tables are not conservative (" + std::to_string(hz->check_hits) + " of " + std::to_string(hz->checked) + " free rays hit geometry)");
+        hz_axis_ = hz->axis;
+        horizon_.upload(hz->bytes, st_);
+        HIP_CHECK(hipStreamSynchronize(st_));
+        if (!cached) hz_build_s_ = std::chrono::duration<double>(std::chrono::steady_clock::now() - t_h0).count();
+        if (getenv("RRT_DEBUG")) fprintf(stderr, "[rrt] horizon tables: axis %u, %zu triangles, mean open share of the upper sectors %.3f, %s in %.3f s%s\n", hz_axis_, tris.size(), hz->mean_open, cached ? "found" : "built",
+                                         std::chrono::duration<double>(std::chrono::steady_clock::now() - t_h0).count(), chk ? (" (self-check: " + std::to_string(hz->checked) + " free rays, " + std::to_string(hz->check_hits) + " hits)").c_str() : "");
       }
     }
     lights_.upload(lights, st_); light_cdf_.upload(cdf_r, st_); lens_.upload(lens, st_); hdims_.upload(hd, st_); perms_.upload(perms, st_);

@@ -163,7 +163,7 @@ STRUCTS = {"rrt_xform": A.Xform, "rrt_tri": A.Tri, "rrt_sphere": A.Sphere, "rrt_
 FIELDS = {"rrt_texture": ["image", "fallback", "world_to_texture"], "rrt_material": ["tex"], "rrt_image": ["levels"],
           "rrt_scene_desc": ["flags", "tris", "n_prims", "textures", "image_texels", "bvh_nodes", "prim_order", "bvh_depth", "world_bound", "camera", "film", "sampler", "integrator"],
           "rrt_camera": ["elems", "exit_pupil_bounds", "exit_pupil_valid"], "rrt_film": ["filter_table", "max_sample_luminance"],
-          "rrt_sampler": ["perms", "perm_seed", "jitter"], "rrt_render_stats": ["ms_total", "any_prims", "list_launches", "ms_gather"], "rrt_rays": ["skip_prim"]}
+          "rrt_sampler": ["perms", "perm_seed", "jitter"], "rrt_render_stats": ["ms_total", "any_prims", "sky_culled", "list_launches", "ms_gather", "s_horizon_build"], "rrt_rays": ["skip_prim"]}
 
 
 def test_ctypes_mirror_matches_c_layout(tmp_path):

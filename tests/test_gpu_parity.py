@@ -18,6 +18,7 @@ import numpy as np
 import pytest
 
 import oracle_lib as O
+from scene_util import rough_terrain
 from rs_ray_toy_amd import (RRT_F32, RRT_F64, RRT_FIXED_BVH, RRT_INSTANCES_FLATTEN, RRT_INSTANCES_KEEP, Renderer, RrtPanic, RrtUnsupported,
                             Scene, scenes)
 
@@ -733,6 +734,64 @@ def test_quad_nodes_change_nothing(which, workdir):
     assert (out[1][1].camera_rays, out[1][1].closest_queries, out[1][1].any_queries) == (out[0][1].camera_rays, out[0][1].closest_queries, out[0][1].any_queries)
     for k in ("prim", "t", "u", "v"):
         assert np.array_equal(hits[1][k], hits[0][k]), k
+
+
+@pytest.mark.parametrize("which", ["cfg4", "rough_1", "rough_2", "rough_z_up", "cfg2", "cfg3", "cfg5", "stacked", "cfg4_passes"])
+def test_horizon_cull_changes_nothing(which, workdir, monkeypatch):
+    """The path shading kernel answers a bounce ray as the miss it is when its elevation exceeds everything the host found visible from ANY point of its start
+    triangle in its azimuth sector (rrt_impl.hpp build_horizons(): per triangle 2 x 16 quantised horizons about the scene's flattest axis; touching neighbours bounded
+    through the cone of their vertex differences, far geometry node by node). Three of four bounce rays leave an open terrain, each after walking the ~18 ancestors of
+    its own leaf. Frames, weights and query counts (the culled rays stay closest-hit queries, rrt_render_stats::sky_culled) are identical bit for bit with and without:
+    the gentle BASELINE terrain, steep noisy ones (valleys whose walls start on a triangle's own edge; also with z as the flat axis), the reference's tilted cubes and
+    an enclosure whose light sits inside (nothing may be culled towards a wall), config 5's two meshes, a second terrain stacked above the first (overhangs), several
+    pool passes. RRT_HZ_CHECK makes the builder test 20 000 random rays it declares free against every triangle in double precision."""
+    monkeypatch.setenv("RRT_HZ_CHECK", "20000")
+    flags = RRT_FIXED_BVH
+    if which in ("cfg4", "cfg4_passes"): cfg, root = scenes.cfg4(workdir, xres=128, yres=96, nsamp=9, max_depth=6, n=64)
+    elif which.startswith("rough"):
+        cfg, root = rough_terrain(workdir, {"rough_1": 1, "rough_2": 2, "rough_z_up": 3}[which])
+        if which == "rough_z_up":      # the same terrain stood on its side (a rigid instance, flattened to world space): z becomes the scene's flattest axis
+            cfg["Aggregate"]["primitives"][0]["instances"] = [{"rotation_axis": [1.0, 0.0, 0.0], "rotation_angle": -90.0}]
+    elif which == "cfg2": cfg, root = scenes.cfg2(workdir, xres=96, yres=96, nsamp=9, max_depth=4); flags = 0
+    elif which == "cfg3": cfg, root = scenes.cfg3(workdir, xres=96, yres=96, nsamp=9)
+    elif which == "cfg5": cfg, root = scenes.cfg5(workdir, xres=96, yres=96, nsamp=9, max_depth=6, n=64)
+    else:   # stacked: the terrain twice, the second copy 3 units above the first and shifted: rays that clear the lower terrain's horizon meet the upper one
+        cfg, root = scenes.cfg4(workdir, xres=96, yres=96, nsamp=9, max_depth=6, n=48)
+        cfg["Aggregate"]["primitives"][0]["instances"] = [{"world_pos": [0.0, 0.0, 0.0]}, {"world_pos": [1.3, 3.0, 0.7]}]
+    sc = Scene.loads(cfg, root, flags=flags)
+    r = Renderer(sc, 0, RRT_F32)
+    if which == "cfg4_passes": r.set_option("max_paths", 128 * 96 * 3)
+    out = {}
+    for h in (1, 0):
+        r.set_option("horizon_cull", h)
+        out[h] = r.render(stats=True)
+    r.close()
+    assert out[1][0][..., :3].max() > 0
+    assert np.array_equal(out[1][0], out[0][0])
+    assert (out[1][1].camera_rays, out[1][1].closest_queries, out[1][1].any_queries) == (out[0][1].camera_rays, out[0][1].closest_queries, out[0][1].any_queries)
+    assert out[0][1].sky_culled == 0
+    print(f"horizon cull, {which}: {out[1][1].sky_culled} of {out[1][1].closest_queries} closest-hit queries answered by the tables")
+    if which in ("cfg4", "cfg5", "cfg4_passes"): assert out[1][1].sky_culled > 0.05 * out[1][1].closest_queries     # (the steep terrains have high horizons: little to cull, and that little exactly)
+    if which == "cfg3": assert out[1][1].sky_culled == 0      # an enclosure: something is visible in every direction
+
+
+def test_horizon_cull_changes_nothing_at_baseline_size(workdir):
+    """The same invariance on the frame bench.py times (BASELINE config 4: 100 352 triangles, 1024 x 1024, 256 spp, depth 8 - 134 M closest-hit queries, a third
+    of them answered by the tables): identical bit for bit. A spawned ray's origin lies on its triangle to ~1e-9 only, so a ray that starts
+    within that distance of an edge could in principle meet a neighbour the tables do not speak for; at this volume none does."""
+    cfg, root = scenes.cfg4(workdir)
+    sc = Scene.loads(cfg, root, flags=RRT_FIXED_BVH)
+    r = Renderer(sc, 0, RRT_F32)
+    out = {}
+    for h in (1, 0):
+        r.set_option("horizon_cull", h)
+        out[h] = r.render(stats=True)
+    r.close()
+    st = out[1][1]
+    print(f"horizon cull at BASELINE size: {st.sky_culled} of {st.closest_queries} closest-hit queries answered by the tables (built in {st.s_horizon_build:.2f} s); {st.ms_total:.1f} ms against {out[0][1].ms_total:.1f} ms without")
+    assert st.sky_culled > 0.2 * st.closest_queries and out[0][1].sky_culled == 0
+    assert (st.camera_rays, st.closest_queries, st.any_queries) == (out[0][1].camera_rays, out[0][1].closest_queries, out[0][1].any_queries)
+    assert np.array_equal(out[1][0], out[0][0])
 
 
 @pytest.mark.parametrize("which", ["cfg4", "cfg4_passes", "cfg2_f64", "cfg5", "cfg4_textured_translucent"])
