@@ -2,6 +2,8 @@
 #include "horizon_build.hpp"
 #include <algorithm>
 #include <atomic>
+#include <exception>
+#include <mutex>
 #include <thread>
 
 namespace rrtd {
@@ -269,11 +271,22 @@ HzTables build_horizons(const HzNode* nodes, size_t n_nodes, const HzTri* tris, 
     open_sum += open_local;
   };
   {
+    // up to 16 threads (a GPU process's share of the host), triangles handed out in chunks of 256 as the threads come free (a triangle under an overhang costs
+    // several times one on open ground); a worker's exception (allocation) is rethrown on the caller's thread
     const unsigned hw = std::max(1u, std::min(16u, std::thread::hardware_concurrency()));
+    std::atomic<size_t> next{0};
+    std::exception_ptr failed;
+    std::mutex failed_mu;
+    auto guarded = [&]() {
+      try {
+        for (;;) { const size_t a = next.fetch_add(256); if (a >= nt) break; work(a, std::min(nt, a + 256)); }
+      } catch (...) { std::lock_guard<std::mutex> lk(failed_mu); if (!failed) failed = std::current_exception(); }
+    };
     std::vector<std::thread> pool;
-    const size_t chunk = (nt + hw - 1) / hw;
-    for (unsigned t = 0; t < hw; t++) { const size_t a = std::min(nt, t * chunk), b = std::min(nt, a + chunk); if (a < b) pool.emplace_back(work, a, b); }
+    for (unsigned t = 1; t < hw && (size_t)t * 256u < nt; t++) pool.emplace_back(guarded);
+    guarded();
     for (auto& th : pool) th.join();
+    if (failed) std::rethrow_exception(failed);
   }
   res.mean_open = (double)open_sum.load() / (255.0 * 16.0 * (double)nt);
   // Self-check (check_rays > 0; the handle passes RRT_HZ_CHECK=<rays>, tests/test_horizon.py calls it without a GPU): random rays from random points of random triangles
