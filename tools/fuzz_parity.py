@@ -75,6 +75,7 @@ if os.environ.get("FUZZ_SPHERE_TABLE") == "1":
     sys.exit(0)
 
 worst = []
+hz_total = [0, 0]
 for case in range(n_cases):
     wd = tempfile.mkdtemp()
     base = rng.choice(["cfg2", "cfg3", "cfg4", "cfg1"])
@@ -150,7 +151,15 @@ for case in range(n_cases):
         print(f"[device] {tag}", flush=True) if os.environ.get("FUZZ_TRACE") else None
         r = Renderer(sc, 0, RRT_F32 if F32 else RRT_F64)
         if max_paths: r.set_option("max_paths", max_paths)
-        film = r.render(rect).astype(np.float64); r.close(); d_err = None
+        film = r.render(rect).astype(np.float64)
+        if F32 and os.environ.get("FUZZ_HORIZON") == "1":     # the horizon tables (fp32 path integrator) must not change a bit: the same frame without them
+            hz_stats = r.render(rect, stats=True)[1]
+            r.set_option("horizon_cull", 0)
+            film_off = r.render(rect).astype(np.float64)
+            hz_total[0] += int(hz_stats.sky_culled); hz_total[1] += int(hz_stats.closest_queries)
+            if not np.array_equal(film, film_off):
+                print(f"HZ-DIFF {tag}: {int((film != film_off).any(-1).sum())} pixels differ with / without the horizon tables ({hz_stats.sky_culled} of {hz_stats.closest_queries} closest-hit queries culled)")
+        r.close(); d_err = None
     except RrtError as e:
         film, d_err = None, str(e)
     if o_err or d_err:
@@ -175,3 +184,4 @@ for case in range(n_cases):
     print(f"{flag}{tag}: max {d.max():.2e}, frac>1e-9 {bad:.4f}, weight diff {wdiff:.1e}")
     worst.append((d.max(), tag))
 print("worst:", sorted(worst, reverse=True)[:3])
+if os.environ.get("FUZZ_HORIZON") == "1": print(f"horizon tables: {hz_total[0]} of {hz_total[1]} closest-hit queries of the sweep answered by them")
