@@ -775,11 +775,30 @@ def test_horizon_cull_changes_nothing(which, workdir, monkeypatch):
     if which == "cfg3": assert out[1][1].sky_culled == 0      # an enclosure: something is visible in every direction
 
 
-def test_horizon_cull_changes_nothing_at_baseline_size(workdir):
-    """The same invariance on the frame bench.py times (BASELINE config 4: 100 352 triangles, 1024 x 1024, 256 spp, depth 8 - 134 M closest-hit queries, a third
-    of them answered by the tables): identical bit for bit. A spawned ray's origin lies on its triangle to ~1e-9 only, so a ray that starts
-    within that distance of an edge could in principle meet a neighbour the tables do not speak for; at this volume none does."""
-    cfg, root = scenes.cfg4(workdir)
+def test_horizon_tables_are_built_once_per_geometry_and_can_be_switched_off(workdir, monkeypatch):
+    """rrt_create builds the tables on the host (rrt_render_stats::s_horizon_build); a second handle on the same geometry finds them in the process cache (keyed by the
+    content of the builder's input, not by address); RRT_HORIZON_TABLES=0 builds none - the frame is the same frame each time."""
+    cfg, root = scenes.cfg4(workdir, xres=64, yres=64, nsamp=5, max_depth=4, n=40)
+    cfg["Film"]["name"] = "unique_to_this_test"      # (nothing the builder sees)
+    scenes.write_heightfield(workdir, n=40, seed=424242)      # geometry no other test of this process has built tables for
+    sc = Scene.loads(cfg, root, flags=RRT_FIXED_BVH)
+    r1 = Renderer(sc, 0, RRT_F32); f1, s1 = r1.render(stats=True)
+    r2 = Renderer(sc, 0, RRT_F32); f2, s2 = r2.render(stats=True)
+    monkeypatch.setenv("RRT_HORIZON_TABLES", "0")
+    r3 = Renderer(sc, 0, RRT_F32); f3, s3 = r3.render(stats=True)
+    for r in (r1, r2, r3): r.close()
+    assert s1.s_horizon_build > 0 and s2.s_horizon_build == 0 and s3.s_horizon_build == 0
+    assert s1.sky_culled > 0 and s2.sky_culled == s1.sky_culled and s3.sky_culled == 0
+    assert np.array_equal(f1, f2) and np.array_equal(f1, f3)
+
+
+@pytest.mark.parametrize("which", ["cfg4", "cfg5"])
+def test_horizon_cull_changes_nothing_at_baseline_size(which, workdir):
+    """The same invariance on the frames bench.py times (BASELINE config 4: 100 352 triangles, 1024 x 1024, 256 spp, depth 8 - 134 M closest-hit queries, a third
+    of them answered by the tables; config 5: two meshes, micro-facet lobes, 2048 x 2048, 1 024 spp, depth 16 - 2.3 G queries, a quarter of them): identical bit for
+    bit. A spawned ray's origin lies on its triangle to ~1e-9 only, so a ray that starts within that distance of an edge could in principle meet
+    a neighbour the tables do not speak for; at this volume none does."""
+    cfg, root = scenes.cfg4(workdir) if which == "cfg4" else scenes.cfg5(workdir)
     sc = Scene.loads(cfg, root, flags=RRT_FIXED_BVH)
     r = Renderer(sc, 0, RRT_F32)
     out = {}
