@@ -159,6 +159,7 @@ struct SceneDev {
   // horizon tables (fp32 path integrator, rrt_impl.hpp build_horizons()): per triangle 2 x 16 bytes - hemisphere +hz_axis / -hz_axis, 16 azimuth sectors (hz_sector) -
   // holding ceil(254 x sin(max elevation at which anything is visible from any point of the triangle in that sector)) + margin; null = off
   const uint8_t* horizon;
+  const float* hz_tau;         // per triangle: the cull applies where min(barycentric) |n.d| > hz_tau (HzTables::tau: the ray's origin is only NEAR its triangle's plane)
   uint32_t hz_axis;
   float root_box[6];
   // camera

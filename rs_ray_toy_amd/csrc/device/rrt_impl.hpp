@@ -840,7 +840,7 @@ class Handle : public HandleBase {
               if (b > 1) HIP_CHECK(hipStreamWaitEvent(st_, ev_shadow_[b & 1], 0));   // shading refills the queue the shadow launch of bounce b - 2 read
             }
             scene_.use_shadow_tabs = use_shadow_lists() ? 1u : 0u;
-            scene_.horizon = (horizon_on_ && horizon_.n) ? horizon_.p : nullptr; scene_.hz_axis = hz_axis_;   // (counting frames too: the cull is geometry, not a kernel's arithmetic - their node counters then hold the rays that are traced)
+            scene_.horizon = (horizon_on_ && horizon_.n) ? horizon_.p : nullptr; scene_.hz_tau = horizon_tau_.p; scene_.hz_axis = hz_axis_;   // (counting frames too: the cull is geometry, not a kernel's arithmetic - their node counters then hold the rays that are traced)
             e = tick(3);
             if (tex_depth_ > 0) hipLaunchKernelGGL((k_shade_path<R, 4, true>), dim3(std::min((uint32_t)((nslots + 255) / 256), 16384u)), dim3(256), 0, st_, scene_, pool_);
             else if (has_translucent_) hipLaunchKernelGGL((k_shade_path<R, 4>), dim3(std::min((uint32_t)((nslots + 255) / 256), 16384u)), dim3(256), 0, st_, scene_, pool_);
@@ -1054,6 +1054,7 @@ class Handle : public HandleBase {
   DevBuf<uint32_t> pix_off_;
   TravScene trav_{};
   DevBuf<PairNode> pairs_;
+  DevBuf<float> horizon_tau_;              // HzTables::tau
   DevBuf<uint8_t> horizon_;                // horizon tables (build_horizons()): 32 bytes per triangle; empty = not built for this scene
   uint32_t hz_axis_ = 1u;
   bool horizon_on_ = true;                 // option "horizon_cull"
@@ -1452,7 +1453,7 @@ class Handle : public HandleBase {
     }
     if constexpr (std::is_same<R, float>::value) {
       // horizon tables: which bounce rays of the path integrator provably leave the scene (build_horizons())
-      horizon_.release();
+      horizon_.release(); horizon_tau_.release();
       const char* hz_env = getenv("RRT_HORIZON_TABLES");   // =0: build none (the "horizon_cull" option then has nothing to switch on)
       if (pairs_ok_ && !mixed_ && d->integrator.type == RRT_INT_PATH && d->bvh_depth + 1 <= 64 && tris.size() < (1u << 27) && !(hz_env && atoi(hz_env) == 0)) {
         const auto t_h0 = std::chrono::steady_clock::now();
@@ -1465,7 +1466,7 @@ class Handle : public HandleBase {
         const std::shared_ptr<const HzTables> hz = horizons_cached(hn, ht, chk ? atol(chk) : 0, &cached);
         if (hz->check_hits != 0) throw DeviceError("internal: horizon tables are not conservative (" + std::to_string(hz->check_hits) + " of " + std::to_string(hz->checked) + " free rays hit geometry)");
         hz_axis_ = hz->axis;
-        horizon_.upload(hz->bytes, st_);
+        horizon_.upload(hz->bytes, st_); horizon_tau_.upload(hz->tau, st_);
         HIP_CHECK(hipStreamSynchronize(st_));
         if (!cached) hz_build_s_ = std::chrono::duration<double>(std::chrono::steady_clock::now() - t_h0).count();
         if (getenv("RRT_DEBUG")) fprintf(stderr, "[rrt] horizon tables: axis %u, %zu triangles, mean open share of the upper sectors %.3f, %s in %.3f s%s\n", hz_axis_, tris.size(), hz->mean_open, cached ? "found" : "built",

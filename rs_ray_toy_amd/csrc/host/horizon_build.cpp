@@ -36,6 +36,10 @@ HzTables build_horizons(const HzNode* nodes, size_t n_nodes, const HzTri* tris, 
   uint32_t k = 0;
   for (uint32_t c = 1; c < 3; c++) if (nodes[0].bmax[c] - nodes[0].bmin[c] < nodes[0].bmax[k] - nodes[0].bmin[k]) k = c;
   res.axis = k;
+  res.tau.assign(nt, INFINITY);
+  double coord_max = 0.0;
+  for (int c = 0; c < 3; c++) coord_max = std::max({coord_max, std::fabs((double)nodes[0].bmin[c]), std::fabs((double)nodes[0].bmax[c])});
+  const double rho = std::ldexp(coord_max, -24);
   const uint32_t ia = (k + 1u) % 3u, ib = (k + 2u) % 3u;   // (a, b): the other two axes in cyclic order - what the kernel hands to hz_sector
   const double kPi = 3.14159265358979323846;
   // angular range of every sector id in degrees of atan2(b, a), from the definition of hz_sector: first-quadrant wedges, then mirrored by the sign bits
@@ -261,6 +265,14 @@ HzTables build_horizons(const HzNode* nodes, size_t n_nodes, const HzTri* tris, 
           push(ni + 1u); push(nd.offset);
         }
       }
+      {   // smallest altitude = 2 x area / longest edge
+        const double e0[3] = {(double)T.p[1][0] - T.p[0][0], (double)T.p[1][1] - T.p[0][1], (double)T.p[1][2] - T.p[0][2]}, e1[3] = {(double)T.p[2][0] - T.p[0][0], (double)T.p[2][1] - T.p[0][1], (double)T.p[2][2] - T.p[0][2]};
+        const double e2[3] = {e1[0] - e0[0], e1[1] - e0[1], e1[2] - e0[2]};
+        const double cx = e0[1] * e1[2] - e0[2] * e1[1], cy = e0[2] * e1[0] - e0[0] * e1[2], cz = e0[0] * e1[1] - e0[1] * e1[0];
+        const double area2 = std::sqrt(cx * cx + cy * cy + cz * cz);
+        const double longest = std::sqrt(std::max({e0[0] * e0[0] + e0[1] * e0[1] + e0[2] * e0[2], e1[0] * e1[0] + e1[1] * e1[1] + e1[2] * e1[2], e2[0] * e2[0] + e2[1] * e2[1] + e2[2] * e2[2]}));
+        if (area2 > 0.0 && longest > 0.0) { const double t4 = 4.0 * rho / (area2 / longest); res.tau[ti] = t4 < 3.0e38 ? (float)(t4 * (1.0 + 1e-6)) : INFINITY; }
+      }
       for (uint32_t id = 0; id < 16u; id++) {
         const double hu = std::min(1.0, Hup[id] + kHzMargin), hd = std::min(1.0, Hdn[id] + kHzMargin);
         out[ti * 32u + id] = (uint8_t)std::min(255.0, std::ceil(254.0 * hu) + 1.0);
@@ -336,7 +348,7 @@ HzTables build_horizons(const HzNode* nodes, size_t n_nodes, const HzTri* tris, 
 #include <chrono>
 #include "rrt.h"
 extern "C" __attribute__((visibility("default"))) int rrt_internal_horizons(const rrt_scene_desc* d, uint8_t* out, uint32_t* axis, double* mean_open, long check_rays,
-                                                                            long* checked, long* check_hits, double* seconds) {
+                                                                            long* checked, long* check_hits, double* seconds, float* tau_out) {
   if (!d || !out) return 1;
   std::vector<rrtd::HzNode> hn(d->n_bvh_nodes);
   std::vector<rrtd::HzTri> ht(d->n_prim_order);
@@ -359,6 +371,7 @@ extern "C" __attribute__((visibility("default"))) int rrt_internal_horizons(cons
   const rrtd::HzTables tab = rrtd::build_horizons(hn.data(), hn.size(), ht.data(), ht.size(), check_rays);
   if (seconds) *seconds = std::chrono::duration<double>(std::chrono::steady_clock::now() - t0).count();   // (with the self-check when one was asked for)
   std::copy(tab.bytes.begin(), tab.bytes.end(), out);
+  if (tau_out) std::copy(tab.tau.begin(), tab.tau.end(), tau_out);
   if (axis) *axis = tab.axis;
   if (mean_open) *mean_open = tab.mean_open;
   if (checked) *checked = tab.checked;

@@ -24,6 +24,11 @@ struct HzNode { float bmin[3], bmax[3]; uint32_t offset; uint32_t n_prims; };   
 struct HzTri { float p[3][3]; uint32_t skip; };                                  // skip: not a world-space triangle (no table is built for it)
 struct HzTables {
   std::vector<uint8_t> bytes;   // 32 per triangle: hemisphere +axis then -axis, 16 sectors each
+  // per triangle: the tables speak for rays that start ON the triangle; a spawned ray starts within rho of its plane (fp32 evaluation of the barycentric sum and the
+  // packed low word of the origin: rho = 2^-24 x the scene's largest coordinate bounds both), so its line meets the plane within rho (1 + tan) <= 2 rho / |n.d| of the
+  // stored point - inside the triangle, where the tables hold, when min(barycentric) x (smallest altitude) exceeds that. tau = 4 rho / smallest altitude (twice the
+  // bound); the kernel culls only where min(barycentric) |n.d| > tau. Infinite for a degenerate triangle.
+  std::vector<float> tau;
   uint32_t axis = 0;
   double mean_open = 0.0;       // mean share of the upper hemisphere the tables declare free
   long checked = 0, check_hits = 0;   // self-check (check_rays > 0): rays declared free / those of them that hit a triangle (must be 0)

@@ -105,6 +105,24 @@ def test_rays_the_tables_declare_free_miss_everything(which, workdir):
     bad = hit & ~own
     assert bad.sum() == 0, (int(bad.sum()), int(free.sum()), res["t"][bad][:5], dd[bad][:5])
     print(f"{which}: {n} triangles, open share {open_share:.3f}, {int(free.sum())} of {m} random rays declared free, none of them hits (oracle); built in {secs:.2f} s")
+    # The device's origin is only NEAR its triangle's plane (fp32 barycentric sum, packed low word): within rho = 2^-24 x the scene's largest coordinate. The kernel
+    # therefore culls only where min(barycentric) |n.d| > tau[triangle] (HzTables::tau = 4 rho / smallest altitude): the same rays, started rho off the plane on either
+    # side and rho off along it, must still miss everything - and the guard must cost almost nothing.
+    tau = horizons.tau[ti]
+    nrm = np.cross(T[:, 1] - T[:, 0], T[:, 2] - T[:, 0]); nrm /= np.linalg.norm(nrm, axis=1)[:, None]
+    bmin = np.minimum(np.minimum(b0, b1), 1 - b0 - b1)
+    guard = bmin * np.abs(np.einsum("ij,ij->i", nrm, d)) > tau
+    rho = 2.0 ** -24 * float(np.max(np.abs(np.concatenate([lo, hi]))))
+    kept = free & guard
+    assert kept.sum() > 0.9 * free.sum(), (int(kept.sum()), int(free.sum()))      # (and that although 30 % of the points were put within 1e-3 of an edge on purpose)
+    jit = rng.normal(size=(m, 3)); jit /= np.linalg.norm(jit, axis=1)[:, None]
+    for side in (+1.0, -1.0):
+        o2 = (p + nrm * side * rho + jit * rho)[kept]
+        res2 = O.trace_closest(sc, o2, d[kept], np.full(int(kept.sum()), np.inf))
+        bad2 = (res2["prim"] >= 0) & (res2["prim"] != ti[kept])
+        # the start triangle itself may be met from rho above it (the device excludes it by plane id); nothing else may
+        assert bad2.sum() == 0, (side, int(bad2.sum()), int(kept.sum()), res2["t"][bad2][:5])
+    print(f"{which}: guard keeps {int(kept.sum())} of {int(free.sum())} free rays (the sample has 30 % of its points within 1e-3 of an edge); started {rho:.1e} off the plane they still miss everything")
 
 
 def test_tables_do_not_depend_on_the_thread_split(workdir):

@@ -19,11 +19,12 @@ def horizons(scene, check_rays=0):
     """(bytes [n_tris, 2, 16], axis, mean open share, rays checked, hits, seconds) through the library's test hook."""
     fn = A.lib().rrt_internal_horizons
     fn.restype = C.c_int
-    fn.argtypes = [C.c_void_p, C.c_void_p, C.POINTER(C.c_uint32), C.POINTER(C.c_double), C.c_long, C.POINTER(C.c_long), C.POINTER(C.c_long), C.POINTER(C.c_double)]
+    fn.argtypes = [C.c_void_p, C.c_void_p, C.POINTER(C.c_uint32), C.POINTER(C.c_double), C.c_long, C.POINTER(C.c_long), C.POINTER(C.c_long), C.POINTER(C.c_double), C.c_void_p]
     n = int(scene.desc.n_prim_order)
     out = np.zeros((n, 2, 16), np.uint8)
+    horizons.tau = np.zeros(n, np.float32)      # (HzTables::tau of the last call)
     axis, mean_open, checked, hits, secs = C.c_uint32(), C.c_double(), C.c_long(), C.c_long(), C.c_double()
-    rc = fn(C.addressof(scene.desc), out.ctypes.data, C.byref(axis), C.byref(mean_open), check_rays, C.byref(checked), C.byref(hits), C.byref(secs))
+    rc = fn(C.addressof(scene.desc), out.ctypes.data, C.byref(axis), C.byref(mean_open), check_rays, C.byref(checked), C.byref(hits), C.byref(secs), horizons.tau.ctypes.data)
     assert rc == 0
     return out, axis.value, mean_open.value, checked.value, hits.value, secs.value
 
