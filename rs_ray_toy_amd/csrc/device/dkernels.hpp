@@ -1111,8 +1111,16 @@ __global__ void __launch_bounds__((shade_path_block<R, KM>())) __attribute__((am
             const float a = s.hz_axis == 0u ? (float)nd.y : (s.hz_axis == 1u ? (float)nd.z : (float)nd.x), b = s.hz_axis == 0u ? (float)nd.z : (s.hz_axis == 1u ? (float)nd.x : (float)nd.y);
             const uint32_t q = s.horizon[(size_t)prim * 32u + (u < 0.0f ? 16u : 0u) + hz_sector(a, b)];
             // (the tables speak for rays that start ON the triangle; the spawn point is within 2^-24 x the scene's size of its plane, and the ray's line then meets the
-            // plane inside the triangle - where the tables hold - if the point is this far from the edges for this inclination: HzTables::tau)
-            if (fabsf(u) * 254.0f > (float)q && fminf(fminf((float)h.z, (float)h.w), 1.0f - (float)h.z - (float)h.w) * fabsf((float)dot(si.n, nd)) > s.hz_tau[prim]) { cont = false; sky = true; }
+            // plane inside the triangle - where the tables hold - if the point is this far from the edges for this inclination: HzTables::tau. Both loads are issued
+            // before either comparison: one latency, not two in a row)
+#ifdef RRT_HZ_NO_GUARD   // measurement variant only
+            const float tau = -1.0f;
+#else
+            const float tau = s.hz_tau[prim];
+#endif
+            const bool above = fabsf(u) * 254.0f > (float)q;
+            const bool inside = fminf(fminf((float)h.z, (float)h.w), 1.0f - (float)h.z - (float)h.w) * fabsf((float)dot(si.n, nd)) > tau;
+            if (above && inside) { cont = false; sky = true; }
           }
           if (cont && (int)bounces < s.max_depth) {
             nx_o = si.p; nx_d = nd;
