@@ -89,7 +89,7 @@ HzTables build_horizons(const HzNode* nodes, size_t n_nodes, const HzTri* tris, 
   std::atomic<uint64_t> open_sum{0};
   struct Bound { double up, dn; uint32_t mask; };   // sines of the largest elevation above / below the horizontal, sectors concerned
   // per-sector bounds of one pair of triangles (sectors outside `mask` are not concerned)
-  struct PairBound { double up[16], dn[16]; uint32_t mask; };
+  struct PairBound { double up[16], dn[16]; uint32_t mask; bool contact; };
   auto pair_bound = [&](const HzTri& T, const HzTri& U, PairBound* pb, const double* Hup, const double* Hdn) {
     const float* tv[3] = {T.p[0], T.p[1], T.p[2]};
     const float* uv[3] = {U.p[0], U.p[1], U.p[2]};
@@ -99,7 +99,7 @@ HzTables build_horizons(const HzNode* nodes, size_t n_nodes, const HzTri* tris, 
       if (v[0] == 0.0 && v[1] == 0.0 && v[2] == 0.0) { n_zero++; continue; }
       g[ng][0] = v[0]; g[ng][1] = v[1]; g[ng][2] = v[2]; ng++;
     }
-    pb->mask = 0u;
+    pb->mask = 0u; pb->contact = false;
     if (ng == 0) return;   // (the same three points)
     double ph[9][2];
     for (int i = 0; i < ng; i++) { ph[i][0] = g[i][ia]; ph[i][1] = g[i][ib]; }
@@ -136,6 +136,11 @@ HzTables build_horizons(const HzNode* nodes, size_t n_nodes, const HzTri* tris, 
       for (int i = 1; i < ng; i++) { if (ph[lo][0] * ph[i][1] - ph[lo][1] * ph[i][0] < 0.0) lo = i; if (ph[hi][0] * ph[i][1] - ph[hi][1] * ph[i][0] > 0.0) hi = i; }
       pb->mask = between(ph[lo], ph[hi]);
     }
+    // Contact without a shared vertex: the footprints overlap (or come within 4 rho) and the vertical differences reach within 4 rho of zero - a triangle that crosses T,
+    // rests on it, or lies a hair above or below it. The guard (HzTables::tau) keeps a ray's origin away from T's EDGES; nothing keeps it from geometry that close to T's
+    // interior (the origin is only within rho of the plane, it may be on the far side of such a triangle): T gets no tables at all. (Exactly coplanar triangles the walk
+    // never opens - their boxes bound the rise by 0 - are the device's business: it excludes them by plane id.)
+    if (n_zero == 0 && hmin <= 4.0 * rho && vk >= -4.0 * rho && vd >= -4.0 * rho) { pb->contact = true; pb->mask = 0xffffu; for (int sct = 0; sct < 16; sct++) pb->up[sct] = pb->dn[sct] = 1.0; return; }
     // (1) no shared vertex: the largest rise over the smallest horizontal distance - one number for every sector the hull meets; and nothing finer for a triangle
     // well away from T (at more than half the differences' own spread: the half spaces below tell sectors apart, which such a pair hardly spans)
     const double all_up = n_zero == 0 ? simple(vk) : 1.0, all_dn = n_zero == 0 ? simple(vd) : 1.0;

@@ -14,7 +14,7 @@ import pytest
 
 import oracle_lib as O
 from rs_ray_toy_amd import RRT_FIXED_BVH, Scene, scenes
-from scene_util import rough_terrain
+from scene_util import boxes_on_a_plane, rough_terrain
 
 sys.path.insert(0, os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "tools"))
 from hz_time import horizons  # noqa: E402
@@ -60,13 +60,15 @@ def make(which, wd):
     elif which == "flat":      # amplitude 0: every triangle in one plane - nothing is above any horizon, and the planar cones are the degenerate case of the builder
         cfg, root = scenes.cfg4(wd, xres=32, yres=32, nsamp=2, max_depth=4, n=12)
         scenes.write_heightfield(wd, n=12, amp=0.0)
+    elif which.startswith("boxes"):      # resting, floating, sunk, leaning and touching boxes on a flat ground: coplanar contact, T-junctions, crossing triangles
+        cfg, root = boxes_on_a_plane(wd, int(which[-1]))
     else:
         cfg, root = rough_terrain(wd, {"rough_1": 1, "rough_2": 2}[which], n=24)
     snap_obj_to_fp32(os.path.join(wd, "heightfield.obj"))
     return cfg, root
 
 
-@pytest.mark.parametrize("which", ["cfg4", "rough_1", "rough_2", "flat"])
+@pytest.mark.parametrize("which", ["cfg4", "rough_1", "rough_2", "flat", "boxes_1", "boxes_2", "boxes_3"])
 def test_rays_the_tables_declare_free_miss_everything(which, workdir):
     cfg, root = make(which, workdir)
     sc = Scene.loads(cfg, root, flags=RRT_FIXED_BVH)
@@ -119,8 +121,12 @@ def test_rays_the_tables_declare_free_miss_everything(which, workdir):
     for side in (+1.0, -1.0):
         o2 = (p + nrm * side * rho + jit * rho)[kept]
         res2 = O.trace_closest(sc, o2, d[kept], np.full(int(kept.sum()), np.inf))
-        bad2 = (res2["prim"] >= 0) & (res2["prim"] != ti[kept])
-        # the start triangle itself may be met from rho above it (the device excludes it by plane id); nothing else may
+        hitp = res2["prim"]
+        Vh = V[np.maximum(hitp, 0)].astype(np.float32).astype(np.float64)
+        # the start triangle itself, or one exactly in its plane (a box's bottom face on the ground), may be met from rho above it: the device excludes both by plane id
+        # (DESIGN.md section 4); nothing else may
+        coplanar = (np.abs(np.einsum("ij,ikj->ik", nrm[kept], Vh - T[kept][:, :1])) <= 1e-12 * float(np.max(hi - lo))).all(1)
+        bad2 = (hitp >= 0) & (hitp != ti[kept]) & ~coplanar
         assert bad2.sum() == 0, (side, int(bad2.sum()), int(kept.sum()), res2["t"][bad2][:5])
     print(f"{which}: guard keeps {int(kept.sum())} of {int(free.sum())} free rays (the sample has 30 % of its points within 1e-3 of an edge); started {rho:.1e} off the plane they still miss everything")
 
