@@ -101,6 +101,52 @@ HzTables build_horizons(const HzNode* nodes, size_t n_nodes, const HzTri* tris, 
     }
     pb->mask = 0u; pb->contact = false;
     if (ng == 0) return;   // (the same three points)
+    // A neighbour that shares a vertex or an edge and FOLDS BACK over T at a shallow angle (a lid, a fin): near the shared feature it is closer to T's interior than an
+    // origin's rounding, and the edge guard (tau) only keeps origins 4 rho from the edge - enough against a lid of slope >= 1/4 over T's plane (an origin within rho of
+    // the plane is still under it), not against a shallower one. Such a T gets no tables. Seen in T's plane: the two triangles' projections overlap (no separating
+    // edge normal), and the neighbour's free vertices rise by less than a quarter of their distance from the shared ones (or stand on both sides of the plane).
+    if (n_zero > 0) {
+      double e0[3], e1[3], nT[3];
+      for (int c = 0; c < 3; c++) { e0[c] = (double)tv[1][c] - tv[0][c]; e1[c] = (double)tv[2][c] - tv[0][c]; }
+      nT[0] = e0[1] * e1[2] - e0[2] * e1[1]; nT[1] = e0[2] * e1[0] - e0[0] * e1[2]; nT[2] = e0[0] * e1[1] - e0[1] * e1[0];
+      const double ln = std::sqrt(nT[0] * nT[0] + nT[1] * nT[1] + nT[2] * nT[2]), l0 = std::sqrt(e0[0] * e0[0] + e0[1] * e0[1] + e0[2] * e0[2]);
+      if (ln > 0.0 && l0 > 0.0) {
+        double bx[3], by[3];
+        for (int c = 0; c < 3; c++) { nT[c] /= ln; bx[c] = e0[c] / l0; }
+        by[0] = nT[1] * bx[2] - nT[2] * bx[1]; by[1] = nT[2] * bx[0] - nT[0] * bx[2]; by[2] = nT[0] * bx[1] - nT[1] * bx[0];
+        double A[3][2], B[3][2], hB[3];
+        bool sharedB[3] = {false, false, false};
+        for (int i = 0; i < 3; i++) {
+          double da[3], db[3];
+          for (int c = 0; c < 3; c++) { da[c] = (double)tv[i][c] - tv[0][c]; db[c] = (double)uv[i][c] - tv[0][c]; }
+          A[i][0] = da[0] * bx[0] + da[1] * bx[1] + da[2] * bx[2]; A[i][1] = da[0] * by[0] + da[1] * by[1] + da[2] * by[2];
+          B[i][0] = db[0] * bx[0] + db[1] * bx[1] + db[2] * bx[2]; B[i][1] = db[0] * by[0] + db[1] * by[1] + db[2] * by[2];
+          hB[i] = db[0] * nT[0] + db[1] * nT[1] + db[2] * nT[2];
+          for (int j = 0; j < 3; j++) if (uv[i][0] == tv[j][0] && uv[i][1] == tv[j][1] && uv[i][2] == tv[j][2]) sharedB[i] = true;
+        }
+        const double size = std::max(l0, std::sqrt(e1[0] * e1[0] + e1[1] * e1[1] + e1[2] * e1[2])), eps = 1e-9 * size;
+        bool separated = false;
+        for (int which = 0; which < 2 && !separated; which++) for (int i = 0; i < 3 && !separated; i++) {
+          const double (*P)[2] = which == 0 ? A : B;
+          const double ax = -(P[(i + 1) % 3][1] - P[i][1]), ay = P[(i + 1) % 3][0] - P[i][0];
+          double mnA = 1e300, mxA = -1e300, mnB = 1e300, mxB = -1e300;
+          for (int v = 0; v < 3; v++) { const double a = A[v][0] * ax + A[v][1] * ay, b = B[v][0] * ax + B[v][1] * ay; mnA = std::min(mnA, a); mxA = std::max(mxA, a); mnB = std::min(mnB, b); mxB = std::max(mxB, b); }
+          const double tol = eps * std::sqrt(ax * ax + ay * ay);
+          if (mxA <= mnB + tol || mxB <= mnA + tol) separated = true;
+        }
+        if (!separated) {
+          double slope = 1e300; bool pos = false, neg = false;
+          for (int i = 0; i < 3; i++) {
+            if (sharedB[i]) continue;
+            double dmin = 1e300;
+            for (int j = 0; j < 3; j++) if (sharedB[j]) dmin = std::min(dmin, std::sqrt((B[i][0] - B[j][0]) * (B[i][0] - B[j][0]) + (B[i][1] - B[j][1]) * (B[i][1] - B[j][1])));
+            if (hB[i] > 0.0) pos = true; else if (hB[i] < 0.0) neg = true; else { pos = true; neg = true; }
+            if (dmin > 0.0 && dmin < 1e300) slope = std::min(slope, std::fabs(hB[i]) / dmin);
+          }
+          if ((pos && neg) || slope < 0.25) { pb->contact = true; pb->mask = 0xffffu; for (int sct = 0; sct < 16; sct++) pb->up[sct] = pb->dn[sct] = 1.0; return; }
+        }
+      }
+    }
     double ph[9][2];
     for (int i = 0; i < ng; i++) { ph[i][0] = g[i][ia]; ph[i][1] = g[i][ib]; }
     double vk = -1e300, vd = -1e300;
