@@ -18,7 +18,7 @@ import numpy as np
 import pytest
 
 import oracle_lib as O
-from scene_util import rough_terrain
+from scene_util import boxes_on_a_plane, rough_terrain
 from rs_ray_toy_amd import (RRT_F32, RRT_F64, RRT_FIXED_BVH, RRT_INSTANCES_FLATTEN, RRT_INSTANCES_KEEP, Renderer, RrtPanic, RrtUnsupported,
                             Scene, scenes)
 
@@ -736,7 +736,7 @@ def test_quad_nodes_change_nothing(which, workdir):
         assert np.array_equal(hits[1][k], hits[0][k]), k
 
 
-@pytest.mark.parametrize("which", ["cfg4", "rough_1", "rough_2", "rough_z_up", "cfg2", "cfg3", "cfg5", "stacked", "cfg4_passes"])
+@pytest.mark.parametrize("which", ["cfg4", "rough_1", "rough_2", "rough_z_up", "cfg2", "cfg3", "cfg5", "stacked", "cfg4_passes", "boxes_1", "boxes_2"])
 def test_horizon_cull_changes_nothing(which, workdir, monkeypatch):
     """The path shading kernel answers a bounce ray as the miss it is when its elevation exceeds everything the host found visible from ANY point of its start
     triangle in its azimuth sector (rrt_impl.hpp build_horizons(): per triangle 2 x 16 quantised horizons about the scene's flattest axis; touching neighbours bounded
@@ -752,6 +752,8 @@ def test_horizon_cull_changes_nothing(which, workdir, monkeypatch):
         cfg, root = rough_terrain(workdir, {"rough_1": 1, "rough_2": 2, "rough_z_up": 3}[which])
         if which == "rough_z_up":      # the same terrain stood on its side (a rigid instance, flattened to world space): z becomes the scene's flattest axis
             cfg["Aggregate"]["primitives"][0]["instances"] = [{"rotation_axis": [1.0, 0.0, 0.0], "rotation_angle": -90.0}]
+    elif which.startswith("boxes"):      # boxes resting on, sunk into, leaning on and a hair above a flat ground, as world-space triangles: coplanar contact, T-junctions, crossings
+        cfg, root = boxes_on_a_plane(workdir, int(which[-1])); cfg["Film"]["xres"] = 96; cfg["Film"]["yres"] = 96
     elif which == "cfg2": cfg, root = scenes.cfg2(workdir, xres=96, yres=96, nsamp=9, max_depth=4); flags = 0
     elif which == "cfg3": cfg, root = scenes.cfg3(workdir, xres=96, yres=96, nsamp=9)
     elif which == "cfg5": cfg, root = scenes.cfg5(workdir, xres=96, yres=96, nsamp=9, max_depth=6, n=64)
