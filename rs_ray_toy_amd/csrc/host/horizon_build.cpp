@@ -7,24 +7,28 @@
 #include <thread>
 
 namespace rrtd {
-// On an open scene most bounce rays leave: on BASELINE config 4 three of four rays spawned at a hit find nothing, each after walking the ~18 ancestors of its own leaf
-// (they all contain the origin). A ray p + t d from a point p of triangle T can only meet geometry points q with (q - p) parallel to d - the same azimuth about an axis e,
-// the same elevation. So, per triangle T, hemisphere (+e / -e) and azimuth sector s (16 wedges, dtypes.hpp hz_sector):
+// On an open scene most bounce rays leave: on BASELINE config 4 three of four rays spawned at a hit find nothing, each after walking ~50 nodes (the ancestors of its own
+// leaf all contain the origin). A ray p + t d from a point p of triangle T can only meet geometry points q with (q - p) parallel to d - the same azimuth about an axis e,
+// the same elevation. So, per triangle T, hemisphere (+e / -e) and azimuth sector s (16 wedges, hz_sector()):
 //     H[T][+-][s] >= sup { +-(q - p).e / |q - p| :  p in T, q in any OTHER triangle, q != p, azimuth(q - p) in s }
 // and a ray from T whose |d.e| exceeds H in its hemisphere and sector provably misses everything: BVHAccel::intersect would return false. The bound must hold for
 // geometry that TOUCHES T as well (its neighbours: a valley wall starts on T's own edge), which is what shapes it:
 //  * every difference q - p is a convex combination of the nine vertex differences g = u_j - t_i (zero for shared vertices);
 //  * no shared vertex: (q - p).e <= max g.e =: vk and the horizontal part of q - p is at least the distance hmin of the origin from the convex hull of the projected g
-//    (lower bound: max over candidate directions n of min n.g_h), so the sine of the elevation is at most vk / sqrt(vk^2 + hmin^2); azimuths: the angular extent of
-//    the projected g (everything if hmin = 0: an overhang);
-//  * shared vertices: the directions form the CONE spanned by the non-zero g; for any n with n.g <= 0 for every generator, every direction v of the cone has
-//    n.v <= 0, hence e.v / |v| <= sqrt(1 - (n.e)^2) when n.e > 0 (decompose e along n); candidates n = +-(g_a x g_b) - the planes of T and of the neighbour are among them,
-//    which makes the bound the neighbour's slope in a valley - and 1 when none is valid; azimuths: the angular hull of the generators' projections (everything if they
-//    do not fit a half plane);
-//  * far geometry is bounded node by node with the same formula on boxes (B - bbox(T)), walking the tree and pruning what cannot raise H in any sector it touches.
+//    (the smallest distance to a segment between two of them, valid when all of them lie on the nearest point's side; else 0: an overhang), so the sine of the
+//    elevation is at most vk / sqrt(vk^2 + hmin^2); azimuths: between the most clockwise and the most counter-clockwise projected g (everything if hmin = 0);
+//  * near pairs and shared vertices: the directions form the CONE spanned by the non-zero g; for any n with n.g <= 0 for every generator, every direction v of the cone has
+//    n.v <= 0, which bounds the rise per unit of horizontal distance along each azimuth, sector by sector; candidates n = the planes through two generators - the planes
+//    of T and of the neighbour are among them, which makes the bound the neighbour's slope in a valley - all 72 of them for a cone that is not pointed, the (at most
+//    nine) faces of the generators' convex hull seen along their mean direction for one that is;
+//  * far geometry is bounded node by node with the plain formula on boxes (B - bbox(T)), walking the tree BEST FIRST (a heap keyed by the bound) and pruning what cannot
+//    raise H in any sector it touches;
+//  * the ray's origin is only NEAR T (HzTables::tau: the kernel's edge guard), so geometry that comes within 4 rho of T's interior - a crossing or resting triangle,
+//    one a hair above or below, a neighbour folded back over T at a shallow angle - takes T's tables away (the contact rules in pair_bound()).
 // e = the axis along which the root box is thinnest (a terrain's "up"). Stored as ceil(254 (H + kHzMargin)) + 1 per byte (255 = never); the margin (0.2 degrees at the
-// horizon) covers the fp32 rounding of the ray, of its origin on T and of the generators' plane tests. Exactness is tested: frames with and without the tables are
-// identical bit for bit (tests/test_gpu_parity.py::test_horizon_cull_changes_nothing), over terrains, enclosed boxes, stacked and touching geometry.
+// horizon) covers the fp32 rounding of the ray's direction and of the generators' plane tests. Exactness is tested: tests/test_horizon.py (no GPU: the builder's own
+// brute force and the oracle's traversal, origins on and rho off the triangles; terrains, boxes in every kind of contact) and, on the device, frames with and without
+// the tables identical bit for bit (tests/test_gpu_parity.py::test_horizon_cull_changes_nothing, ..._at_baseline_size).
 constexpr double kHzMargin = 0.004;
 // a triangle whose nearest point is at more than 1 / (kFar - 1) = 5 times the spread of the vertex differences gets the plain rise-over-distance bound only
 constexpr double kFar = 1.2;
