@@ -1100,10 +1100,7 @@ __global__ void __launch_bounds__((shade_path_block<R, KM>())) __attribute__((am
           bounces += 1;
           // the next loop iteration would trace and then break on `bounces >= max_depth` without using the
           // hit (emission is 0): that dead closest-hit query is not issued.
-#ifdef RRT_SKY_HACK   // premise experiment only (NOT exact): what the closest-hit launches would cost without the bounce rays that leave steeply upward
-          if (nd.y > R(RRT_SKY_HACK)) cont = false;
-#endif
-          // Horizon cull (SceneDev::horizon, rrt_impl.hpp build_horizons()): the next ray starts on triangle `prim`; if its elevation above / below the scene's
+          // Horizon cull (SceneDev::horizon, host/horizon_build.cpp): the next ray starts on triangle `prim`; if its elevation above / below the scene's
           // flattest axis exceeds everything the host found visible from ANY point of that triangle in the ray's azimuth sector, BVHAccel::intersect would
           // return false for it and the path would end at `if !found_intersection { break }` (path.rs:91) - it is counted as the closest-hit query it is, and not traced.
           if (cont && (int)bounces < s.max_depth && s.horizon != nullptr) {

@@ -156,7 +156,7 @@ struct SceneDev {
   // fp32 path integrator: the camera kernels answer a camera ray that misses the root box themselves (the test lane_ray_begin() makes, on the ray as stored:
   // such a ray is a miss, which the path integrator shades with nothing) instead of sending it through the queue - see camera_ray_meets_root()
   uint32_t root_cull;
-  // horizon tables (fp32 path integrator, rrt_impl.hpp build_horizons()): per triangle 2 x 16 bytes - hemisphere +hz_axis / -hz_axis, 16 azimuth sectors (hz_sector) -
+  // horizon tables (fp32 path integrator, host/horizon_build.cpp build_horizons()): per triangle 2 x 16 bytes - hemisphere +hz_axis / -hz_axis, 16 azimuth sectors (hz_sector) -
   // holding ceil(254 x sin(max elevation at which anything is visible from any point of the triangle in that sector)) + margin; null = off
   const uint8_t* horizon;
   const float* hz_tau;         // per triangle: the cull applies where min(barycentric) |n.d| > hz_tau (HzTables::tau: the ray's origin is only NEAR its triangle's plane)

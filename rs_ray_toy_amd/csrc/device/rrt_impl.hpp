@@ -1055,7 +1055,7 @@ class Handle : public HandleBase {
   TravScene trav_{};
   DevBuf<PairNode> pairs_;
   DevBuf<float> horizon_tau_;              // HzTables::tau
-  DevBuf<uint8_t> horizon_;                // horizon tables (build_horizons()): 32 bytes per triangle; empty = not built for this scene
+  DevBuf<uint8_t> horizon_;                // horizon tables (host/horizon_build.cpp): 32 bytes per triangle; empty = not built for this scene
   uint32_t hz_axis_ = 1u;
   bool horizon_on_ = true;                 // option "horizon_cull"
   double hz_build_s_ = 0.0;                // host seconds this handle spent building the tables when it was created (0: found in the process cache, or none built)
